@@ -1,0 +1,1211 @@
+/* x264_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Scalar CPU restatement of the arithmetic of x264 core 66's six DSP tables
+ * (pixel, dct/zigzag, quant, mc, predict, deblock).  It is the checker that
+ * the HIP path is compared with; nothing under x264_vs2008_amd/ may link,
+ * load or call it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it.
+ *
+ * Pinning: every entry is compared bit-for-bit with the reference's own C
+ * build (oracle/_ref/libx264ref.so, compiled from the reference sources where
+ * they lie) by oracle/gen_golden.py and with the committed vectors under
+ * tests/golden/ by tests/test_oracle_golden.py.
+ *
+ * R/ = x264-snapshot-20090216-2245/.  Each block cites the file:line whose
+ * behaviour it restates.  All arithmetic is C int (32-bit, arithmetic >>)
+ * unless a narrower store is written out, because the reference's narrowing
+ * stores (int16_t temporaries) are part of the observable result.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/x264hip_tables.h"
+
+#define FENC X264HIP_FENC_STRIDE
+#define FDEC X264HIP_FDEC_STRIDE
+
+typedef uint8_t  u8;
+typedef int16_t  i16;
+typedef uint16_t u16;
+typedef uint32_t u32;
+
+/* clip to 0..255, R/common/common.h:104-107 */
+static inline u8 clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : (u8)v; }
+static inline int clip3(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+static const int blk_w[10] = {16, 16, 8, 8, 8, 4, 4, 4, 2, 2};
+static const int blk_h[10] = {16, 8, 16, 8, 4, 8, 4, 2, 4, 2};
+
+/* ======================================================================
+ * P1/P6: SAD and SSD, R/common/pixel.c:40-96
+ * ==================================================================== */
+static int sad_wh(const u8 *a, int sa, const u8 *b, int sb, int w, int h)
+{
+    int acc = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++)
+            acc += abs(a[x] - b[x]);
+    return acc;
+}
+static int ssd_wh(const u8 *a, int sa, const u8 *b, int sb, int w, int h)
+{
+    int acc = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++) {
+            int d = a[x] - b[x];
+            acc += d * d;
+        }
+    return acc;
+}
+
+/* ======================================================================
+ * P3/P4/P5: Hadamard metrics.  The reference evaluates two 16-bit lanes
+ * inside one uint32 (R/common/pixel.c:164-181); carries between the lanes
+ * are observable on extreme inputs, so the same lane arithmetic is kept:
+ * a packed word holds lo + (hi << 16) modulo 2^32.
+ * ==================================================================== */
+static inline u32 lanes_abs(u32 v)
+{   /* |lo| + (|hi| << 16), R/common/pixel.c:177-181 */
+    u32 m = ((v >> 15) & 0x10001u) * 0xffffu;
+    return (v + m) ^ m;
+}
+static inline void wht4(u32 *o0, u32 *o1, u32 *o2, u32 *o3, u32 i0, u32 i1, u32 i2, u32 i3)
+{   /* 4-point butterfly, output order of R/common/pixel.c:164-173 */
+    u32 p = i0 + i1, q = i0 - i1, r = i2 + i3, s = i2 - i3;
+    *o0 = p + r; *o2 = p - r; *o1 = q + s; *o3 = q - s;
+}
+
+/* 4x4 block: lanes carry (sum, difference) of neighbouring columns.
+ * R/common/pixel.c:187-212 */
+static int satd4x4_raw(const u8 *a, int sa, const u8 *b, int sb)
+{
+    u32 col[2][4];
+    for (int y = 0; y < 4; y++, a += sa, b += sb) {
+        u32 d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3];
+        u32 e0 = (d0 + d1) + ((d0 - d1) << 16);
+        u32 e1 = (d2 + d3) + ((d2 - d3) << 16);
+        col[0][y] = e0 + e1;
+        col[1][y] = e0 - e1;
+    }
+    int total = 0;
+    for (int c = 0; c < 2; c++) {
+        u32 t0, t1, t2, t3;
+        wht4(&t0, &t1, &t2, &t3, col[c][0], col[c][1], col[c][2], col[c][3]);
+        u32 m = lanes_abs(t0) + lanes_abs(t1) + lanes_abs(t2) + lanes_abs(t3);
+        total += (u16)m + (m >> 16);
+    }
+    return total >> 1;
+}
+/* 8x4 block: lane lo = left 4x4, lane hi = right 4x4; one shift at the end.
+ * R/common/pixel.c:214-233 */
+static int satd8x4_raw(const u8 *a, int sa, const u8 *b, int sb)
+{
+    u32 t[4][4];
+    for (int y = 0; y < 4; y++, a += sa, b += sb) {
+        u32 d[4];
+        for (int x = 0; x < 4; x++)
+            d[x] = (u32)(a[x] - b[x]) + ((u32)(a[x + 4] - b[x + 4]) << 16);
+        wht4(&t[y][0], &t[y][1], &t[y][2], &t[y][3], d[0], d[1], d[2], d[3]);
+    }
+    u32 acc = 0;
+    for (int x = 0; x < 4; x++) {
+        u32 v0, v1, v2, v3;
+        wht4(&v0, &v1, &v2, &v3, t[0][x], t[1][x], t[2][x], t[3][x]);
+        acc += lanes_abs(v0) + lanes_abs(v1) + lanes_abs(v2) + lanes_abs(v3);
+    }
+    return (int)(((u16)acc + (acc >> 16)) >> 1);
+}
+/* composites: sum of 8x4 results (4x8 = two 4x4), R/common/pixel.c:235-253 */
+static int satd_wh(const u8 *a, int sa, const u8 *b, int sb, int w, int h)
+{
+    int acc = 0;
+    if (w == 4) {
+        for (int y = 0; y < h; y += 4)
+            acc += satd4x4_raw(a + y * sa, sa, b + y * sb, sb);
+        return acc;
+    }
+    for (int y = 0; y < h; y += 4)
+        for (int x = 0; x < w; x += 8)
+            acc += satd8x4_raw(a + y * sa + x, sa, b + y * sb + x, sb);
+    return acc;
+}
+
+/* 8x8 Hadamard, unnormalised sum; R/common/pixel.c:256-289 */
+static int sa8d_raw(const u8 *a, int sa, const u8 *b, int sb)
+{
+    u32 t[8][4];
+    for (int y = 0; y < 8; y++, a += sa, b += sb) {
+        u32 e[4];
+        for (int k = 0; k < 4; k++) {
+            u32 d0 = a[2 * k] - b[2 * k], d1 = a[2 * k + 1] - b[2 * k + 1];
+            e[k] = (d0 + d1) + ((d0 - d1) << 16);
+        }
+        wht4(&t[y][0], &t[y][1], &t[y][2], &t[y][3], e[0], e[1], e[2], e[3]);
+    }
+    int total = 0;
+    for (int x = 0; x < 4; x++) {
+        u32 u[4], v[4];
+        wht4(&u[0], &u[1], &u[2], &u[3], t[0][x], t[1][x], t[2][x], t[3][x]);
+        wht4(&v[0], &v[1], &v[2], &v[3], t[4][x], t[5][x], t[6][x], t[7][x]);
+        u32 m = 0;
+        for (int k = 0; k < 4; k++)
+            m += lanes_abs(u[k] + v[k]) + lanes_abs(u[k] - v[k]);
+        total += (u16)m + (m >> 16);
+    }
+    return total;
+}
+static int sa8d_8x8(u8 *a, int sa, u8 *b, int sb)
+{   /* R/common/pixel.c:291-295 */
+    return (sa8d_raw(a, sa, b, sb) + 2) >> 2;
+}
+static int sa8d_16x16(u8 *a, int sa, u8 *b, int sb)
+{   /* four raw sums, then one rounding; R/common/pixel.c:297-304 */
+    int s = sa8d_raw(a, sa, b, sb) + sa8d_raw(a + 8, sa, b + 8, sb)
+          + sa8d_raw(a + 8 * sa, sa, b + 8 * sb, sb)
+          + sa8d_raw(a + 8 * sa + 8, sa, b + 8 * sb + 8, sb);
+    return (s + 2) >> 2;
+}
+
+/* AC energy of the 4x4 and 8x8 Hadamard of one 8x8 source block.
+ * R/common/pixel.c:306-344 */
+static uint64_t hadamard_ac_8x8_raw(const u8 *p, int stride)
+{
+    u32 w[32];
+    for (int y = 0; y < 8; y++, p += stride) {
+        /* slot layout: rows 0-3 -> words 0..15, rows 4-7 -> words 16..31;
+         * inside a 16-word group, word = 4*coefficient_pair + row */
+        u32 *g = w + (y & 3) + (y & 4) * 4;
+        u32 e0 = (u32)(p[0] + p[1]) + ((u32)(p[0] - p[1]) << 16);
+        u32 e1 = (u32)(p[2] + p[3]) + ((u32)(p[2] - p[3]) << 16);
+        u32 e2 = (u32)(p[4] + p[5]) + ((u32)(p[4] - p[5]) << 16);
+        u32 e3 = (u32)(p[6] + p[7]) + ((u32)(p[6] - p[7]) << 16);
+        g[0] = e0 + e1;  g[4]  = e0 - e1;
+        g[8] = e2 + e3;  g[12] = e2 - e3;
+    }
+    u32 acc4 = 0, acc8 = 0;
+    for (int k = 0; k < 8; k++) {
+        u32 *q = w + 4 * k;
+        wht4(&q[0], &q[1], &q[2], &q[3], q[0], q[1], q[2], q[3]);
+        acc4 += lanes_abs(q[0]) + lanes_abs(q[1]) + lanes_abs(q[2]) + lanes_abs(q[3]);
+    }
+    for (int k = 0; k < 8; k++) {
+        u32 v0, v1, v2, v3;
+        wht4(&v0, &v1, &v2, &v3, w[k], w[8 + k], w[16 + k], w[24 + k]);
+        acc8 += lanes_abs(v0) + lanes_abs(v1) + lanes_abs(v2) + lanes_abs(v3);
+    }
+    u32 dc = (u16)(w[0] + w[8] + w[16] + w[24]);
+    int s4 = (int)((u16)acc4 + (acc4 >> 16) - dc);
+    int s8 = (int)((u16)acc8 + (acc8 >> 16) - dc);
+    return ((uint64_t)s8 << 32) + s4;
+}
+static uint64_t hadamard_ac_wh(const u8 *p, int stride, int w, int h)
+{   /* R/common/pixel.c:346-358 */
+    uint64_t s = 0;
+    for (int y = 0; y < h; y += 8)
+        for (int x = 0; x < w; x += 8)
+            s += hadamard_ac_8x8_raw(p + y * stride + x, stride);
+    return ((s >> 34) << 32) + ((u32)s >> 1);
+}
+
+/* P7: variance, R/common/pixel.c:142-161 */
+static int var_n(const u8 *p, int stride, int n, int shift)
+{
+    u32 sum = 0, sqr = 0;
+    for (int y = 0; y < n; y++, p += stride)
+        for (int x = 0; x < n; x++) {
+            sum += p[x];
+            sqr += p[x] * p[x];
+        }
+    return (int)(sqr - (sum * sum >> shift));
+}
+
+/* P8: SSIM, R/common/pixel.c:435-509 (float; -ffp-contract=off on this file) */
+static void o_ssim_4x4x2_core(const u8 *p1, int s1, const u8 *p2, int s2, int sums[2][4])
+{
+    for (int z = 0; z < 2; z++, p1 += 4, p2 += 4) {
+        u32 a1 = 0, a2 = 0, aa = 0, ab = 0;
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int u = p1[x + y * s1], v = p2[x + y * s2];
+                a1 += u; a2 += v; aa += u * u + v * v; ab += u * v;
+            }
+        sums[z][0] = a1; sums[z][1] = a2; sums[z][2] = aa; sums[z][3] = ab;
+    }
+}
+static float ssim_one(int s1, int s2, int ss, int s12)
+{
+    const int c1 = (int)(.01 * .01 * 255 * 255 * 64 + .5);
+    const int c2 = (int)(.03 * .03 * 255 * 255 * 64 * 63 + .5);
+    int vars = ss * 64 - s1 * s1 - s2 * s2;
+    int covar = s12 * 64 - s1 * s2;
+    float num = (float)(2 * s1 * s2 + c1) * (float)(2 * covar + c2);
+    float den = (float)(s1 * s1 + s2 * s2 + c1) * (float)(vars + c2);
+    return num / den;
+}
+static float o_ssim_end4(int sum0[5][4], int sum1[5][4], int width)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < width; i++)
+        acc += ssim_one(sum0[i][0] + sum0[i + 1][0] + sum1[i][0] + sum1[i + 1][0],
+                        sum0[i][1] + sum0[i + 1][1] + sum1[i][1] + sum1[i + 1][1],
+                        sum0[i][2] + sum0[i + 1][2] + sum1[i][2] + sum1[i + 1][2],
+                        sum0[i][3] + sum0[i + 1][3] + sum1[i][3] + sum1[i + 1][3]);
+    return acc;
+}
+
+/* plane drivers, R/common/pixel.c:98-136 and :471-496 */
+int64_t x264o_pixel_ssd_wxh(u8 *p1, int s1, u8 *p2, int s2, int width, int height)
+{
+    int64_t acc = 0;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int d = p1[y * s1 + x] - p2[y * s2 + x];
+            acc += d * d;
+        }
+    return acc;
+}
+float x264o_pixel_ssim_wxh(u8 *p1, int s1, u8 *p2, int s2, int width, int height, void *buf)
+{
+    int (*row_a)[4] = buf;
+    int (*row_b)[4] = row_a + width / 4 + 3;
+    float acc = 0.0f;
+    int z = 0;
+    width >>= 2; height >>= 2;
+    for (int y = 1; y < height; y++) {
+        for (; z <= y; z++) {
+            int (*t)[4] = row_a; row_a = row_b; row_b = t;
+            for (int x = 0; x < width; x += 2)
+                o_ssim_4x4x2_core(&p1[4 * (x + z * s1)], s1, &p2[4 * (x + z * s2)], s2, &row_a[x]);
+        }
+        for (int x = 0; x < width - 1; x += 4) {
+            int n = width - x - 1; if (n > 4) n = 4;
+            acc += o_ssim_end4(row_a + x, row_b + x, n);
+        }
+    }
+    return acc;
+}
+
+/* P9: successive-elimination prefilter, R/common/pixel.c:515-559 */
+static int ads_n(int n, int *dc, u16 *sums, int delta, u16 *cost, i16 *mvs, int width, int thresh)
+{
+    int found = 0;
+    for (int i = 0; i < width; i++, sums++) {
+        int v = abs(dc[0] - sums[0]) + cost[i];
+        if (n == 2) v += abs(dc[1] - sums[delta]);
+        if (n == 4) v += abs(dc[1] - sums[8]) + abs(dc[2] - sums[delta]) + abs(dc[3] - sums[delta + 8]);
+        if (v < thresh) mvs[found++] = i;
+    }
+    return found;
+}
+static int o_ads4(int dc[4], u16 *s, int d, u16 *c, i16 *m, int w, int t) { return ads_n(4, dc, s, d, c, m, w, t); }
+static int o_ads2(int dc[4], u16 *s, int d, u16 *c, i16 *m, int w, int t) { return ads_n(2, dc, s, d, c, m, w, t); }
+static int o_ads1(int dc[4], u16 *s, int d, u16 *c, i16 *m, int w, int t) { return ads_n(1, dc, s, d, c, m, w, t); }
+
+/* per-size entry points (the table needs one address per size) */
+#define CMP_ENTRY(op, W, H) \
+    static int o_##op##_##W##x##H(u8 *a, int sa, u8 *b, int sb) { return op##_wh(a, sa, b, sb, W, H); }
+#define X34_ENTRY(op, W, H) \
+    static void o_##op##_x3_##W##x##H(u8 *f, u8 *p0, u8 *p1, u8 *p2, int s, int r[3]) { \
+        r[0] = op##_wh(f, FENC, p0, s, W, H); r[1] = op##_wh(f, FENC, p1, s, W, H); \
+        r[2] = op##_wh(f, FENC, p2, s, W, H); } \
+    static void o_##op##_x4_##W##x##H(u8 *f, u8 *p0, u8 *p1, u8 *p2, u8 *p3, int s, int r[4]) { \
+        r[0] = op##_wh(f, FENC, p0, s, W, H); r[1] = op##_wh(f, FENC, p1, s, W, H); \
+        r[2] = op##_wh(f, FENC, p2, s, W, H); r[3] = op##_wh(f, FENC, p3, s, W, H); }
+#define ALL7(M, op) M(op,16,16) M(op,16,8) M(op,8,16) M(op,8,8) M(op,8,4) M(op,4,8) M(op,4,4)
+ALL7(CMP_ENTRY, sad) ALL7(CMP_ENTRY, ssd) ALL7(CMP_ENTRY, satd)
+ALL7(X34_ENTRY, sad) ALL7(X34_ENTRY, satd)
+#define FILL7(dst, op) do { dst[0]=o_##op##_16x16; dst[1]=o_##op##_16x8; dst[2]=o_##op##_8x16; \
+    dst[3]=o_##op##_8x8; dst[4]=o_##op##_8x4; dst[5]=o_##op##_4x8; dst[6]=o_##op##_4x4; } while (0)
+
+static int o_var_16x16(u8 *p, int s) { return var_n(p, s, 16, 8); }
+static int o_var_8x8(u8 *p, int s)   { return var_n(p, s, 8, 6); }
+static uint64_t o_hac_16x16(u8 *p, int s) { return hadamard_ac_wh(p, s, 16, 16); }
+static uint64_t o_hac_16x8(u8 *p, int s)  { return hadamard_ac_wh(p, s, 16, 8); }
+static uint64_t o_hac_8x16(u8 *p, int s)  { return hadamard_ac_wh(p, s, 8, 16); }
+static uint64_t o_hac_8x8(u8 *p, int s)   { return hadamard_ac_wh(p, s, 8, 8); }
+
+/* x264_pixel_init with cpu=0, R/common/pixel.c:565-613; the derived
+ * mbcmp/fpelcmp slots are left NULL exactly as x264_pixel_init leaves them
+ * (mbcmp_init fills them later, R/encoder/encoder.c:608-618). */
+void x264o_pixel_init(x264hip_pixel_function_t *pf)
+{
+    memset(pf, 0, sizeof(*pf));
+    FILL7(pf->sad, sad); FILL7(pf->sad_aligned, sad); FILL7(pf->ssd, ssd); FILL7(pf->satd, satd);
+    FILL7(pf->sad_x3, sad_x3); FILL7(pf->sad_x4, sad_x4);
+    FILL7(pf->satd_x3, satd_x3); FILL7(pf->satd_x4, satd_x4);
+    pf->hadamard_ac[0] = o_hac_16x16; pf->hadamard_ac[1] = o_hac_16x8;
+    pf->hadamard_ac[2] = o_hac_8x16;  pf->hadamard_ac[3] = o_hac_8x8;
+    pf->ads[X264HIP_PIXEL_16x16] = o_ads4; pf->ads[X264HIP_PIXEL_16x8] = o_ads2;
+    pf->ads[X264HIP_PIXEL_8x8] = o_ads1;
+    pf->sa8d[X264HIP_PIXEL_16x16] = sa8d_16x16; pf->sa8d[X264HIP_PIXEL_8x8] = sa8d_8x8;
+    pf->var[X264HIP_PIXEL_16x16] = o_var_16x16; pf->var[X264HIP_PIXEL_8x8] = o_var_8x8;
+    pf->ssim_4x4x2_core = o_ssim_4x4x2_core;
+    pf->ssim_end4 = o_ssim_end4;
+}
+
+/* ======================================================================
+ * D1-D5: transforms and scans, R/common/dct.c
+ * ==================================================================== */
+/* forward 4x4 core transform on a residual, R/common/dct.c:122-155.
+ * The intermediate is held in int16 as the reference does. */
+static void fwd4(i16 out[16], const i16 in[16])
+{
+    i16 mid[16];
+    for (int r = 0; r < 4; r++) {
+        int a = in[4 * r] + in[4 * r + 3], b = in[4 * r + 1] + in[4 * r + 2];
+        int c = in[4 * r] - in[4 * r + 3], d = in[4 * r + 1] - in[4 * r + 2];
+        mid[0 + r] = a + b; mid[4 + r] = 2 * c + d; mid[8 + r] = a - b; mid[12 + r] = c - 2 * d;
+    }
+    for (int r = 0; r < 4; r++) {
+        int a = mid[4 * r] + mid[4 * r + 3], b = mid[4 * r + 1] + mid[4 * r + 2];
+        int c = mid[4 * r] - mid[4 * r + 3], d = mid[4 * r + 1] - mid[4 * r + 2];
+        out[4 * r] = a + b; out[4 * r + 1] = 2 * c + d; out[4 * r + 2] = a - b; out[4 * r + 3] = c - 2 * d;
+    }
+}
+static void o_sub4x4_dct(i16 dct[4][4], u8 *p1, u8 *p2)
+{
+    i16 res[16];
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+            res[4 * y + x] = p1[y * FENC + x] - p2[y * FDEC + x];
+    fwd4(&dct[0][0], res);
+}
+static void o_sub8x8_dct(i16 dct[4][4][4], u8 *p1, u8 *p2)
+{   /* R/common/dct.c:157-163 */
+    for (int k = 0; k < 4; k++)
+        o_sub4x4_dct(dct[k], p1 + (k >> 1) * 4 * FENC + (k & 1) * 4, p2 + (k >> 1) * 4 * FDEC + (k & 1) * 4);
+}
+static void o_sub16x16_dct(i16 dct[16][4][4], u8 *p1, u8 *p2)
+{   /* R/common/dct.c:165-171 */
+    for (int k = 0; k < 4; k++)
+        o_sub8x8_dct(&dct[4 * k], p1 + (k >> 1) * 8 * FENC + (k & 1) * 8, p2 + (k >> 1) * 8 * FDEC + (k & 1) * 8);
+}
+/* inverse 4x4 + add, R/common/dct.c:174-216 */
+static void o_add4x4_idct(u8 *dst, i16 dct[4][4])
+{
+    i16 mid[4][4], res[4][4];
+    for (int c = 0; c < 4; c++) {
+        int e = dct[0][c] + dct[2][c], f = dct[0][c] - dct[2][c];
+        int g = dct[1][c] + (dct[3][c] >> 1), h = (dct[1][c] >> 1) - dct[3][c];
+        mid[c][0] = e + g; mid[c][1] = f + h; mid[c][2] = f - h; mid[c][3] = e - g;
+    }
+    for (int c = 0; c < 4; c++) {
+        int e = mid[0][c] + mid[2][c], f = mid[0][c] - mid[2][c];
+        int g = mid[1][c] + (mid[3][c] >> 1), h = (mid[1][c] >> 1) - mid[3][c];
+        res[0][c] = (e + g + 32) >> 6; res[1][c] = (f + h + 32) >> 6;
+        res[2][c] = (f - h + 32) >> 6; res[3][c] = (e - g + 32) >> 6;
+    }
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+            dst[y * FDEC + x] = clip_u8(dst[y * FDEC + x] + res[y][x]);
+}
+static void o_add8x8_idct(u8 *dst, i16 dct[4][4][4])
+{
+    for (int k = 0; k < 4; k++)
+        o_add4x4_idct(dst + (k >> 1) * 4 * FDEC + (k & 1) * 4, dct[k]);
+}
+static void o_add16x16_idct(u8 *dst, i16 dct[16][4][4])
+{
+    for (int k = 0; k < 4; k++)
+        o_add8x8_idct(dst + (k >> 1) * 8 * FDEC + (k & 1) * 8, &dct[4 * k]);
+}
+/* DC-only reconstruction, R/common/dct.c:351-382 */
+static void add_dc4(u8 *dst, i16 dc)
+{
+    dc = (dc + 32) >> 6;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+            dst[y * FDEC + x] = clip_u8(dst[y * FDEC + x] + dc);
+}
+static void o_add8x8_idct_dc(u8 *dst, i16 dct[2][2])
+{
+    for (int k = 0; k < 4; k++)
+        add_dc4(dst + (k >> 1) * 4 * FDEC + (k & 1) * 4, dct[k >> 1][k & 1]);
+}
+static void o_add16x16_idct_dc(u8 *dst, i16 dct[4][4])
+{
+    for (int k = 0; k < 16; k++)
+        add_dc4(dst + (k >> 2) * 4 * FDEC + (k & 3) * 4, dct[k >> 2][k & 3]);
+}
+
+/* 8-point forward / inverse lifting steps, R/common/dct.c:238-261, :295-321 */
+static void fwd8_1d(int o[8], const int s[8])
+{
+    int p07 = s[0] + s[7], p16 = s[1] + s[6], p25 = s[2] + s[5], p34 = s[3] + s[4];
+    int m07 = s[0] - s[7], m16 = s[1] - s[6], m25 = s[2] - s[5], m34 = s[3] - s[4];
+    int a0 = p07 + p34, a1 = p16 + p25, a2 = p07 - p34, a3 = p16 - p25;
+    int a4 = m16 + m25 + (m07 + (m07 >> 1));
+    int a5 = m07 - m34 - (m25 + (m25 >> 1));
+    int a6 = m07 + m34 - (m16 + (m16 >> 1));
+    int a7 = m16 - m25 + (m34 + (m34 >> 1));
+    o[0] = a0 + a1;        o[1] = a4 + (a7 >> 2);
+    o[2] = a2 + (a3 >> 1); o[3] = a5 + (a6 >> 2);
+    o[4] = a0 - a1;        o[5] = a6 - (a5 >> 2);
+    o[6] = (a2 >> 1) - a3; o[7] = (a4 >> 2) - a7;
+}
+static void inv8_1d(int o[8], const int s[8])
+{
+    int a0 = s[0] + s[4], a2 = s[0] - s[4];
+    int a4 = (s[2] >> 1) - s[6], a6 = (s[6] >> 1) + s[2];
+    int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    int a1 = -s[3] + s[5] - s[7] - (s[7] >> 1);
+    int a3 =  s[1] + s[7] - s[3] - (s[3] >> 1);
+    int a5 = -s[1] + s[7] + s[5] + (s[5] >> 1);
+    int a7 =  s[3] + s[5] + s[1] + (s[1] >> 1);
+    int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    o[0] = b0 + b7; o[1] = b2 + b5; o[2] = b4 + b3; o[3] = b6 + b1;
+    o[4] = b6 - b1; o[5] = b4 - b3; o[6] = b2 - b5; o[7] = b0 - b7;
+}
+static void o_sub8x8_dct8(i16 dct[8][8], u8 *p1, u8 *p2)
+{   /* R/common/dct.c:263-284: columns first (in place, int16), then rows,
+     * written transposed */
+    i16 t[8][8];
+    int s[8], o[8];
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++)
+            t[y][x] = p1[y * FENC + x] - p2[y * FDEC + x];
+    for (int c = 0; c < 8; c++) {
+        for (int k = 0; k < 8; k++) s[k] = t[k][c];
+        fwd8_1d(o, s);
+        for (int k = 0; k < 8; k++) t[k][c] = o[k];
+    }
+    for (int r = 0; r < 8; r++) {
+        for (int k = 0; k < 8; k++) s[k] = t[r][k];
+        fwd8_1d(o, s);
+        for (int k = 0; k < 8; k++) dct[k][r] = o[k];
+    }
+}
+static void o_sub16x16_dct8(i16 dct[4][8][8], u8 *p1, u8 *p2)
+{
+    for (int k = 0; k < 4; k++)
+        o_sub8x8_dct8(dct[k], p1 + (k >> 1) * 8 * FENC + (k & 1) * 8, p2 + (k >> 1) * 8 * FDEC + (k & 1) * 8);
+}
+static void o_add8x8_idct8(u8 *dst, i16 dct[8][8])
+{   /* R/common/dct.c:323-341: mutates its input (rounding term + first pass) */
+    int s[8], o[8];
+    dct[0][0] += 32;
+    for (int c = 0; c < 8; c++) {
+        for (int k = 0; k < 8; k++) s[k] = dct[k][c];
+        inv8_1d(o, s);
+        for (int k = 0; k < 8; k++) dct[k][c] = o[k];
+    }
+    for (int r = 0; r < 8; r++) {
+        for (int k = 0; k < 8; k++) s[k] = dct[r][k];
+        inv8_1d(o, s);
+        for (int k = 0; k < 8; k++)
+            dst[r + k * FDEC] = clip_u8(dst[r + k * FDEC] + (o[k] >> 6));
+    }
+}
+static void o_add16x16_idct8(u8 *dst, i16 dct[4][8][8])
+{
+    for (int k = 0; k < 4; k++)
+        o_add8x8_idct8(dst + (k >> 1) * 8 * FDEC + (k & 1) * 8, dct[k]);
+}
+/* luma DC Hadamard, R/common/dct.c:39-105 (int16 intermediate) */
+static void dc_hadamard(i16 d[4][4], int round)
+{
+    i16 t[4][4];
+    for (int r = 0; r < 4; r++) {
+        int a = d[r][0] + d[r][1], b = d[r][0] - d[r][1], c = d[r][2] + d[r][3], e = d[r][2] - d[r][3];
+        t[0][r] = a + c; t[1][r] = a - c; t[2][r] = b - e; t[3][r] = b + e;
+    }
+    for (int r = 0; r < 4; r++) {
+        int a = t[r][0] + t[r][1], b = t[r][0] - t[r][1], c = t[r][2] + t[r][3], e = t[r][2] - t[r][3];
+        d[r][0] = (a + c + round) >> round; d[r][1] = (a - c + round) >> round;
+        d[r][2] = (b - e + round) >> round; d[r][3] = (b + e + round) >> round;
+    }
+}
+static void o_dct4x4dc(i16 d[4][4])  { dc_hadamard(d, 1); }
+static void o_idct4x4dc(i16 d[4][4]) { dc_hadamard(d, 0); }
+
+void x264o_dct_init(x264hip_dct_function_t *f)
+{   /* R/common/dct.c:388-410 */
+    f->sub4x4_dct = o_sub4x4_dct;     f->add4x4_idct = o_add4x4_idct;
+    f->sub8x8_dct = o_sub8x8_dct;     f->add8x8_idct = o_add8x8_idct;
+    f->add8x8_idct_dc = o_add8x8_idct_dc;
+    f->sub16x16_dct = o_sub16x16_dct; f->add16x16_idct = o_add16x16_idct;
+    f->add16x16_idct_dc = o_add16x16_idct_dc;
+    f->sub8x8_dct8 = o_sub8x8_dct8;   f->add8x8_idct8 = o_add8x8_idct8;
+    f->sub16x16_dct8 = o_sub16x16_dct8; f->add16x16_idct8 = o_add16x16_idct8;
+    f->dct4x4dc = o_dct4x4dc;         f->idct4x4dc = o_idct4x4dc;
+}
+
+/* Scan orders as flat indices into the reference's coefficient storage
+ * (which is transposed: index = column*N + row), i.e. the i-th scanned
+ * coefficient is coef[scan[i]].  R/common/dct.c:488-562. */
+const u8 x264o_scan4[2][16] = {
+    { 0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15 },
+    { 0, 1, 4, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 } };
+const u8 x264o_scan8[2][64] = {
+    { 0, 8, 1, 2, 9, 16, 24, 17, 10, 3, 4, 11, 18, 25, 32, 40,
+      33, 26, 19, 12, 5, 6, 13, 20, 27, 34, 41, 48, 56, 49, 42, 35,
+      28, 21, 14, 7, 15, 22, 29, 36, 43, 50, 57, 58, 51, 44, 37, 30,
+      23, 31, 38, 45, 52, 59, 60, 53, 46, 39, 47, 54, 61, 62, 55, 63 },
+    { 0, 1, 2, 8, 9, 3, 4, 10, 16, 11, 5, 6, 7, 12, 17, 24,
+      18, 13, 14, 15, 19, 25, 32, 26, 20, 21, 22, 23, 27, 33, 40, 34,
+      28, 29, 30, 31, 35, 41, 48, 42, 36, 37, 38, 39, 43, 49, 50, 44,
+      45, 46, 47, 51, 56, 57, 52, 53, 54, 55, 58, 59, 60, 61, 62, 63 } };
+
+#define SCAN_ENTRIES(tag, fld) \
+static void o_scan8_##tag(i16 lv[64], i16 d[8][8]) { for (int i = 0; i < 64; i++) lv[i] = d[0][x264o_scan8[fld][i]]; } \
+static void o_scan4_##tag(i16 lv[16], i16 d[4][4]) { for (int i = 0; i < 16; i++) lv[i] = d[0][x264o_scan4[fld][i]]; } \
+static void o_zsub8_##tag(i16 lv[64], const u8 *s, u8 *d) { /* R/common/dct.c:564-606 (lossless) */ \
+    for (int i = 0; i < 64; i++) { int k = x264o_scan8[fld][i], x = k >> 3, y = k & 7; lv[i] = s[x + y * FENC] - d[x + y * FDEC]; } \
+    for (int y = 0; y < 8; y++) memcpy(d + y * FDEC, s + y * FENC, 8); } \
+static void o_zsub4_##tag(i16 lv[16], const u8 *s, u8 *d) { \
+    for (int i = 0; i < 16; i++) { int k = x264o_scan4[fld][i], x = k >> 2, y = k & 3; lv[i] = s[x + y * FENC] - d[x + y * FDEC]; } \
+    for (int y = 0; y < 4; y++) memcpy(d + y * FDEC, s + y * FENC, 4); }
+SCAN_ENTRIES(frame, 0)
+SCAN_ENTRIES(field, 1)
+
+static void o_interleave_8x8_cavlc(i16 *dst, i16 *src, u8 *nnz)
+{   /* R/common/dct.c:611-624 */
+    for (int g = 0; g < 4; g++) {
+        int any = 0;
+        for (int j = 0; j < 16; j++) {
+            any |= src[g + 4 * j];
+            dst[16 * g + j] = src[g + 4 * j];
+        }
+        nnz[(g & 1) + (g >> 1) * 8] = !!any;
+    }
+}
+void x264o_zigzag_init(x264hip_zigzag_function_t *f, int b_interlaced)
+{   /* R/common/dct.c:626-677 */
+    if (b_interlaced) {
+        f->scan_8x8 = o_scan8_field; f->scan_4x4 = o_scan4_field;
+        f->sub_8x8 = o_zsub8_field;  f->sub_4x4 = o_zsub4_field;
+    } else {
+        f->scan_8x8 = o_scan8_frame; f->scan_4x4 = o_scan4_frame;
+        f->sub_8x8 = o_zsub8_frame;  f->sub_4x4 = o_zsub4_frame;
+    }
+    f->interleave_8x8_cavlc = o_interleave_8x8_cavlc;
+}
+
+/* ======================================================================
+ * Q1-Q6: quantisation, R/common/quant.c
+ * ==================================================================== */
+/* R/common/quant.c:33-40.  The product is formed in 32-bit int (it wraps
+ * for out-of-range inputs exactly as the reference's int arithmetic does
+ * under gcc); the store narrows to int16. */
+static inline int quant_one(i16 *c, int mf, int bias)
+{
+    int v = *c;
+    if (v > 0) v = (int)((u32)(bias + v) * (u32)mf) >> 16;
+    else       v = -((int)((u32)(bias - v) * (u32)mf) >> 16);
+    *c = (i16)v;
+    return v;
+}
+static int o_quant_8x8(i16 d[8][8], u16 mf[64], u16 bias[64])
+{
+    int nz = 0;
+    for (int i = 0; i < 64; i++) nz |= quant_one(&d[0][i], mf[i], bias[i]);
+    return !!nz;
+}
+static int o_quant_4x4(i16 d[4][4], u16 mf[16], u16 bias[16])
+{
+    int nz = 0;
+    for (int i = 0; i < 16; i++) nz |= quant_one(&d[0][i], mf[i], bias[i]);
+    return !!nz;
+}
+static int o_quant_4x4_dc(i16 d[4][4], int mf, int bias)
+{
+    int nz = 0;
+    for (int i = 0; i < 16; i++) nz |= quant_one(&d[0][i], mf, bias);
+    return !!nz;
+}
+static int o_quant_2x2_dc(i16 d[2][2], int mf, int bias)
+{
+    int nz = 0;
+    for (int i = 0; i < 4; i++) nz |= quant_one(&d[0][i], mf, bias);
+    return !!nz;
+}
+/* R/common/quant.c:76-178 */
+static void dequant_n(i16 *d, const int *mf, int n, int shift_base, int qp)
+{
+    const int *m = mf + (qp % 6) * n;
+    int bits = qp / 6 - shift_base;
+    if (bits >= 0)
+        for (int i = 0; i < n; i++) d[i] = (i16)((d[i] * m[i]) << bits);
+    else {
+        int half = 1 << (-bits - 1);
+        for (int i = 0; i < n; i++) d[i] = (i16)((d[i] * m[i] + half) >> -bits);
+    }
+}
+static void o_dequant_4x4(i16 d[4][4], int mf[6][4][4], int qp) { dequant_n(&d[0][0], &mf[0][0][0], 16, 4, qp); }
+static void o_dequant_8x8(i16 d[8][8], int mf[6][8][8], int qp) { dequant_n(&d[0][0], &mf[0][0][0], 64, 6, qp); }
+static void o_dequant_4x4_dc(i16 d[4][4], int mf[6][4][4], int qp)
+{
+    int bits = qp / 6 - 6;
+    if (bits >= 0) {
+        int m = mf[qp % 6][0][0] << bits;
+        for (int i = 0; i < 16; i++) d[0][i] = (i16)(d[0][i] * m);
+    } else {
+        int m = mf[qp % 6][0][0], half = 1 << (-bits - 1);
+        for (int i = 0; i < 16; i++) d[0][i] = (i16)((d[0][i] * m + half) >> -bits);
+    }
+}
+static void o_denoise_dct(i16 *d, u32 *sum, u16 *offset, int size)
+{   /* R/common/quant.c:180-192; DC (index 0) is never touched */
+    for (int i = 1; i < size; i++) {
+        int v = d[i], neg = v >> 15;
+        int mag = (v + neg) ^ neg;
+        sum[i] += mag;
+        mag -= offset[i];
+        d[i] = mag < 0 ? 0 : (i16)((mag ^ neg) - neg);
+    }
+}
+/* R/common/quant.c:203-252 */
+static int decimate(const i16 *d, int n)
+{
+    static const u8 small[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const u8 big[64] = {3,3,3,3,2,2,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1};
+    const u8 *tab = n == 64 ? big : small;
+    int i = n - 1, score = 0;
+    while (i >= 0 && d[i] == 0) i--;
+    while (i >= 0) {
+        if ((unsigned)(d[i--] + 1) > 2) return 9;
+        int run = 0;
+        while (i >= 0 && d[i] == 0) { i--; run++; }
+        score += tab[run];
+    }
+    return score;
+}
+static int o_decimate15(i16 *d) { return decimate(d + 1, 15); }
+static int o_decimate16(i16 *d) { return decimate(d, 16); }
+static int o_decimate64(i16 *d) { return decimate(d, 64); }
+/* R/common/quant.c:254-300 */
+static int last_nz(const i16 *d, int n) { int i = n - 1; while (i >= 0 && d[i] == 0) i--; return i; }
+static int o_last4(i16 *d)  { return last_nz(d, 4); }
+static int o_last15(i16 *d) { return last_nz(d, 15); }
+static int o_last16(i16 *d) { return last_nz(d, 16); }
+static int o_last64(i16 *d) { return last_nz(d, 64); }
+static int level_run(i16 *d, x264hip_run_level_t *rl, int n)
+{
+    int i = rl->last = last_nz(d, n), total = 0;
+    do {
+        int run = 0;
+        rl->level[total] = d[i];
+        while (--i >= 0 && d[i] == 0) run++;
+        rl->run[total++] = run;
+    } while (i >= 0);
+    return total;
+}
+static int o_level_run4(i16 *d, x264hip_run_level_t *rl)  { return level_run(d, rl, 4); }
+static int o_level_run15(i16 *d, x264hip_run_level_t *rl) { return level_run(d, rl, 15); }
+static int o_level_run16(i16 *d, x264hip_run_level_t *rl) { return level_run(d, rl, 16); }
+
+void x264o_quant_init(x264hip_quant_function_t *f)
+{   /* R/common/quant.c:303-435 */
+    f->quant_8x8 = o_quant_8x8; f->quant_4x4 = o_quant_4x4;
+    f->quant_4x4_dc = o_quant_4x4_dc; f->quant_2x2_dc = o_quant_2x2_dc;
+    f->dequant_8x8 = o_dequant_8x8; f->dequant_4x4 = o_dequant_4x4; f->dequant_4x4_dc = o_dequant_4x4_dc;
+    f->denoise_dct = o_denoise_dct;
+    f->decimate_score15 = o_decimate15; f->decimate_score16 = o_decimate16; f->decimate_score64 = o_decimate64;
+    f->coeff_last[X264HIP_DCT_CHROMA_DC] = o_last4;  f->coeff_last[X264HIP_DCT_LUMA_AC] = o_last15;
+    f->coeff_last[X264HIP_DCT_LUMA_4x4] = o_last16;  f->coeff_last[X264HIP_DCT_LUMA_8x8] = o_last64;
+    f->coeff_last[X264HIP_DCT_LUMA_DC] = o_last16;   f->coeff_last[X264HIP_DCT_CHROMA_AC] = o_last15;
+    f->coeff_level_run[X264HIP_DCT_CHROMA_DC] = o_level_run4;
+    f->coeff_level_run[X264HIP_DCT_LUMA_AC] = o_level_run15;
+    f->coeff_level_run[X264HIP_DCT_LUMA_4x4] = o_level_run16;
+    f->coeff_level_run[X264HIP_DCT_LUMA_DC] = o_level_run16;
+    f->coeff_level_run[X264HIP_DCT_CHROMA_AC] = o_level_run15;
+}
+
+/* Quantiser tables for the flat (default) scaling lists.
+ * R/common/set.c:27-66 (base tables), :68-168 (x264_cqm_init), with
+ * deadzones {intra Y, inter Y, intra C, inter C} = {21,11,21,11}
+ * (32 - 11, 32 - 21; R/common/set.c:75-78 with the param defaults
+ * i_luma_deadzone = {21, 11}, R/common/common.c).
+ * cat: 0 = intra Y, 1 = inter Y, 2 = intra C, 3 = inter C (4x4);
+ *      0 = intra Y, 1 = inter Y (8x8).                                   */
+static const u8 base_dq4[6][3] = {{10,13,16},{11,14,18},{13,16,20},{14,18,23},{16,20,25},{18,23,29}};
+static const u16 base_q4[6][3] = {{13107,8066,5243},{11916,7490,4660},{10082,6554,4194},
+                                  {9362,5825,3647},{8192,5243,3355},{7282,4559,2893}};
+static const u8 base_dq8[6][6] = {{20,18,32,19,25,24},{22,19,35,21,28,26},{26,23,42,24,33,31},
+                                  {28,25,45,26,35,33},{32,28,51,30,40,38},{36,32,58,34,46,43}};
+static const u16 base_q8[6][6] = {{13107,11428,20972,12222,16777,15481},{11916,10826,19174,11058,14980,14290},
+                                  {10082,8943,15978,9675,12710,11985},{9362,8228,14913,8931,11984,11259},
+                                  {8192,7346,13159,7740,10486,9777},{7282,6428,11570,6830,9118,8640}};
+static int cls4(int i) { return (i & 1) + ((i >> 2) & 1); }
+static int cls8(int i)
+{   /* position class of an 8x8 coefficient: R/common/set.c:104-113 */
+    static const u8 map[16] = {0,3,4,3, 3,1,5,1, 4,5,2,5, 3,1,5,1};
+    return map[((i >> 1) & 12) | (i & 3)];
+}
+void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant /* [6][n] or NULL */)
+{
+    int n = is8x8 ? 64 : 16;
+    int dz = (cat & 1) ? 32 - 21 : 32 - 11;
+    for (int i = 0; i < n; i++) {
+        int q = is8x8 ? base_q8[qp % 6][cls8(i)] : base_q4[qp % 6][cls4(i)];
+        /* flat list: scaling = 16, so the rounded division by it is exact;
+         * then a rounding shift by qp/6-1 (4x4) or qp/6 (8x8) */
+        int s = is8x8 ? qp / 6 : qp / 6 - 1;
+        int m = s < 0 ? q << -s : s == 0 ? q : (q + (1 << (s - 1))) >> s;
+        mf[i] = (u16)m;
+        int b = ((dz << 10) + (m >> 1)) / m, cap = (1 << 15) / m;
+        bias[i] = (u16)(b < cap ? b : cap);
+    }
+    if (dequant)
+        for (int k = 0; k < 6; k++)
+            for (int i = 0; i < n; i++)
+                dequant[k * n + i] = (is8x8 ? base_dq8[k][cls8(i)] : base_dq4[k][cls4(i)]) * 16;
+}
+
+/* ======================================================================
+ * M1-M7: motion compensation and frame filters, R/common/mc.c
+ * ==================================================================== */
+static void avg_wh(u8 *dst, int sd, const u8 *a, int sa, const u8 *b, int sb, int w, int h, int wt)
+{   /* R/common/mc.c:34-118 */
+    for (int y = 0; y < h; y++, dst += sd, a += sa, b += sb)
+        for (int x = 0; x < w; x++)
+            dst[x] = wt == 32 ? (u8)((a[x] + b[x] + 1) >> 1)
+                              : clip_u8((a[x] * wt + b[x] * (64 - wt) + 32) >> 6);
+}
+#define AVG_ENTRY(W, H) static void o_avg_##W##x##H(u8 *d, int sd, u8 *a, int sa, u8 *b, int sb, int wt) \
+    { avg_wh(d, sd, a, sa, b, sb, W, H, wt); }
+AVG_ENTRY(16,16) AVG_ENTRY(16,8) AVG_ENTRY(8,16) AVG_ENTRY(8,8) AVG_ENTRY(8,4)
+AVG_ENTRY(4,8) AVG_ENTRY(4,4) AVG_ENTRY(4,2) AVG_ENTRY(2,4) AVG_ENTRY(2,2)
+
+static void copy_wh(u8 *dst, int sd, const u8 *src, int ss, int w, int h)
+{
+    for (int y = 0; y < h; y++) memcpy(dst + y * sd, src + y * ss, w);
+}
+static void o_copy_w16(u8 *d, int sd, u8 *s, int ss, int h) { copy_wh(d, sd, s, ss, 16, h); }
+static void o_copy_w8(u8 *d, int sd, u8 *s, int ss, int h)  { copy_wh(d, sd, s, ss, 8, h); }
+static void o_copy_w4(u8 *d, int sd, u8 *s, int ss, int h)  { copy_wh(d, sd, s, ss, 4, h); }
+static void o_plane_copy(u8 *d, int sd, u8 *s, int ss, int w, int h) { copy_wh(d, sd, s, ss, w, h); }
+
+/* quarter-pel sample = one of, or the rounded mean of two of, the four
+ * half-pel planes {full, H, V, HV}.  R/common/mc.c:157-202 */
+static const u8 qpel_plane_a[16] = {0,1,1,1, 0,1,1,1, 2,3,3,3, 0,1,1,1};
+static const u8 qpel_plane_b[16] = {0,0,0,0, 2,2,3,2, 2,2,3,2, 2,2,3,2};
+static void o_mc_luma(u8 *dst, int sd, u8 **src, int ss, int mvx, int mvy, int w, int h)
+{
+    int fx = mvx & 3, fy = mvy & 3, idx = fy * 4 + fx;
+    int base = (mvy >> 2) * ss + (mvx >> 2);
+    const u8 *a = src[qpel_plane_a[idx]] + base + (fy == 3) * ss;
+    if (idx & 5) {
+        const u8 *b = src[qpel_plane_b[idx]] + base + (fx == 3);
+        avg_wh(dst, sd, a, ss, b, ss, w, h, 32);
+    } else
+        copy_wh(dst, sd, a, ss, w, h);
+}
+static u8 *o_get_ref(u8 *dst, int *sd, u8 **src, int ss, int mvx, int mvy, int w, int h)
+{
+    int fx = mvx & 3, fy = mvy & 3, idx = fy * 4 + fx;
+    int base = (mvy >> 2) * ss + (mvx >> 2);
+    u8 *a = src[qpel_plane_a[idx]] + base + (fy == 3) * ss;
+    if (idx & 5) {
+        const u8 *b = src[qpel_plane_b[idx]] + base + (fx == 3);
+        avg_wh(dst, *sd, a, ss, b, ss, w, h, 32);
+        return dst;
+    }
+    *sd = ss;
+    return a;
+}
+static void o_mc_chroma(u8 *dst, int sd, u8 *src, int ss, int mvx, int mvy, int w, int h)
+{   /* R/common/mc.c:205-236 */
+    int dx = mvx & 7, dy = mvy & 7;
+    int wa = (8 - dx) * (8 - dy), wb = dx * (8 - dy), wc = (8 - dx) * dy, wd = dx * dy;
+    src += (mvy >> 3) * ss + (mvx >> 3);
+    for (int y = 0; y < h; y++, dst += sd, src += ss)
+        for (int x = 0; x < w; x++)
+            dst[x] = (u8)((wa * src[x] + wb * src[x + 1] + wc * src[x + ss] + wd * src[x + ss + 1] + 32) >> 6);
+}
+/* six-tap half-pel planes, R/common/mc.c:132-155 */
+static inline int tap6(int a, int b, int c, int d, int e, int f) { return a + f - 5 * (b + e) + 20 * (c + d); }
+static void o_hpel_filter(u8 *dh, u8 *dv, u8 *dc, u8 *src, int stride, int width, int height, i16 *buf)
+{
+    for (int y = 0; y < height; y++, dh += stride, dv += stride, dc += stride, src += stride) {
+        for (int x = -2; x < width + 3; x++) {
+            int v = tap6(src[x - 2 * stride], src[x - stride], src[x], src[x + stride],
+                         src[x + 2 * stride], src[x + 3 * stride]);
+            dv[x] = clip_u8((v + 16) >> 5);
+            buf[x + 2] = (i16)v;
+        }
+        for (int x = 0; x < width; x++) {
+            const i16 *b = buf + 2 + x;
+            dc[x] = clip_u8((tap6(b[-2], b[-1], b[0], b[1], b[2], b[3]) + 512) >> 10);
+        }
+        for (int x = 0; x < width; x++)
+            dh[x] = clip_u8((tap6(src[x - 2], src[x - 1], src[x], src[x + 1], src[x + 2], src[x + 3]) + 16) >> 5);
+    }
+}
+/* integral images for exhaustive search, R/common/mc.c:270-304 (u16 wraps) */
+static void integral_h(u16 *sum, const u8 *pix, int stride, int n)
+{
+    int v = 0;
+    for (int k = 0; k < n; k++) v += pix[k];
+    for (int x = 0; x < stride - n; x++) {
+        sum[x] = (u16)(v + sum[x - stride]);
+        v += pix[x + n] - pix[x];
+    }
+}
+static void o_integral_init4h(u16 *sum, u8 *pix, int stride) { integral_h(sum, pix, stride, 4); }
+static void o_integral_init8h(u16 *sum, u8 *pix, int stride) { integral_h(sum, pix, stride, 8); }
+static void o_integral_init4v(u16 *sum8, u16 *sum4, int stride)
+{
+    for (int x = 0; x < stride - 8; x++)
+        sum4[x] = (u16)(sum8[x + 4 * stride] - sum8[x]);
+    for (int x = 0; x < stride - 8; x++)
+        sum8[x] = (u16)(sum8[x + 8 * stride] + sum8[x + 8 * stride + 4] - sum8[x] - sum8[x + 4]);
+}
+static void o_integral_init8v(u16 *sum8, int stride)
+{
+    for (int x = 0; x < stride - 8; x++)
+        sum8[x] = (u16)(sum8[x + 8 * stride] - sum8[x]);
+}
+/* half-resolution planes for the lookahead, R/common/mc.c:333-357 */
+static inline int avg4(int a, int b, int c, int d) { return (((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1; }
+static void o_lowres_core(u8 *src, u8 *d0, u8 *dh, u8 *dv, u8 *dc, int ss, int ds, int w, int h)
+{
+    for (int y = 0; y < h; y++, d0 += ds, dh += ds, dv += ds, dc += ds) {
+        const u8 *r0 = src + 2 * y * ss, *r1 = r0 + ss, *r2 = r1 + ss;
+        for (int x = 0; x < w; x++) {
+            d0[x] = avg4(r0[2 * x],     r1[2 * x],     r0[2 * x + 1], r1[2 * x + 1]);
+            dh[x] = avg4(r0[2 * x + 1], r1[2 * x + 1], r0[2 * x + 2], r1[2 * x + 2]);
+            dv[x] = avg4(r1[2 * x],     r2[2 * x],     r1[2 * x + 1], r2[2 * x + 1]);
+            dc[x] = avg4(r1[2 * x + 1], r2[2 * x + 1], r1[2 * x + 2], r2[2 * x + 2]);
+        }
+    }
+}
+static void o_prefetch_fenc(u8 *a, int b, u8 *c, int d, int e) { (void)a; (void)b; (void)c; (void)d; (void)e; }
+static void o_prefetch_ref(u8 *a, int b, int c) { (void)a; (void)b; (void)c; }
+static void o_memzero(void *d, int n) { memset(d, 0, n); }
+
+void x264o_mc_init(x264hip_mc_functions_t *f)
+{   /* R/common/mc.c:359-402 */
+    memset(f, 0, sizeof(*f));
+    f->mc_luma = o_mc_luma; f->get_ref = o_get_ref; f->mc_chroma = o_mc_chroma;
+    f->avg[0] = o_avg_16x16; f->avg[1] = o_avg_16x8; f->avg[2] = o_avg_8x16; f->avg[3] = o_avg_8x8;
+    f->avg[4] = o_avg_8x4; f->avg[5] = o_avg_4x8; f->avg[6] = o_avg_4x4; f->avg[7] = o_avg_4x2;
+    f->avg[8] = o_avg_2x4; f->avg[9] = o_avg_2x2;
+    f->copy_16x16_unaligned = o_copy_w16;
+    f->copy[X264HIP_PIXEL_16x16] = o_copy_w16; f->copy[X264HIP_PIXEL_8x8] = o_copy_w8;
+    f->copy[X264HIP_PIXEL_4x4] = o_copy_w4;
+    f->plane_copy = o_plane_copy; f->hpel_filter = o_hpel_filter;
+    f->prefetch_fenc = o_prefetch_fenc; f->prefetch_ref = o_prefetch_ref;
+    f->memcpy_aligned = memcpy; f->memzero_aligned = o_memzero;
+    f->frame_init_lowres_core = o_lowres_core;
+    f->integral_init4h = o_integral_init4h; f->integral_init8h = o_integral_init8h;
+    f->integral_init4v = o_integral_init4v; f->integral_init8v = o_integral_init8v;
+}
+
+/* ======================================================================
+ * I1-I4: intra prediction (H.264 8.3.1-8.3.4), R/common/predict.c.
+ * All operate in place on a stride-32 reconstruction buffer.
+ * ==================================================================== */
+#define PX(x, y) s[(x) + (y) * FDEC]
+static inline int f2(int a, int b, int c) { return (a + 2 * b + c + 2) >> 2; }
+static inline int f1(int a, int b) { return (a + b + 1) >> 1; }
+static void fill(u8 *s, int w, int h, int v)
+{
+    for (int y = 0; y < h; y++) memset(s + y * FDEC, v, w);
+}
+static void copy_top(u8 *s, int w, int h)
+{
+    for (int y = 0; y < h; y++) memcpy(s + y * FDEC, s - FDEC, w);
+}
+static void copy_left(u8 *s, int w, int h)
+{
+    for (int y = 0; y < h; y++) memset(s + y * FDEC, PX(-1, y), w);
+}
+static int sum_top(const u8 *s, int x0, int n)  { int a = 0; for (int i = 0; i < n; i++) a += PX(x0 + i, -1); return a; }
+static int sum_left(const u8 *s, int y0, int n) { int a = 0; for (int i = 0; i < n; i++) a += PX(-1, y0 + i); return a; }
+/* plane prediction; (n, coefficient, shift) = (16,5,6) luma, (8,17,5) chroma.
+ * R/common/predict.c:134-169, :311-346 */
+static void plane_pred(u8 *s, int n, int coef, int shift)
+{
+    int half = n / 2, H = 0, V = 0;
+    for (int i = 1; i <= half; i++) {
+        H += i * (PX(half - 1 + i, -1) - PX(half - 1 - i, -1));
+        V += i * (PX(-1, half - 1 + i) - PX(-1, half - 1 - i));
+    }
+    int a = 16 * (PX(-1, n - 1) + PX(n - 1, -1));
+    int b = (coef * H + (1 << (shift - 1))) >> shift;
+    int c = (coef * V + (1 << (shift - 1))) >> shift;
+    int origin = a - (half - 1) * (b + c) + 16;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            PX(x, y) = clip_u8((origin + b * x + c * y) >> 5);
+}
+/* 16x16, R/common/predict.c:52-169 */
+static void p16_v(u8 *s)       { copy_top(s, 16, 16); }
+static void p16_h(u8 *s)       { copy_left(s, 16, 16); }
+static void p16_dc(u8 *s)      { fill(s, 16, 16, (sum_top(s, 0, 16) + sum_left(s, 0, 16) + 16) >> 5); }
+static void p16_dc_left(u8 *s) { fill(s, 16, 16, (sum_left(s, 0, 16) + 8) >> 4); }
+static void p16_dc_top(u8 *s)  { fill(s, 16, 16, (sum_top(s, 0, 16) + 8) >> 4); }
+static void p16_dc_128(u8 *s)  { fill(s, 16, 16, 128); }
+static void p16_p(u8 *s)       { plane_pred(s, 16, 5, 6); }
+void x264o_predict_16x16_init(x264hip_predict_t pf[7])
+{
+    pf[0] = p16_v; pf[1] = p16_h; pf[2] = p16_dc; pf[3] = p16_p;
+    pf[4] = p16_dc_left; pf[5] = p16_dc_top; pf[6] = p16_dc_128;
+}
+/* 8x8 chroma, R/common/predict.c:176-346: four 4x4 quadrants with their own DC */
+static void p8c_dc(u8 *s)
+{
+    int t0 = sum_top(s, 0, 4), t1 = sum_top(s, 4, 4), l0 = sum_left(s, 0, 4), l1 = sum_left(s, 4, 4);
+    fill(s, 4, 4, (t0 + l0 + 4) >> 3);             fill(s + 4, 4, 4, (t1 + 2) >> 2);
+    fill(s + 4 * FDEC, 4, 4, (l1 + 2) >> 2);       fill(s + 4 * FDEC + 4, 4, 4, (t1 + l1 + 4) >> 3);
+}
+static void p8c_dc_left(u8 *s)
+{
+    fill(s, 8, 4, (sum_left(s, 0, 4) + 2) >> 2);
+    fill(s + 4 * FDEC, 8, 4, (sum_left(s, 4, 4) + 2) >> 2);
+}
+static void p8c_dc_top(u8 *s)
+{
+    int a = (sum_top(s, 0, 4) + 2) >> 2, b = (sum_top(s, 4, 4) + 2) >> 2;
+    fill(s, 4, 8, a); fill(s + 4, 4, 8, b);
+}
+static void p8c_dc_128(u8 *s) { fill(s, 8, 8, 128); }
+static void p8c_h(u8 *s)      { copy_left(s, 8, 8); }
+static void p8c_v(u8 *s)      { copy_top(s, 8, 8); }
+static void p8c_p(u8 *s)      { plane_pred(s, 8, 17, 5); }
+void x264o_predict_8x8c_init(x264hip_predict_t pf[7])
+{
+    pf[0] = p8c_dc; pf[1] = p8c_h; pf[2] = p8c_v; pf[3] = p8c_p;
+    pf[4] = p8c_dc_left; pf[5] = p8c_dc_top; pf[6] = p8c_dc_128;
+}
+
+/* Directional predictors for an NxN block from an edge array e[] laid out
+ * e[n-1-k] = left k, e[n] = top-left, e[n+1+k] = top k (k up to 2n-1):
+ * the shared geometry of H.264's 4x4 (8.3.1.2) and 8x8 (8.3.2.2) modes. */
+static void dir_pred(u8 *s, int n, int mode, const int *e)
+{
+#define L(k)  e[n - 1 - (k)]
+#define T(k)  e[n + 1 + (k)]
+#define Z(k)  e[n + (k)]        /* diagonal coordinate: Z(0)=TL, Z(+k)=T(k-1), Z(-k)=L(k-1) */
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int v;
+            switch (mode) {
+            case 3: /* diagonal down-left */
+                v = (x == n - 1 && y == n - 1) ? f2(T(2 * n - 2), T(2 * n - 1), T(2 * n - 1))
+                                               : f2(T(x + y), T(x + y + 1), T(x + y + 2));
+                break;
+            case 4: /* diagonal down-right */
+                v = f2(Z(x - y - 1), Z(x - y), Z(x - y + 1));
+                break;
+            case 5: { /* vertical-right */
+                int z = 2 * x - y;
+                if (z >= 0) v = (z & 1) ? f2(Z(x - (y >> 1) - 1), Z(x - (y >> 1)), Z(x - (y >> 1) + 1))
+                                        : f1(Z(x - (y >> 1)), Z(x - (y >> 1) + 1));
+                else if (z == -1) v = f2(L(0), Z(0), T(0));
+                else v = f2(L(y - 2 * x - 1), L(y - 2 * x - 2), L(y - 2 * x - 3));
+                break; }
+            case 6: { /* horizontal-down */
+                int z = 2 * y - x;
+                if (z >= 0) v = (z & 1) ? f2(Z(-(y - (x >> 1)) + 1), Z(-(y - (x >> 1))), Z(-(y - (x >> 1)) - 1))
+                                        : f1(Z(-(y - (x >> 1))), Z(-(y - (x >> 1)) - 1));
+                else if (z == -1) v = f2(L(0), Z(0), T(0));
+                else v = f2(T(x - 2 * y - 1), T(x - 2 * y - 2), T(x - 2 * y - 3));
+                break; }
+            case 7: /* vertical-left */
+                v = (y & 1) ? f2(T(x + (y >> 1)), T(x + (y >> 1) + 1), T(x + (y >> 1) + 2))
+                            : f1(T(x + (y >> 1)), T(x + (y >> 1) + 1));
+                break;
+            default: { /* 8: horizontal-up */
+                int z = x + 2 * y, last = 2 * n - 3;
+                if (z > last) v = L(n - 1);
+                else if (z == last) v = f2(L(n - 2), L(n - 1), L(n - 1));
+                else v = (z & 1) ? f2(L(y + (x >> 1)), L(y + (x >> 1) + 1), L(y + (x >> 1) + 2))
+                                 : f1(L(y + (x >> 1)), L(y + (x >> 1) + 1));
+                break; }
+            }
+            PX(x, y) = (u8)v;
+        }
+#undef L
+#undef T
+#undef Z
+}
+/* 4x4, R/common/predict.c:348-497: edges are raw neighbours */
+static void edges4(const u8 *s, int *e)
+{
+    for (int k = 0; k < 4; k++) e[3 - k] = PX(-1, k);
+    e[4] = PX(-1, -1);
+    for (int k = 0; k < 8; k++) e[5 + k] = PX(k, -1);
+}
+static void p4_v(u8 *s)       { copy_top(s, 4, 4); }
+static void p4_h(u8 *s)       { copy_left(s, 4, 4); }
+static void p4_dc(u8 *s)      { fill(s, 4, 4, (sum_top(s, 0, 4) + sum_left(s, 0, 4) + 4) >> 3); }
+static void p4_dc_left(u8 *s) { fill(s, 4, 4, (sum_left(s, 0, 4) + 2) >> 2); }
+static void p4_dc_top(u8 *s)  { fill(s, 4, 4, (sum_top(s, 0, 4) + 2) >> 2); }
+static void p4_dc_128(u8 *s)  { fill(s, 4, 4, 128); }
+/* each directional mode reads only the neighbours H.264 says it needs; the
+ * others may be unavailable memory in the caller, so load selectively */
+static void p4_dir(u8 *s, int mode)
+{
+    int e[13] = {0};
+    int need_left = mode == 4 || mode == 5 || mode == 6 || mode == 8;
+    int need_top = mode != 8, need_tl = mode == 4 || mode == 5 || mode == 6;
+    int need_tr = mode == 3 || mode == 7;
+    if (need_left) for (int k = 0; k < 4; k++) e[3 - k] = PX(-1, k);
+    if (need_tl) e[4] = PX(-1, -1);
+    if (need_top) for (int k = 0; k < 4; k++) e[5 + k] = PX(k, -1);
+    if (need_tr) for (int k = 4; k < 8; k++) e[5 + k] = PX(k, -1);
+    (void)edges4;
+    dir_pred(s, 4, mode, e);
+}
+static void p4_ddl(u8 *s) { p4_dir(s, 3); }
+static void p4_ddr(u8 *s) { p4_dir(s, 4); }
+static void p4_vr(u8 *s)  { p4_dir(s, 5); }
+static void p4_hd(u8 *s)  { p4_dir(s, 6); }
+static void p4_vl(u8 *s)  { p4_dir(s, 7); }
+static void p4_hu(u8 *s)  { p4_dir(s, 8); }
+void x264o_predict_4x4_init(x264hip_predict_t pf[12])
+{
+    pf[0] = p4_v; pf[1] = p4_h; pf[2] = p4_dc; pf[3] = p4_ddl; pf[4] = p4_ddr; pf[5] = p4_vr;
+    pf[6] = p4_hd; pf[7] = p4_vl; pf[8] = p4_hu; pf[9] = p4_dc_left; pf[10] = p4_dc_top; pf[11] = p4_dc_128;
+}
+/* 8x8 edge low-pass, R/common/predict.c:499-564.
+ * edge[7..14] = left 7..0, edge[15] = top-left, edge[16..31] = top 0..15,
+ * edge[32] = copy of top 15. */
+void x264o_predict_8x8_filter(u8 *s, u8 edge[33], int i_neighbor, int i_filters)
+{
+    int have_tl = i_neighbor & X264HIP_MB_TOPLEFT;
+    if (i_filters & X264HIP_MB_LEFT) {
+        edge[15] = (u8)((PX(0, -1) + 2 * PX(-1, -1) + PX(-1, 0) + 2) >> 2);
+        edge[14] = (u8)(((have_tl ? PX(-1, -1) : PX(-1, 0)) + 2 * PX(-1, 0) + PX(-1, 1) + 2) >> 2);
+        for (int y = 1; y < 7; y++) edge[14 - y] = (u8)f2(PX(-1, y - 1), PX(-1, y), PX(-1, y + 1));
+        edge[7] = (u8)((PX(-1, 6) + 3 * PX(-1, 7) + 2) >> 2);
+    }
+    if (i_filters & X264HIP_MB_TOP) {
+        int have_tr = i_neighbor & X264HIP_MB_TOPRIGHT;
+        edge[16] = (u8)(((have_tl ? PX(-1, -1) : PX(0, -1)) + 2 * PX(0, -1) + PX(1, -1) + 2) >> 2);
+        for (int x = 1; x < 7; x++) edge[16 + x] = (u8)f2(PX(x - 1, -1), PX(x, -1), PX(x + 1, -1));
+        edge[23] = (u8)((PX(6, -1) + 2 * PX(7, -1) + (have_tr ? PX(8, -1) : PX(7, -1)) + 2) >> 2);
+        if (i_filters & X264HIP_MB_TOPRIGHT) {
+            if (have_tr) {
+                for (int x = 8; x < 15; x++) edge[16 + x] = (u8)f2(PX(x - 1, -1), PX(x, -1), PX(x + 1, -1));
+                edge[31] = edge[32] = (u8)((PX(14, -1) + 3 * PX(15, -1) + 2) >> 2);
+            } else {
+                memset(edge + 24, PX(7, -1), 9);
+            }
+        }
+    }
+}
+/* 8x8 modes from the filtered edge, R/common/predict.c:566-751 */
+static void p8_fill(u8 *s, int v) { fill(s, 8, 8, v); }
+static int esum(const u8 *edge, int from, int n) { int a = 0; for (int i = 0; i < n; i++) a += edge[from + i]; return a; }
+static void p8_dc_128(u8 *s, u8 *e)  { (void)e; p8_fill(s, 128); }
+static void p8_dc_left(u8 *s, u8 *e) { p8_fill(s, (esum(e, 7, 8) + 4) >> 3); }
+static void p8_dc_top(u8 *s, u8 *e)  { p8_fill(s, (esum(e, 16, 8) + 4) >> 3); }
+static void p8_dc(u8 *s, u8 *e)      { p8_fill(s, (esum(e, 7, 8) + esum(e, 16, 8) + 8) >> 4); }
+static void p8_h(u8 *s, u8 *e)       { for (int y = 0; y < 8; y++) memset(s + y * FDEC, e[14 - y], 8); }
+static void p8_v(u8 *s, u8 *e)       { for (int y = 0; y < 8; y++) memcpy(s + y * FDEC, e + 16, 8); }
+static void p8_dir(u8 *s, const u8 *edge, int mode)
+{
+    int e[25];
+    for (int i = 0; i < 25; i++) e[i] = edge[7 + i];   /* e[7-k]=left k, e[8]=TL, e[9+k]=top k */
+    dir_pred(s, 8, mode, e);
+}
+static void p8_ddl(u8 *s, u8 *e) { p8_dir(s, e, 3); }
+static void p8_ddr(u8 *s, u8 *e) { p8_dir(s, e, 4); }
+static void p8_vr(u8 *s, u8 *e)  { p8_dir(s, e, 5); }
+static void p8_hd(u8 *s, u8 *e)  { p8_dir(s, e, 6); }
+static void p8_vl(u8 *s, u8 *e)  { p8_dir(s, e, 7); }
+static void p8_hu(u8 *s, u8 *e)  { p8_dir(s, e, 8); }
+void x264o_predict_8x8_init(x264hip_predict8x8_t pf[12], x264hip_predict_8x8_filter_t *filter)
+{
+    pf[0] = p8_v; pf[1] = p8_h; pf[2] = p8_dc; pf[3] = p8_ddl; pf[4] = p8_ddr; pf[5] = p8_vr;
+    pf[6] = p8_hd; pf[7] = p8_vl; pf[8] = p8_hu; pf[9] = p8_dc_left; pf[10] = p8_dc_top; pf[11] = p8_dc_128;
+    *filter = x264o_predict_8x8_filter;
+}
+
+/* ======================================================================
+ * B1: loop-filter edge kernels (H.264 8.7.2), R/common/frame.c:420-586.
+ * (xs, ys): step across / along the edge.
+ * ==================================================================== */
+static void db_luma(u8 *p, int xs, int ys, int alpha, int beta, const int8_t *tc0)
+{
+    for (int g = 0; g < 4; g++) {
+        if (tc0[g] < 0) { p += 4 * ys; continue; }
+        for (int k = 0; k < 4; k++, p += ys) {
+            int p2 = p[-3 * xs], p1 = p[-2 * xs], p0 = p[-xs], q0 = p[0], q1 = p[xs], q2 = p[2 * xs];
+            if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) continue;
+            int tc = tc0[g];
+            if (abs(p2 - p0) < beta) {
+                p[-2 * xs] = (u8)(p1 + clip3(((p2 + ((p0 + q0 + 1) >> 1)) >> 1) - p1, -tc0[g], tc0[g]));
+                tc++;
+            }
+            if (abs(q2 - q0) < beta) {
+                p[xs] = (u8)(q1 + clip3(((q2 + ((p0 + q0 + 1) >> 1)) >> 1) - q1, -tc0[g], tc0[g]));
+                tc++;
+            }
+            int d = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            p[-xs] = clip_u8(p0 + d);
+            p[0] = clip_u8(q0 - d);
+        }
+    }
+}
+static void db_chroma(u8 *p, int xs, int ys, int alpha, int beta, const int8_t *tc0)
+{
+    for (int g = 0; g < 4; g++) {
+        int tc = tc0[g];
+        if (tc <= 0) { p += 2 * ys; continue; }
+        for (int k = 0; k < 2; k++, p += ys) {
+            int p1 = p[-2 * xs], p0 = p[-xs], q0 = p[0], q1 = p[xs];
+            if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) continue;
+            int d = clip3((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc, tc);
+            p[-xs] = clip_u8(p0 + d);
+            p[0] = clip_u8(q0 - d);
+        }
+    }
+}
+static void db_luma_intra(u8 *p, int xs, int ys, int alpha, int beta)
+{
+    for (int k = 0; k < 16; k++, p += ys) {
+        int p2 = p[-3 * xs], p1 = p[-2 * xs], p0 = p[-xs], q0 = p[0], q1 = p[xs], q2 = p[2 * xs];
+        if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) continue;
+        if (abs(p0 - q0) < (alpha >> 2) + 2) {
+            if (abs(p2 - p0) < beta) {
+                int p3 = p[-4 * xs];
+                p[-xs] = (u8)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+                p[-2 * xs] = (u8)((p2 + p1 + p0 + q0 + 2) >> 2);
+                p[-3 * xs] = (u8)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            } else
+                p[-xs] = (u8)((2 * p1 + p0 + q1 + 2) >> 2);
+            if (abs(q2 - q0) < beta) {
+                int q3 = p[3 * xs];
+                p[0] = (u8)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+                p[xs] = (u8)((p0 + q0 + q1 + q2 + 2) >> 2);
+                p[2 * xs] = (u8)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+            } else
+                p[0] = (u8)((2 * q1 + q0 + p1 + 2) >> 2);
+        } else {
+            p[-xs] = (u8)((2 * p1 + p0 + q1 + 2) >> 2);
+            p[0] = (u8)((2 * q1 + q0 + p1 + 2) >> 2);
+        }
+    }
+}
+static void db_chroma_intra(u8 *p, int xs, int ys, int alpha, int beta)
+{
+    for (int k = 0; k < 8; k++, p += ys) {
+        int p1 = p[-2 * xs], p0 = p[-xs], q0 = p[0], q1 = p[xs];
+        if (abs(p0 - q0) >= alpha || abs(p1 - p0) >= beta || abs(q1 - q0) >= beta) continue;
+        p[-xs] = (u8)((2 * p1 + p0 + q1 + 2) >> 2);
+        p[0] = (u8)((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+}
+static void o_db_v_luma(u8 *p, int s, int a, int b, int8_t *t)   { db_luma(p, s, 1, a, b, t); }
+static void o_db_h_luma(u8 *p, int s, int a, int b, int8_t *t)   { db_luma(p, 1, s, a, b, t); }
+static void o_db_v_chroma(u8 *p, int s, int a, int b, int8_t *t) { db_chroma(p, s, 1, a, b, t); }
+static void o_db_h_chroma(u8 *p, int s, int a, int b, int8_t *t) { db_chroma(p, 1, s, a, b, t); }
+static void o_db_v_luma_i(u8 *p, int s, int a, int b)   { db_luma_intra(p, s, 1, a, b); }
+static void o_db_h_luma_i(u8 *p, int s, int a, int b)   { db_luma_intra(p, 1, s, a, b); }
+static void o_db_v_chroma_i(u8 *p, int s, int a, int b) { db_chroma_intra(p, s, 1, a, b); }
+static void o_db_h_chroma_i(u8 *p, int s, int a, int b) { db_chroma_intra(p, 1, s, a, b); }
+void x264o_deblock_init(x264hip_deblock_function_t *f)
+{   /* R/common/frame.c:835-876 */
+    f->deblock_v_luma = o_db_v_luma; f->deblock_h_luma = o_db_h_luma;
+    f->deblock_v_chroma = o_db_v_chroma; f->deblock_h_chroma = o_db_h_chroma;
+    f->deblock_v_luma_intra = o_db_v_luma_i; f->deblock_h_luma_intra = o_db_h_luma_i;
+    f->deblock_v_chroma_intra = o_db_v_chroma_i; f->deblock_h_chroma_intra = o_db_h_chroma_i;
+}
+
+/* size tables exported for the harness */
+int x264o_block_w(int i) { return blk_w[i]; }
+int x264o_block_h(int i) { return blk_h[i]; }

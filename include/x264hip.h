@@ -1,0 +1,193 @@
+/* x264hip.h -- C ABI of the MI355X (gfx950) back-end for x264 core 66's
+ * per-macroblock analyse/encode hot path.
+ *
+ * R/ = x264-snapshot-20090216-2245/ of chinaxuyongtao/x264-vs2008.
+ *
+ * Two levels, both plain C (pointers + sizes, no C++ or torch types):
+ *
+ *  1. TABLE LEVEL -- x264_<family>_init_hip() fill the reference's own six
+ *     function-pointer tables (include/x264hip_tables.h) with entries that
+ *     take the reference's exact arguments (host pointers) and run the
+ *     arithmetic on the GPU.  This is the hook shape the reference already
+ *     has for its SIMD back-ends (x264_pixel_altivec_init, R/common/pixel.c:
+ *     781-786; x264_mc_init_mmx, R/common/mc.c:395-397) and is what
+ *     x264_encoder_open calls at R/encoder/encoder.c:730-745.  One call = one
+ *     launch + one sync: exact, but latency-bound; it exists for drop-in
+ *     parity, not for speed.
+ *
+ *  2. FRAME LEVEL -- x264hip_frame_* / x264hip_*_frame keep whole planes
+ *     resident in HBM and process every macroblock of a frame per launch
+ *     (one wavefront per macroblock for motion search).  These are what the
+ *     callers named below invoke when the HIP flag is set; see INTEGRATION.md.
+ *
+ * Error convention: table entries cannot fail (the reference's signatures
+ * have no error channel); everything fallible happens in x264hip_init(),
+ * which returns 0 or a negative code and leaves x264hip_last_error() set.
+ * The *_init_hip() functions return -1 and leave the table untouched if the
+ * library is not initialised.  Frame-level calls return 0 / negative.
+ *
+ * Threading: table entries use a per-thread stream + pinned staging arena
+ * (the reference calls them concurrently from its frame threads without
+ * locks, R/common/common.h:50).  Frame-level calls are stream-ordered on the
+ * stream of the x264hip_frame_ctx they are given.
+ */
+#ifndef X264HIP_H
+#define X264HIP_H
+
+#include "x264hip_tables.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flag bit proposed for x264_cpu_names[] / param.cpu: next free after
+ * X264_CPU_LZCNT 0x010000 (R/x264.h:65) */
+#define X264_CPU_HIP 0x020000
+
+typedef struct {
+    int    device;        /* HIP device ordinal */
+    size_t arena_bytes;   /* per-thread pinned staging arena for table calls; 0 = default (4 MiB) */
+} x264hip_cfg;
+
+int         x264hip_init(const x264hip_cfg *cfg);   /* 0 ok; <0: no device / alloc failure */
+void        x264hip_shutdown(void);
+const char *x264hip_last_error(void);
+int         x264hip_device_count(void);
+
+/* ---- table level: replaces x264_*_init(cpu, ...) of R/encoder/encoder.c:730-745 */
+int x264_pixel_init_hip(x264hip_pixel_function_t *pixf);            /* R/common/pixel.c:565 */
+int x264_dct_init_hip(x264hip_dct_function_t *dctf);                /* R/common/dct.c:388 */
+int x264_zigzag_init_hip(x264hip_zigzag_function_t *pf, int b_interlaced); /* R/common/dct.c:626 */
+int x264_quant_init_hip(x264hip_quant_function_t *pf);              /* R/common/quant.c:303 */
+int x264_mc_init_hip(x264hip_mc_functions_t *pf);                   /* R/common/mc.c:359 */
+int x264_predict_16x16_init_hip(x264hip_predict_t pf[7]);           /* R/common/predict.c:753 */
+int x264_predict_8x8c_init_hip(x264hip_predict_t pf[7]);            /* R/common/predict.c:774 */
+int x264_predict_4x4_init_hip(x264hip_predict_t pf[12]);            /* R/common/predict.c:818 */
+int x264_predict_8x8_init_hip(x264hip_predict8x8_t pf[12], x264hip_predict_8x8_filter_t *filter); /* predict.c:795 */
+int x264_deblock_init_hip(x264hip_deblock_function_t *pf);          /* R/common/frame.c:835 */
+/* plane drivers that take a table in the reference (R/common/pixel.c:98,471) */
+int64_t x264hip_pixel_ssd_wxh(uint8_t *pix1, int i_pix1, uint8_t *pix2, int i_pix2, int i_width, int i_height);
+float   x264hip_pixel_ssim_wxh(uint8_t *pix1, int i_pix1, uint8_t *pix2, int i_pix2, int i_width, int i_height, void *buf);
+
+/* ---- frame level -------------------------------------------------------------
+ * Plane layout follows x264_frame_new (R/common/frame.c:29-152): every plane
+ * is padded by PADH = PADV = 32 pixels (R/common/frame.h:27-29), luma stride
+ * = ALIGN(width + 64, 16), chroma stride = luma stride / 2; the four luma
+ * planes of a reference (full, H, V, HV half-pel) are separate allocations
+ * here.  All pointers handed back are DEVICE pointers to the first visible
+ * pixel (not to the padding), exactly like x264_frame_t.plane[].          */
+typedef struct x264hip_frame_ctx x264hip_frame_ctx;
+
+typedef struct {
+    int width, height;        /* visible luma size; coded size is rounded up to 16 */
+    int mb_w, mb_h;           /* filled by x264hip_frame_ctx_new */
+    int stride_y, stride_c;   /* filled by x264hip_frame_ctx_new */
+    int lines_y, lines_c;     /* coded lines */
+} x264hip_frame_dims;
+
+/* one picture resident in HBM: source (fenc) or reconstruction (fdec/ref) */
+typedef struct {
+    uint8_t *plane[3];        /* Y, U, V (device) */
+    uint8_t *filtered[4];     /* [0] = plane[0], [1..3] = H, V, HV half-pel planes (device) */
+    uint8_t *lowres[4];       /* half-resolution luma + its H,V,HV planes (device) */
+    uint16_t *integral;       /* ESA integral image or NULL */
+    int      stride_lowres, width_lowres, lines_lowres;
+} x264hip_picture;
+
+x264hip_frame_ctx *x264hip_frame_ctx_new(x264hip_frame_dims *dims, void *hip_stream /* NULL = own stream */);
+void  x264hip_frame_ctx_delete(x264hip_frame_ctx *c);
+void *x264hip_frame_ctx_stream(x264hip_frame_ctx *c);
+int   x264hip_picture_alloc(x264hip_frame_ctx *c, x264hip_picture *pic);
+void  x264hip_picture_free(x264hip_frame_ctx *c, x264hip_picture *pic);
+int   x264hip_sync(x264hip_frame_ctx *c);
+
+/* x264_frame_copy_picture + border pad (R/common/frame.c:185-216, encoder.c:1406-1411):
+ * host I420 -> device planes, then edges replicated into the padding.      */
+int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic,
+                           const uint8_t *y, int sy, const uint8_t *u, int su, const uint8_t *v, int sv);
+int x264hip_picture_download(x264hip_frame_ctx *c, const x264hip_picture *pic, int plane_id /*0..2 Y,U,V; 3..5 H,V,HV; 6..9 lowres*/,
+                             uint8_t *dst, int dst_stride, int with_padding);
+/* x264_frame_expand_border / _filtered / _lowres (R/common/frame.c:218-334) */
+int x264hip_expand_border(x264hip_frame_ctx *c, x264hip_picture *pic, int which /*0 planes, 1 filtered, 2 lowres*/);
+/* x264_frame_filter: H, V, HV half-pel planes of the whole frame (R/common/mc.c:404-426) */
+int x264hip_hpel_filter_frame(x264hip_frame_ctx *c, x264hip_picture *pic);
+/* x264_frame_init_lowres (R/common/mc.c:306-357) */
+int x264hip_lowres_init_frame(x264hip_frame_ctx *c, x264hip_picture *pic);
+/* AQ energy: pixf.var of Y 16x16 and U,V 8x8 per macroblock
+ * (x264_adaptive_quant_frame's ac_energy_mb, R/encoder/ratecontrol.c:171-195).
+ * out[mb] = var16(Y) + var8(U) + var8(V)                                    */
+int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, int32_t *out_dev);
+/* x264_pixel_ssd_wxh over the three planes (PSNR, R/encoder/encoder.c:1034-1045) */
+int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3]);
+
+/* Motion search, one wavefront per macroblock (x264_me_search_ref's full-pel
+ * stage as an exhaustive +-range window, R/encoder/me.c:156-631 with the ESA
+ * cost rule :449-470; cost = SAD + p_cost_mv[mx - mvp.x] + p_cost_mv[my - mvp.y],
+ * COST_MV R/encoder/me.c:54-62).  For every macroblock and every partition
+ * of {16x16, 16x8 x2, 8x16 x2, 8x8 x4} it returns the best full-pel vector
+ * and its cost; ties resolve to the first candidate in raster order of
+ * (my, mx), which is the order of the reference's ESA scan (me.c:480-560).
+ *   cost_mv : device table of uint16 costs indexed by qpel delta + 2*cost_mv_range
+ *   centers : per-MB search centre in full pels (int16 x,y) or NULL for (0,0)
+ *   mvp     : per-MB predictor in qpel (int16 x,y) or NULL for (0,0)
+ *   out_mv  : [mb][9] int16 x,y (full-pel, absolute)   out_cost : [mb][9] int32 */
+typedef struct {
+    int range;                 /* full-pel search range, <= 24 */
+    const uint16_t *cost_mv;   /* device; centre entry at cost_mv[cost_mv_range] */
+    int cost_mv_range;         /* qpel span on each side */
+    const int16_t *centers;    /* device or NULL */
+    const int16_t *mvp;        /* device or NULL */
+} x264hip_me_params;
+int x264hip_me_fullpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
+                             const x264hip_me_params *p, int16_t *out_mv_dev, int32_t *out_cost_dev);
+
+/* Sub-pel refinement of the 16x16 vector (refine_subpel, R/encoder/me.c:680-778,
+ * exhaustive form): half-pel then quarter-pel 3x3 neighbourhoods scored with
+ * SATD (mbcmp) + mv cost through the qpel blend of the four planes
+ * (get_ref, R/common/mc.c:181-202).  in/out mv in qpel.                      */
+int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
+                            const x264hip_me_params *p, const int16_t *mv_fullpel_dev /* [mb][9][2], uses entry 0 */,
+                            int16_t *out_mv_qpel_dev /* [mb][2] */, int32_t *out_cost_dev /* [mb] */);
+
+/* Inter residual pipeline for every macroblock (x264_macroblock_encode's
+ * inter branch, R/encoder/macroblock.c:596-768, without trellis/denoise):
+ * x264_mb_mc 16x16 (mc_luma + mc_chroma) -> sub16x16_dct(8) -> quant ->
+ * zigzag scan -> decimate -> dequant -> add idct into the reconstruction;
+ * chroma: sub8x8_dct, 2x2 DC, quant, decimate (<7), dequant, idct.
+ *   mv_qpel : [mb][2]; qp : per-frame luma QP (chroma QP from the standard
+ *   table with offset 0); transform8x8 : 0 = 4x4, 1 = 8x8 luma transform.
+ *   levels_y : [mb][16][16] (4x4) or [mb][4][64] (8x8) scanned levels;
+ *   levels_c : [mb][2][4][16] AC (index 0 unused) ; dc_c : [mb][2][4]
+ *   cbp     : [mb] luma cbp (bits 0-3) | chroma cbp << 4
+ *   nnz     : [mb][24] per-4x4 non-zero flags in x264 block order (16 Y, 4 U, 4 V) */
+typedef struct {
+    int qp, transform8x8, b_interlaced;
+    const uint16_t *quant4_mf, *quant4_bias;   /* device [4][52][16] */
+    const uint16_t *quant8_mf, *quant8_bias;   /* device [2][52][64] */
+    const int32_t  *dequant4_mf;               /* device [4][6][16]  */
+    const int32_t  *dequant8_mf;               /* device [2][6][64]  */
+} x264hip_residual_params;
+int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
+                                 x264hip_picture *recon, const x264hip_residual_params *p,
+                                 const int16_t *mv_qpel_dev, int16_t *levels_y_dev, int16_t *levels_c_dev,
+                                 int16_t *dc_c_dev, int32_t *cbp_dev, uint8_t *nnz_dev);
+
+/* x264_frame_deblock_row for every row (R/common/frame.c:621-792), inter
+ * frame without B-specific rules: bS from intra flag / nnz / mv+ref
+ * differences, alpha/beta/tc0 from the per-MB qp, vertical edges of the
+ * whole frame first, then horizontal edges (the standard's order per MB is
+ * preserved because every edge kernel reads only already-final neighbours).
+ *   mb_type_intra : [mb] u8 ; qp : [mb] u8 ; nnz : [mb][24] ; mv : [mb][16][2]
+ *   int16 qpel per 4x4 ; ref : [mb][4] int8 per 8x8 ; transform8x8 : [mb] u8 */
+typedef struct {
+    const uint8_t *mb_intra, *qp, *nnz, *transform8x8;
+    const int16_t *mv;
+    const int8_t  *ref;
+    int alpha_c0_offset, beta_offset, chroma_qp_offset;
+} x264hip_deblock_params;
+int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x264hip_deblock_params *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X264HIP_H */

@@ -1,0 +1,108 @@
+// runtime.hip -- library lifecycle: device selection, error string, per-thread
+// stream + pinned staging arena for the table-level entries.
+//
+// Everything that can fail happens here, at x264hip_init() time, mirroring the
+// reference's rule that table entries have no error channel and only
+// x264_encoder_open may fail (R/encoder/encoder.c:634-645).
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include "internal.h"
+
+namespace x264hip {
+
+static std::mutex g_mu;
+static char g_err[512] = "";
+static std::atomic<bool> g_init{false};
+static int g_device = 0;
+static size_t g_arena = 4u << 20;
+
+void set_error(const char *fmt, ...)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+bool initialised() { return g_init.load(); }
+int device_id() { return g_device; }
+size_t arena_bytes() { return g_arena; }
+
+ThreadCtx::~ThreadCtx()
+{
+    // Process teardown order between thread_local destructors and the HIP
+    // runtime is unspecified; leak rather than call into a dead runtime.
+}
+
+ThreadCtx *thread_ctx()
+{
+    static thread_local ThreadCtx ctx;
+    if (ctx.ok) return &ctx;
+    if (!initialised()) {
+        fprintf(stderr, "x264hip: table entry called before x264hip_init() succeeded\n");
+        abort();
+    }
+    hipError_t e = hipSetDevice(g_device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx.host, g_arena, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx.dev, ctx.host, 0);
+    if (e != hipSuccess) {
+        // No CPU fallback by design: a table entry that cannot reach the GPU
+        // must not silently compute something else.
+        fprintf(stderr, "x264hip: cannot create per-thread HIP context: %s\n", hipGetErrorString(e));
+        abort();
+    }
+    ctx.cap = g_arena;
+    ctx.ok = true;
+    return &ctx;
+}
+
+}  // namespace x264hip
+
+using namespace x264hip;
+
+extern "C" int x264hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int x264hip_init(const x264hip_cfg *cfg)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return -1;
+    }
+    int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= n) {
+        set_error("device %d out of range (0..%d)", dev, n - 1);
+        return -2;
+    }
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (prop.warpSize != 64) {
+        set_error("device %d has wavefront size %d; this library is written for wave64 gfx950", dev, prop.warpSize);
+        return -3;
+    }
+    g_device = dev;
+    if (cfg && cfg->arena_bytes) g_arena = cfg->arena_bytes;
+    g_init.store(true);
+    set_error("");
+    return 0;
+}
+
+extern "C" void x264hip_shutdown(void)
+{
+    if (!g_init.load()) return;
+    (void)hipDeviceSynchronize();
+    g_init.store(false);
+}
+
+extern "C" const char *x264hip_last_error(void) { return g_err; }

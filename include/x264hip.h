@@ -53,6 +53,12 @@ int         x264hip_init(const x264hip_cfg *cfg);   /* 0 ok; <0: no device / all
 void        x264hip_shutdown(void);
 const char *x264hip_last_error(void);
 int         x264hip_device_count(void);
+/* plain device memory for hosts without a HIP binding of their own (tests, bench.py) */
+void *x264hip_malloc(size_t bytes);          /* zero-filled; NULL on failure */
+void  x264hip_free(void *dev);
+int   x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int   x264hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int   x264hip_device_synchronize(void);
 
 /* ---- table level: replaces x264_*_init(cpu, ...) of R/encoder/encoder.c:730-745 */
 int x264_pixel_init_hip(x264hip_pixel_function_t *pixf);            /* R/common/pixel.c:565 */
@@ -137,6 +143,9 @@ typedef struct {
     int cost_mv_range;         /* qpel span on each side */
     const int16_t *centers;    /* device or NULL */
     const int16_t *mvp;        /* device or NULL */
+    uint16_t *sad_surface;     /* device or NULL: [mb][(2*range+1)^2] raw 16x16 SADs in (my,mx) raster
+                                  order; entries of vectors outside the mv limits are unspecified */
+    int mv_range;              /* param.analyse.i_mv_range in pixels (level limit); 0 = 512 */
 } x264hip_me_params;
 int x264hip_me_fullpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
                              const x264hip_me_params *p, int16_t *out_mv_dev, int32_t *out_cost_dev);

@@ -106,3 +106,29 @@ extern "C" void x264hip_shutdown(void)
 }
 
 extern "C" const char *x264hip_last_error(void) { return g_err; }
+
+// ---- plain device-memory helpers for hosts that have no HIP binding of their own ----
+extern "C" void *x264hip_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!initialised() || hipSetDevice(g_device) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+    (void)hipMemset(p, 0, bytes);
+    return p;
+}
+extern "C" void x264hip_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int x264hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int x264hip_device_synchronize(void)
+{
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}

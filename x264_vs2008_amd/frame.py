@@ -1,0 +1,164 @@
+"""Host-side mirror of the frame level of include/x264hip.h (ctypes).
+
+Thin: it owns no arithmetic.  Device buffers other than pictures are
+DeviceArray objects backed by the library's own malloc/memcpy entry points
+(torch's bundled HIP runtime and the system one this library links cannot
+both drive the GPU from one process, so torch.cuda is never touched here).
+"""
+import ctypes as C
+
+import numpy as np
+
+PADH = PADV = 32
+
+
+class Dims(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("mb_w", C.c_int), ("mb_h", C.c_int),
+                ("stride_y", C.c_int), ("stride_c", C.c_int), ("lines_y", C.c_int), ("lines_c", C.c_int)]
+
+
+class Picture(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("filtered", C.c_void_p * 4), ("lowres", C.c_void_p * 4),
+                ("integral", C.c_void_p), ("stride_lowres", C.c_int), ("width_lowres", C.c_int),
+                ("lines_lowres", C.c_int)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [("range", C.c_int), ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int),
+                ("centers", C.c_void_p), ("mvp", C.c_void_p), ("sad_surface", C.c_void_p),
+                ("mv_range", C.c_int)]
+
+
+class ResidualParams(C.Structure):
+    _fields_ = [("qp", C.c_int), ("transform8x8", C.c_int), ("b_interlaced", C.c_int),
+                ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p),
+                ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
+                ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p)]
+
+
+class DeblockParams(C.Structure):
+    _fields_ = [("mb_intra", C.c_void_p), ("qp", C.c_void_p), ("nnz", C.c_void_p), ("transform8x8", C.c_void_p),
+                ("mv", C.c_void_p), ("ref", C.c_void_p),
+                ("alpha_c0_offset", C.c_int), ("beta_offset", C.c_int), ("chroma_qp_offset", C.c_int)]
+
+
+class DeviceArray:
+    """A device buffer with a numpy shape/dtype, moved with the C ABI's memcpy helpers."""
+
+    def __init__(self, lib, shape, dtype, init=None):
+        self.lib, self.shape, self.dtype = lib, tuple(np.atleast_1d(shape)), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        lib.x264hip_malloc.restype = C.c_void_p
+        self.ptr = lib.x264hip_malloc(C.c_size_t(self.nbytes))
+        if not self.ptr:
+            raise MemoryError("x264hip_malloc(%d) failed" % self.nbytes)
+        if init is not None:
+            self.set(init)
+
+    @property
+    def p(self):
+        return C.c_void_p(self.ptr)
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes
+        assert self.lib.x264hip_memcpy_h2d(self.p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes)) == 0
+
+    def get(self):
+        out = np.zeros(self.shape, self.dtype)
+        assert self.lib.x264hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.p, C.c_size_t(self.nbytes)) == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.x264hip_free(self.p)
+            self.ptr = None
+
+
+PLANE_IDS = {"y": 0, "u": 1, "v": 2, "h": 3, "vv": 4, "c": 5, "l0": 6, "lh": 7, "lv": 8, "lc": 9}
+
+
+class FrameCtx:
+    """x264hip_frame_ctx + helpers to move numpy images in and out."""
+
+    def __init__(self, lib, width, height, stream=None):
+        self.lib = lib
+        lib.x264hip_frame_ctx_new.restype = C.c_void_p
+        lib.x264hip_frame_ctx_stream.restype = C.c_void_p
+        self.dims = Dims(width=width, height=height)
+        self.h = lib.x264hip_frame_ctx_new(C.byref(self.dims), C.c_void_p(stream))
+        if not self.h:
+            raise RuntimeError("x264hip_frame_ctx_new failed: %s" % lib.x264hip_last_error().decode())
+        self.h = C.c_void_p(self.h)
+        self.pictures = []
+
+    @property
+    def stream(self):
+        return self.lib.x264hip_frame_ctx_stream(self.h)
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.x264hip_last_error().decode()))
+
+    def new_picture(self):
+        pic = Picture()
+        self.check(self.lib.x264hip_picture_alloc(self.h, C.byref(pic)), "picture_alloc")
+        self.pictures.append(pic)
+        return pic
+
+    def upload(self, pic, y, u, v):
+        y, u, v = (np.ascontiguousarray(a) for a in (y, u, v))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.check(self.lib.x264hip_picture_upload(self.h, C.byref(pic), p(y), y.shape[1], p(u), u.shape[1],
+                                                   p(v), v.shape[1]), "picture_upload")
+
+    def geometry(self, pic, name):
+        d = self.dims
+        i = PLANE_IDS[name]
+        if i == 0 or 3 <= i < 6:
+            return d.stride_y, d.mb_w * 16, d.lines_y, PADH, PADV
+        if i < 3:
+            return d.stride_c, d.mb_w * 8, d.lines_c, PADH // 2, PADV // 2
+        return pic.stride_lowres, pic.width_lowres, pic.lines_lowres, PADH, PADV
+
+    def download(self, pic, name, padded=True):
+        stride, w, h, padh, padv = self.geometry(pic, name)
+        shape = (h + 2 * padv, stride) if padded else (h, w)
+        out = np.zeros(shape, np.uint8)
+        self.check(self.lib.x264hip_picture_download(self.h, C.byref(pic), PLANE_IDS[name],
+                                                     out.ctypes.data_as(C.c_void_p), shape[1], int(padded)),
+                   "picture_download")
+        return out
+
+    def sync(self):
+        self.check(self.lib.x264hip_sync(self.h), "sync")
+
+    def close(self):
+        for pic in self.pictures:
+            self.lib.x264hip_picture_free(self.h, C.byref(pic))
+        self.pictures = []
+        if self.h:
+            self.lib.x264hip_frame_ctx_delete(self.h)
+            self.h = None
+
+
+def host_plane(stride, lines, padh, padv):
+    """Zeroed host image with the device layout; returns (full, offset_of_pixel00)."""
+    full = np.zeros((lines + 2 * padv, stride), np.uint8)
+    return full, padv * stride + padh
+
+
+def cost_mv_table(lam, span):
+    """p_cost_mv for one lambda (R/encoder/analyse.c:182-198): index i + span
+    holds the cost of a qpel delta of i.  The reference's macro is
+    log2f(x) = ((float)log((double)x)) / log(2.0) (analyse.c:40), i.e. the
+    natural log is rounded to float and everything after it is double; the
+    result is truncated to int16."""
+    i = np.arange(0, span + 1, dtype=np.float64)
+    log2 = np.log(i + 1.0).astype(np.float32).astype(np.float64) / np.log(2.0)
+    v = (lam * (log2 * 2 + float(np.float32(0.718)) + (i != 0)) + float(np.float32(0.5)))
+    v = v.astype(np.int64).astype(np.int16).view(np.uint16)
+    tab = np.zeros(2 * span + 1, np.uint16)
+    tab[span:] = v
+    tab[:span] = v[1:][::-1]
+    return tab

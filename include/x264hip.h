@@ -59,6 +59,11 @@ void  x264hip_free(void *dev);
 int   x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int   x264hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int   x264hip_device_synchronize(void);
+/* HIP events on a named stream (timing of kernels on the stream they run on) */
+void *x264hip_event_create(void);
+void  x264hip_event_destroy(void *ev);
+int   x264hip_event_record(void *ev, void *hip_stream);
+float x264hip_event_elapsed_ms(void *start, void *stop);   /* waits for stop; <0 on error */
 
 /* ---- table level: replaces x264_*_init(cpu, ...) of R/encoder/encoder.c:730-745 */
 int x264_pixel_init_hip(x264hip_pixel_function_t *pixf);            /* R/common/pixel.c:565 */
@@ -163,14 +168,19 @@ int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, c
  * x264_mb_mc 16x16 (mc_luma + mc_chroma) -> sub16x16_dct(8) -> quant ->
  * zigzag scan -> decimate -> dequant -> add idct into the reconstruction;
  * chroma: sub8x8_dct, 2x2 DC, quant, decimate (<7), dequant, idct.
- *   mv_qpel : [mb][2]; qp : per-frame luma QP (chroma QP from the standard
- *   table with offset 0); transform8x8 : 0 = 4x4, 1 = 8x8 luma transform.
- *   levels_y : [mb][16][16] (4x4) or [mb][4][64] (8x8) scanned levels;
- *   levels_c : [mb][2][4][16] AC (index 0 unused) ; dc_c : [mb][2][4]
- *   cbp     : [mb] luma cbp (bits 0-3) | chroma cbp << 4
- *   nnz     : [mb][24] per-4x4 non-zero flags in x264 block order (16 Y, 4 U, 4 V) */
+ *   mv_qpel : [mb][2]; qp / qp_chroma : per-frame luma and chroma QP
+ *   (h->mb.i_chroma_qp); transform8x8 : 0 = 4x4, 1 = 8x8 luma transform;
+ *   b_interlaced selects the field scan tables.
+ *   levels_y : [mb][16][16] (4x4) or [mb][4][64] (8x8) scanned levels, zero
+ *              for blocks that quantise to nothing;
+ *   levels_c : [mb][2][4][16] scanned AC (index 0 is the removed DC = 0);
+ *   dc_c    : [mb][2][4] quantised 2x2 chroma DC in zigzag_scan_2x2_dc order
+ *   cbp     : [mb] luma cbp (bits 0-3) | chroma cbp (0,1,2) << 4
+ *   nnz     : [mb][26] non-zero flags: 16 Y 4x4 blocks (x264 z-order), 4 U,
+ *              4 V AC blocks, U DC, V DC -- after decimation, as stored in
+ *              h->mb.cache.non_zero_count                                   */
 typedef struct {
-    int qp, transform8x8, b_interlaced;
+    int qp, qp_chroma, transform8x8, b_interlaced;
     const uint16_t *quant4_mf, *quant4_bias;   /* device [4][52][16] */
     const uint16_t *quant8_mf, *quant8_bias;   /* device [2][52][64] */
     const int32_t  *dequant4_mf;               /* device [4][6][16]  */

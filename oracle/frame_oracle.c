@@ -33,12 +33,42 @@ static x264hip_quant_function_t quantf;
 static x264hip_mc_functions_t mcf;
 static x264hip_deblock_function_t dbf;
 static int ready;
+#ifdef X264O_USE_REF
+/* Second build of this file (oracle/_ref/libframe_ref.so, `make ref`): the
+ * same per-frame loops, but every table entry is the REFERENCE's own C
+ * function from _ref/libx264ref.so.  bench.py times this one as
+ * cpu_baseline.kind = "reference"; tests use it to check the twin's loops. */
+void x264_pixel_init(int, x264hip_pixel_function_t *);
+void x264_dct_init(int, x264hip_dct_function_t *);
+void x264_zigzag_init(int, x264hip_zigzag_function_t *, int);
+void x264_quant_init(void *, int, x264hip_quant_function_t *);
+void x264_mc_init(int, x264hip_mc_functions_t *);
+void x264_deblock_init(int, x264hip_deblock_function_t *);
+int64_t x264_pixel_ssd_wxh(x264hip_pixel_function_t *, u8 *, int, u8 *, int, int, int);
+#define x264o_pixel_ssd_wxh(a, sa, b, sb, w, h) x264_pixel_ssd_wxh(&pixf, a, sa, b, sb, w, h)
+#define x264o_plane_expand_border x264r_plane_expand_border
+#define x264o_plane_pad_mod16 x264r_plane_pad_mod16
+#define x264o_frame_hpel x264r_frame_hpel
+#define x264o_frame_lowres x264r_frame_lowres
+#define x264o_frame_aq_var x264r_frame_aq_var
+#define x264o_frame_ssd x264r_frame_ssd
+#define x264o_frame_me_fullpel x264r_frame_me_fullpel
+#define x264o_frame_me_subpel x264r_frame_me_subpel
+#define x264o_frame_inter_residual x264r_frame_inter_residual
+#define x264o_frame_deblock x264r_frame_deblock
+#endif
 static void init(void)
 {
     if (ready) return;
+#ifdef X264O_USE_REF
+    x264_pixel_init(0, &pixf); x264_dct_init(0, &dctf);
+    x264_zigzag_init(0, &zigf[0], 0); x264_zigzag_init(0, &zigf[1], 1);
+    x264_quant_init(0, 0, &quantf); x264_mc_init(0, &mcf); x264_deblock_init(0, &dbf);
+#else
     x264o_pixel_init(&pixf); x264o_dct_init(&dctf);
     x264o_zigzag_init(&zigf[0], 0); x264o_zigzag_init(&zigf[1], 1);
     x264o_quant_init(&quantf); x264o_mc_init(&mcf); x264o_deblock_init(&dbf);
+#endif
     ready = 1;
 }
 
@@ -206,5 +236,150 @@ void x264o_frame_me_subpel(u8 *fenc, u8 *p0, u8 *p1, u8 *p2, u8 *p3, int mb_w, i
             bmx = wx; bmy = wy; bcost = best;
         }
         out_mv[2 * mb] = bmx; out_mv[2 * mb + 1] = bmy; out_cost[mb] = bcost;
+    }
+}
+
+/* ---------------------------------------------------------------- residual
+ * x264_macroblock_encode, inter 16x16 branch (R/encoder/macroblock.c:596-768)
+ * with b_dct_decimate on, no trellis / noise reduction / lossless, followed by
+ * x264_mb_encode_8x8_chroma(b_inter = 1) (:272-363).  The macroblock is moved
+ * through fenc_buf / fdec_buf-shaped scratch (strides 16 / 32) exactly as
+ * x264_macroblock_cache_load does, so the table entries see the strides they
+ * were written for. */
+#define FENC 16
+#define FDEC 32
+static const u8 blk_x[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
+static const u8 blk_y[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
+
+void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* source planes */
+                                u8 *r0, u8 *r1, u8 *r2, u8 *r3, u8 *ru, u8 *rv,   /* reference: 4 luma planes + chroma */
+                                u8 *dy, u8 *du, u8 *dv,                 /* reconstruction planes */
+                                int mb_w, int mb_h, int sy, int sc, int qp, int qpc, int transform8x8, int interlaced,
+                                const u16 *q4mf, const u16 *q4bias, const u16 *q8mf, const u16 *q8bias,
+                                const int32_t *dq4, const int32_t *dq8, const i16 *mv,
+                                i16 *levels_y, i16 *levels_c, i16 *dc_c, int32_t *cbp_out, u8 *nnz_out)
+{
+    init();
+    u8 fenc[24 * FENC], fdec[27 * FDEC];
+    u8 *fe_y = fenc, *fe_u = fenc + 16 * FENC, *fe_v = fenc + 16 * FENC + 8;
+    u8 *fd_y = fdec + 2 * FDEC, *fd_u = fdec + 19 * FDEC, *fd_v = fdec + 19 * FDEC + 16;
+    u16 *mf4y = (u16 *)q4mf + (1 * 52 + qp) * 16, *b4y = (u16 *)q4bias + (1 * 52 + qp) * 16;
+    u16 *mf4c = (u16 *)q4mf + (3 * 52 + qpc) * 16, *b4c = (u16 *)q4bias + (3 * 52 + qpc) * 16;
+    u16 *mf8y = (u16 *)q8mf + (1 * 52 + qp) * 64, *b8y = (u16 *)q8bias + (1 * 52 + qp) * 64;
+    int (*dq4y)[4][4] = (int (*)[4][4])(dq4 + 1 * 96), (*dq4c)[4][4] = (int (*)[4][4])(dq4 + 3 * 96);
+    int (*dq8y)[8][8] = (int (*)[8][8])(dq8 + 1 * 384);
+    x264hip_zigzag_function_t *zz = &zigf[!!interlaced];
+    for (int mb = 0; mb < mb_w * mb_h; mb++) {
+        int mbx = mb % mb_w, mby = mb / mb_w, mvx = mv[2 * mb], mvy = mv[2 * mb + 1];
+        int oy = 16 * mby * sy + 16 * mbx, ocs = 8 * mby * sc + 8 * mbx;
+        i16 *ly = levels_y + mb * 256, *lc = levels_c + mb * 128, *ldc = dc_c + mb * 8;
+        u8 *nnz = nnz_out + mb * 26;
+        memset(ly, 0, 512); memset(lc, 0, 256); memset(ldc, 0, 16); memset(nnz, 0, 26);
+        for (int y = 0; y < 16; y++) memcpy(fe_y + y * FENC, fy + oy + y * sy, 16);
+        for (int y = 0; y < 8; y++) { memcpy(fe_u + y * FENC, fu + ocs + y * sc, 8); memcpy(fe_v + y * FENC, fv + ocs + y * sc, 8); }
+        /* x264_mb_mc_0xywh for a 16x16 partition, R/common/macroblock.c:462-487 */
+        u8 *src4[4] = {r0 + oy, r1 + oy, r2 + oy, r3 + oy};
+        mcf.mc_luma(fd_y, FDEC, src4, sy, mvx, mvy, 16, 16);
+        mcf.mc_chroma(fd_u, FDEC, ru + ocs, sc, mvx, mvy, 8, 8);
+        mcf.mc_chroma(fd_v, FDEC, rv + ocs, sc, mvx, mvy, 8, 8);
+        int cbp_luma = 0, decimate_mb = 0;
+        if (transform8x8) {
+            i16 dct8[4][8][8];
+            dctf.sub16x16_dct8(dct8, fe_y, fd_y);
+            for (int idx = 0; idx < 4; idx++) {
+                int nz = quantf.quant_8x8(dct8[idx], mf8y, b8y);
+                if (nz) {
+                    zz->scan_8x8(ly + 64 * idx, dct8[idx]);
+                    int s = quantf.decimate_score64(ly + 64 * idx);
+                    decimate_mb += s;
+                    if (s >= 4) cbp_luma |= 1 << idx;
+                }
+            }
+            if (decimate_mb < 6) cbp_luma = 0;
+            else
+                for (int idx = 0; idx < 4; idx++)
+                    if (cbp_luma & (1 << idx)) {
+                        quantf.dequant_8x8(dct8[idx], dq8y, qp);
+                        dctf.add8x8_idct8(fd_y + (idx & 1) * 8 + (idx >> 1) * 8 * FDEC, dct8[idx]);
+                        for (int k = 0; k < 4; k++) nnz[4 * idx + k] = 1;
+                    }
+        } else {
+            i16 dct4[16][4][4];
+            dctf.sub16x16_dct(dct4, fe_y, fd_y);
+            for (int i8 = 0; i8 < 4; i8++) {
+                int dec8 = 0;
+                for (int i4 = 0; i4 < 4; i4++) {
+                    int idx = 4 * i8 + i4;
+                    int nz = quantf.quant_4x4(dct4[idx], mf4y, b4y);
+                    nnz[idx] = nz;
+                    if (nz) {
+                        zz->scan_4x4(ly + 16 * idx, dct4[idx]);
+                        quantf.dequant_4x4(dct4[idx], dq4y, qp);
+                        if (dec8 < 6) dec8 += quantf.decimate_score16(ly + 16 * idx);
+                    }
+                }
+                decimate_mb += dec8;
+                if (dec8 < 4) nnz[4 * i8] = nnz[4 * i8 + 1] = nnz[4 * i8 + 2] = nnz[4 * i8 + 3] = 0;
+                else cbp_luma |= 1 << i8;
+            }
+            if (decimate_mb < 6) { cbp_luma = 0; memset(nnz, 0, 16); }
+            else
+                for (int i8 = 0; i8 < 4; i8++)
+                    if (cbp_luma & (1 << i8))
+                        dctf.add8x8_idct(fd_y + (i8 & 1) * 8 + (i8 >> 1) * 8 * FDEC, &dct4[4 * i8]);
+        }
+        /* chroma, R/encoder/macroblock.c:272-363 */
+        int cbp_chroma = 0;
+        for (int ch = 0; ch < 2; ch++) {
+            u8 *ps = ch ? fe_v : fe_u, *pd = ch ? fd_v : fd_u;
+            i16 d4[4][4][4], d2[2][2];
+            int score = 0, nz_ac = 0;
+            dctf.sub8x8_dct(d4, ps, pd);
+            {   /* dct2x2dc, :73-85 */
+                int a = d4[0][0][0] + d4[1][0][0], b = d4[2][0][0] + d4[3][0][0];
+                int c = d4[0][0][0] - d4[1][0][0], d = d4[2][0][0] - d4[3][0][0];
+                d2[0][0] = a + b; d2[1][0] = c + d; d2[0][1] = a - b; d2[1][1] = c - d;
+                d4[0][0][0] = d4[1][0][0] = d4[2][0][0] = d4[3][0][0] = 0;
+            }
+            for (int i = 0; i < 4; i++) {
+                int nz = quantf.quant_4x4(d4[i], mf4c, b4c);
+                nnz[16 + 4 * ch + i] = nz;
+                if (nz) {
+                    nz_ac = 1;
+                    zz->scan_4x4(lc + (4 * ch + i) * 16, d4[i]);
+                    quantf.dequant_4x4(d4[i], dq4c, qpc);
+                    score += quantf.decimate_score15(lc + (4 * ch + i) * 16);
+                }
+            }
+            int nz_dc = quantf.quant_2x2_dc(d2, mf4c[0] >> 1, b4c[0] << 1);
+            nnz[24 + ch] = nz_dc;
+            /* IDCT_DEQUANT_START, :40-51 */
+            int e0 = d2[0][0] + d2[0][1], e1 = d2[1][0] + d2[1][1], e2 = d2[0][0] - d2[0][1], e3 = d2[1][0] - d2[1][1];
+            int dmf = dq4c[qpc % 6][0][0], qbits = qpc / 6 - 5;
+            if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+            if (score < 7 || !nz_ac) {
+                nnz[16 + 4 * ch] = nnz[17 + 4 * ch] = nnz[18 + 4 * ch] = nnz[19 + 4 * ch] = 0;
+                if (!nz_dc) continue;
+                ldc[4 * ch] = d2[0][0]; ldc[4 * ch + 1] = d2[1][0]; ldc[4 * ch + 2] = d2[0][1]; ldc[4 * ch + 3] = d2[1][1];
+                i16 dd[2][2];
+                dd[0][0] = (e0 + e1) * dmf >> -qbits; dd[0][1] = (e0 - e1) * dmf >> -qbits;
+                dd[1][0] = (e2 + e3) * dmf >> -qbits; dd[1][1] = (e2 - e3) * dmf >> -qbits;
+                dctf.add8x8_idct_dc(pd, dd);
+            } else {
+                cbp_chroma = 1;
+                if (nz_dc) {
+                    ldc[4 * ch] = d2[0][0]; ldc[4 * ch + 1] = d2[1][0]; ldc[4 * ch + 2] = d2[0][1]; ldc[4 * ch + 3] = d2[1][1];
+                    d4[0][0][0] = (e0 + e1) * dmf >> -qbits; d4[1][0][0] = (e0 - e1) * dmf >> -qbits;
+                    d4[2][0][0] = (e2 + e3) * dmf >> -qbits; d4[3][0][0] = (e2 - e3) * dmf >> -qbits;
+                }
+                dctf.add8x8_idct(pd, d4);
+            }
+        }
+        if (cbp_chroma) cbp_chroma = 2;
+        else if (nnz[24] | nnz[25]) cbp_chroma = 1;
+        cbp_out[mb] = cbp_luma | (cbp_chroma << 4);
+        (void)blk_x; (void)blk_y;
+        for (int y = 0; y < 16; y++) memcpy(dy + oy + y * sy, fd_y + y * FDEC, 16);
+        for (int y = 0; y < 8; y++) { memcpy(du + ocs + y * sc, fd_u + y * FDEC, 8); memcpy(dv + ocs + y * sc, fd_v + y * FDEC, 8); }
     }
 }

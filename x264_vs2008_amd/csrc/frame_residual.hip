@@ -1,0 +1,354 @@
+// frame_residual.hip -- FRAME LEVEL, part 3: the inter residual pipeline of
+// every macroblock of a frame in one launch, one wavefront per macroblock:
+//
+//   x264_mb_mc (16x16: mc_luma through the qpel blend of the four half-pel
+//   planes + bilinear 1/8-pel mc_chroma)  ->  sub16x16_dct / sub16x16_dct8
+//   -> quant -> zigzag scan -> decimate (JVT-B118 scores: 8x8 < 4, MB < 6,
+//   chroma < 7) -> dequant -> inverse transform added to the prediction
+//   -> reconstruction planes, scanned levels, cbp, nnz flags.
+//
+// Restates x264_macroblock_encode's inter branch (R/encoder/macroblock.c:
+// 596-768) and x264_mb_encode_8x8_chroma (:272-363) with b_dct_decimate on
+// and trellis / noise reduction / lossless off.  Block-level steps are the
+// table entries of device_prims.h; the decision logic (which blocks survive
+// decimation) is a few dozen scalar operations done by one lane per
+// macroblock from scores the other lanes left in LDS.
+//
+// Lane roles inside a wavefront: 64 lanes = 256 luma prediction pixels / 4;
+// lanes 0-15 own one luma 4x4 block each (lanes 0-3 one 8x8 block each in
+// 8x8-transform mode), lanes 0-7 own the chroma 4x4 blocks (U: 0-3, V: 4-7).
+#include "device_prims.h"
+#include "frame_internal.h"
+
+using namespace x264hip;
+
+#define RS_WAVES 4
+
+struct ResGeom {
+    int mb_w, mb_h, sy, sc, qp, qpc, field;
+};
+
+struct ResLds {
+    u8  fe[384];          // source: Y 16x16, U 8x8, V 8x8
+    u8  pr[384];          // prediction, then reconstruction
+    i16 coef[16][16];     // dequantised luma coefficients (4x4 mode: [blk][16]; 8x8 mode: [4][64] flat)
+    i16 ccoef[8][16];     // dequantised chroma AC (+ DC once decided)
+    int score[16];        // luma decimate scores / nz flags packed: score | nz << 8
+    int cscore[8];
+    i16 cdc[8];           // chroma DCs before the 2x2 transform
+    int keep8;            // luma cbp after decimation
+    int cmode[2];         // chroma per channel: 0 pred only, 1 DC only, 2 full
+    i16 cdcout[8];        // chroma per-block DC to add (mode 1) or to put at coef[0] (mode 2)
+};
+
+__device__ __forceinline__ void blk_xy(int k, int &x, int &y)
+{
+    x = ((k >> 2) & 1) * 8 + (k & 1) * 4;
+    y = (k >> 3) * 8 + ((k >> 1) & 1) * 4;
+}
+__device__ __forceinline__ int decimate_scan(const i16 *lv, int n, const u8 *tab)
+{   // R/common/quant.c:213-239 on already scanned levels lv[0..n)
+    int i = n - 1, score = 0;
+    while (i >= 0 && lv[i] == 0) i--;
+    while (i >= 0) {
+        if ((unsigned)(lv[i--] + 1) > 2u) return 9;
+        int run = 0;
+        while (i >= 0 && lv[i] == 0) { i--; run++; }
+        score += tab[run];
+    }
+    return score;
+}
+
+template <int DCT8>
+__global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
+    const u8 *__restrict__ fy, const u8 *__restrict__ fu, const u8 *__restrict__ fv,
+    const u8 *__restrict__ r0, const u8 *__restrict__ r1, const u8 *__restrict__ r2, const u8 *__restrict__ r3,
+    const u8 *__restrict__ ru, const u8 *__restrict__ rv,
+    u8 *__restrict__ dy, u8 *__restrict__ du, u8 *__restrict__ dv, ResGeom g,
+    const u16 *__restrict__ q4mf, const u16 *__restrict__ q4bias, const u16 *__restrict__ q8mf, const u16 *__restrict__ q8bias,
+    const int *__restrict__ dq4, const int *__restrict__ dq8, const i16 *__restrict__ mv,
+    i16 *__restrict__ levels_y, i16 *__restrict__ levels_c, i16 *__restrict__ dc_c, int *__restrict__ cbp_out, u8 *__restrict__ nnz_out)
+{
+    __shared__ ResLds s_all[RS_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mb = blockIdx.x * RS_WAVES + wave;
+    if (mb >= g.mb_w * g.mb_h) return;
+    ResLds &s = s_all[wave];
+    const int mbx = mb % g.mb_w, mby = mb / g.mb_w;
+    const int mvx = mv[2 * mb], mvy = mv[2 * mb + 1];
+    const ptrdiff_t oy = (ptrdiff_t)16 * mby * g.sy + 16 * mbx, oc = (ptrdiff_t)8 * mby * g.sc + 8 * mbx;
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
+                         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+    // ---- source + prediction into LDS ----
+    {
+        int r = lane >> 2, x = (lane & 3) * 4;
+        *(u32 *)(s.fe + r * 16 + x) = *(const u32 *)(fy + oy + (ptrdiff_t)r * g.sy + x);
+        // mc_luma, R/common/mc.c:160-179
+        int qx = mvx & 3, qy = mvy & 3, idx = qy * 4 + qx;
+        ptrdiff_t base = oy + (ptrdiff_t)((mvy >> 2) + r) * g.sy + (mvx >> 2) + x;
+        const u8 *pa = (c_qpel_a[idx] == 0 ? r0 : c_qpel_a[idx] == 1 ? r1 : c_qpel_a[idx] == 2 ? r2 : r3) + base + (qy == 3) * g.sy;
+        const u8 *pb = (c_qpel_b[idx] == 0 ? r0 : c_qpel_b[idx] == 2 ? r2 : r3) + base + (qx == 3);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            s.pr[r * 16 + x + i] = (idx & 5) ? (u8)(((int)pa[i] + (int)pb[i] + 1) >> 1) : pa[i];
+        // chroma: one pixel of U and one of V per lane (mc_chroma, mc.c:205-236)
+        int cx = lane & 7, cy = lane >> 3;
+        int dx = mvx & 7, dyy = mvy & 7;
+        int ca = (8 - dx) * (8 - dyy), cb = dx * (8 - dyy), cc = (8 - dx) * dyy, cd = dx * dyy;
+        ptrdiff_t cbase = oc + (ptrdiff_t)((mvy >> 3) + cy) * g.sc + (mvx >> 3) + cx;
+        const u8 *pu = ru + cbase, *pv = rv + cbase;
+        s.pr[256 + lane] = (u8)((ca * pu[0] + cb * pu[1] + cc * pu[g.sc] + cd * pu[g.sc + 1] + 32) >> 6);
+        s.pr[320 + lane] = (u8)((ca * pv[0] + cb * pv[1] + cc * pv[g.sc] + cd * pv[g.sc + 1] + 32) >> 6);
+        s.fe[256 + lane] = fu[oc + (ptrdiff_t)cy * g.sc + cx];
+        s.fe[320 + lane] = fv[oc + (ptrdiff_t)cy * g.sc + cx];
+    }
+    WAVE_SYNC();
+
+    i16 *ly = levels_y + (size_t)mb * 256;
+    // ---- luma transform + quant + scan + dequant + scores ----
+    if (!DCT8) {
+        if (lane < 16) {
+            int bx, by, r[16];
+            blk_xy(lane, bx, by);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.pr[(by + j) * 16 + bx + i];
+            i16 c[16];
+            fwd4x4(c, r);
+            const u16 *mf = q4mf + (1 * 52 + g.qp) * 16, *bs = q4bias + (1 * 52 + g.qp) * 16;
+            const int *dq = dq4 + 1 * 96 + (g.qp % 6) * 16;
+            int nz = 0, bits = g.qp / 6 - 4;
+            i16 lv[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+#pragma unroll
+            for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[g.field][i]] : (i16)0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { ly[16 * lane + i] = lv[i]; s.coef[lane][i] = (i16)dequant_one(c[i], dq[i], bits); }
+            s.score[lane] = (nz ? decimate_scan(lv, 16, c_decimate4) : 0) | ((nz != 0) << 8);
+        }
+    } else {
+        if (lane < 4) {
+            const u8 *p1 = s.fe + (lane >> 1) * 8 * 16 + (lane & 1) * 8, *p2 = s.pr + (lane >> 1) * 8 * 16 + (lane & 1) * 8;
+            i16 *co = &s.coef[0][0] + 64 * lane;
+            i16 t[64];
+            int a[8], o[8];
+            for (int c = 0; c < 8; c++) {
+                for (int k = 0; k < 8; k++) a[k] = (int)p1[k * 16 + c] - (int)p2[k * 16 + c];
+                fwd8_1d(o, a);
+                for (int k = 0; k < 8; k++) t[k * 8 + c] = (i16)o[k];
+            }
+            for (int r = 0; r < 8; r++) {
+                for (int k = 0; k < 8; k++) a[k] = t[r * 8 + k];
+                fwd8_1d(o, a);
+                for (int k = 0; k < 8; k++) co[k * 8 + r] = (i16)o[k];
+            }
+            const u16 *mf = q8mf + (1 * 52 + g.qp) * 64, *bs = q8bias + (1 * 52 + g.qp) * 64;
+            int nz = 0;
+            for (int i = 0; i < 64; i++) { int q = quant_one(co[i], mf[i], bs[i]); co[i] = (i16)q; nz |= q; }
+            i16 *lv = ly + 64 * lane;
+            for (int i = 0; i < 64; i++) lv[i] = nz ? co[c_scan8[g.field][i]] : (i16)0;
+            int sc = 0;
+            if (nz) {   // decimate_score64 on the scanned levels (read back from the coefficient order)
+                int i = 63;
+                while (i >= 0 && co[c_scan8[g.field][i]] == 0) i--;
+                while (i >= 0) {
+                    if ((unsigned)(co[c_scan8[g.field][i--]] + 1) > 2u) { sc = 9; break; }
+                    int run = 0;
+                    while (i >= 0 && co[c_scan8[g.field][i]] == 0) { i--; run++; }
+                    sc += c_decimate8[run];
+                }
+            }
+            s.score[lane] = sc | ((nz != 0) << 8);
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- decimation decisions (macroblock.c:627-742), one lane ----
+    u8 *nnz = nnz_out + (size_t)mb * 26;
+    if (lane == 0) {
+        int cbp = 0, dec_mb = 0;
+        u8 nz16[16];
+        if (!DCT8) {
+            for (int i8 = 0; i8 < 4; i8++) {
+                int dec8 = 0;
+                for (int i4 = 0; i4 < 4; i4++) {
+                    int v = s.score[4 * i8 + i4];
+                    nz16[4 * i8 + i4] = (u8)(v >> 8);
+                    if ((v >> 8) && dec8 < 6) dec8 += v & 255;
+                }
+                dec_mb += dec8;
+                if (dec8 < 4) nz16[4 * i8] = nz16[4 * i8 + 1] = nz16[4 * i8 + 2] = nz16[4 * i8 + 3] = 0;
+                else cbp |= 1 << i8;
+            }
+            if (dec_mb < 6) { cbp = 0; for (int i = 0; i < 16; i++) nz16[i] = 0; }
+        } else {
+            for (int i = 0; i < 4; i++) {
+                int v = s.score[i];
+                if (v >> 8) { dec_mb += v & 255; if ((v & 255) >= 4) cbp |= 1 << i; }
+            }
+            if (dec_mb < 6) cbp = 0;
+            for (int i = 0; i < 16; i++) nz16[i] = (u8)((cbp >> (i >> 2)) & 1);
+        }
+        s.keep8 = cbp;
+        for (int i = 0; i < 16; i++) nnz[i] = nz16[i];
+    }
+    WAVE_SYNC();
+
+    // ---- luma reconstruction ----
+    if (!DCT8) {
+        if (lane < 16 && ((s.keep8 >> (lane >> 2)) & 1)) {
+            int bx, by, res[16];
+            blk_xy(lane, bx, by);
+            inv4x4(res, s.coef[lane]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    u8 *p = s.pr + (by + j) * 16 + bx + i;
+                    *p = (u8)clip_u8((int)*p + res[4 * j + i]);
+                }
+        }
+    } else {
+        if (lane < 4 && ((s.keep8 >> lane) & 1)) {
+            i16 *d = &s.coef[0][0] + 64 * lane;
+            u8 *dst = s.pr + (lane >> 1) * 8 * 16 + (lane & 1) * 8;
+            const int *dq = dq8 + 1 * 384 + (g.qp % 6) * 64;
+            int bits = g.qp / 6 - 6, a[8], o[8];
+            for (int i = 0; i < 64; i++) d[i] = (i16)dequant_one(d[i], dq[i], bits);
+            d[0] = (i16)(d[0] + 32);
+            for (int c = 0; c < 8; c++) {
+                for (int k = 0; k < 8; k++) a[k] = d[k * 8 + c];
+                inv8_1d(o, a);
+                for (int k = 0; k < 8; k++) d[k * 8 + c] = (i16)o[k];
+            }
+            for (int r = 0; r < 8; r++) {
+                for (int k = 0; k < 8; k++) a[k] = d[r * 8 + k];
+                inv8_1d(o, a);
+                for (int k = 0; k < 8; k++) {
+                    u8 *p = dst + r + k * 16;
+                    *p = (u8)clip_u8((int)*p + (o[k] >> 6));
+                }
+            }
+        }
+    }
+
+    // ---- chroma blocks: transform, AC quant, scan, dequant, scores ----
+    i16 *lc = levels_c + (size_t)mb * 128;
+    if (lane < 8) {
+        int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, r[16];
+        const u8 *fe = s.fe + 256 + 64 * ch, *pr = s.pr + 256 + 64 * ch;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                r[4 * j + i] = (int)fe[(by + j) * 8 + bx + i] - (int)pr[(by + j) * 8 + bx + i];
+        i16 c[16], lv[16];
+        fwd4x4(c, r);
+        s.cdc[lane] = c[0];
+        c[0] = 0;                                     // dct2x2dc takes the DCs out (macroblock.c:73-85)
+        const u16 *mf = q4mf + (3 * 52 + g.qpc) * 16, *bs = q4bias + (3 * 52 + g.qpc) * 16;
+        const int *dq = dq4 + 3 * 96 + (g.qpc % 6) * 16;
+        int nz = 0, bits = g.qpc / 6 - 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[g.field][i]] : (i16)0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { lc[16 * lane + i] = lv[i]; s.ccoef[lane][i] = nz ? (i16)dequant_one(c[i], dq[i], bits) : (i16)0; }
+        s.cscore[lane] = (nz ? decimate_scan(lv + 1, 15, c_decimate4) : 0) | ((nz != 0) << 8);
+    }
+    WAVE_SYNC();
+    // ---- chroma DC + decisions, one lane per channel (macroblock.c:320-356) ----
+    if (lane < 2) {
+        int ch = lane;
+        int b0 = s.cdc[4 * ch], b1 = s.cdc[4 * ch + 1], b2 = s.cdc[4 * ch + 2], b3 = s.cdc[4 * ch + 3];
+        int a0 = b0 + b1, a1 = b2 + b3, a2 = b0 - b1, a3 = b2 - b3;
+        i16 d2[4] = {(i16)(a0 + a1), (i16)(a0 - a1), (i16)(a2 + a3), (i16)(a2 - a3)};   // [0][0] [0][1] [1][0] [1][1]
+        const u16 *mf = q4mf + (3 * 52 + g.qpc) * 16, *bs = q4bias + (3 * 52 + g.qpc) * 16;
+        int nz_dc = 0;
+        for (int i = 0; i < 4; i++) { int q = quant_one(d2[i], (int)mf[0] >> 1, (int)bs[0] << 1); d2[i] = (i16)q; nz_dc |= q; }
+        int score = 0, nz_ac = 0;
+        u8 nzf[4];
+        for (int i = 0; i < 4; i++) { int v = s.cscore[4 * ch + i]; nzf[i] = (u8)(v >> 8); if (v >> 8) { nz_ac = 1; score += v & 255; } }
+        int e0 = d2[0] + d2[1], e1 = d2[2] + d2[3], e2 = d2[0] - d2[1], e3 = d2[2] - d2[3];
+        int dmf = dq4[3 * 96 + (g.qpc % 6) * 16], qbits = g.qpc / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        int mode;
+        if (score < 7 || !nz_ac) { nzf[0] = nzf[1] = nzf[2] = nzf[3] = 0; mode = nz_dc ? 1 : 0; }
+        else mode = 2;
+        i16 *ldc = dc_c + (size_t)mb * 8 + 4 * ch;
+        bool put = nz_dc != 0;
+        ldc[0] = put ? d2[0] : (i16)0; ldc[1] = put ? d2[2] : (i16)0; ldc[2] = put ? d2[1] : (i16)0; ldc[3] = put ? d2[3] : (i16)0;
+        s.cdcout[4 * ch + 0] = (i16)((e0 + e1) * dmf >> -qbits); s.cdcout[4 * ch + 1] = (i16)((e0 - e1) * dmf >> -qbits);
+        s.cdcout[4 * ch + 2] = (i16)((e2 + e3) * dmf >> -qbits); s.cdcout[4 * ch + 3] = (i16)((e2 - e3) * dmf >> -qbits);
+        if (!nz_dc) s.cdcout[4 * ch] = s.cdcout[4 * ch + 1] = s.cdcout[4 * ch + 2] = s.cdcout[4 * ch + 3] = 0;
+        s.cmode[ch] = mode | (nz_dc ? 16 : 0);
+        for (int i = 0; i < 4; i++) nnz[16 + 4 * ch + i] = nzf[i];
+        nnz[24 + ch] = (u8)(nz_dc != 0);
+    }
+    WAVE_SYNC();
+    // ---- chroma reconstruction ----
+    if (lane < 8) {
+        int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, mode = s.cmode[ch] & 15;
+        u8 *pr = s.pr + 256 + 64 * ch;
+        if (mode == 2) {
+            int res[16];
+            s.ccoef[lane][0] = s.cdcout[lane];
+            inv4x4(res, s.ccoef[lane]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    u8 *p = pr + (by + j) * 8 + bx + i;
+                    *p = (u8)clip_u8((int)*p + res[4 * j + i]);
+                }
+        } else if (mode == 1) {
+            int dc = (int)(i16)((s.cdcout[lane] + 32) >> 6);
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++) {
+                    u8 *p = pr + (by + j) * 8 + bx + i;
+                    *p = (u8)clip_u8((int)*p + dc);
+                }
+        }
+    }
+    if (lane == 0) {
+        int m0 = s.cmode[0], m1 = s.cmode[1];
+        int cc = ((m0 & 15) == 2 || (m1 & 15) == 2) ? 2 : (((m0 | m1) & 16) ? 1 : 0);
+        cbp_out[mb] = s.keep8 | (cc << 4);
+    }
+    WAVE_SYNC();
+    // ---- write the reconstruction ----
+    {
+        int r = lane >> 2, x = (lane & 3) * 4;
+        *(u32 *)(dy + oy + (ptrdiff_t)r * g.sy + x) = *(const u32 *)(s.pr + r * 16 + x);
+        if (lane < 32) {
+            int chn = lane >> 4, l = lane & 15, cr = l >> 1, cx4 = (l & 1) * 4;
+            u8 *d = (chn ? dv : du) + oc + (ptrdiff_t)cr * g.sc + cx4;
+            *(u32 *)d = *(const u32 *)(s.pr + 256 + 64 * chn + cr * 8 + cx4);
+        }
+    }
+#undef WAVE_SYNC
+}
+
+extern "C" int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
+                                            x264hip_picture *recon, const x264hip_residual_params *p,
+                                            const int16_t *mv_qpel_dev, int16_t *levels_y_dev, int16_t *levels_c_dev,
+                                            int16_t *dc_c_dev, int32_t *cbp_dev, uint8_t *nnz_dev)
+{
+    if (p->qp < 0 || p->qp > 51 || p->qp_chroma < 0 || p->qp_chroma > 51) { set_error("residual: qp out of range"); return -1; }
+    ResGeom g = {c->d.mb_w, c->d.mb_h, c->d.stride_y, c->d.stride_c, p->qp, p->qp_chroma, !!p->b_interlaced};
+    int n = g.mb_w * g.mb_h;
+    dim3 grid((n + RS_WAVES - 1) / RS_WAVES), block(64 * RS_WAVES);
+#define ARGS fenc->plane[0], fenc->plane[1], fenc->plane[2], ref->filtered[0], ref->filtered[1], ref->filtered[2], ref->filtered[3], \
+        ref->plane[1], ref->plane[2], recon->plane[0], recon->plane[1], recon->plane[2], g, p->quant4_mf, p->quant4_bias, \
+        p->quant8_mf, p->quant8_bias, p->dequant4_mf, p->dequant8_mf, mv_qpel_dev, levels_y_dev, levels_c_dev, dc_c_dev, cbp_dev, nnz_dev
+    if (p->transform8x8) hipLaunchKernelGGL(k_inter_residual<1>, grid, block, 0, c->stream, ARGS);
+    else hipLaunchKernelGGL(k_inter_residual<0>, grid, block, 0, c->stream, ARGS);
+#undef ARGS
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -132,3 +132,24 @@ extern "C" int x264hip_device_synchronize(void)
     HIPCHK(hipDeviceSynchronize());
     return 0;
 }
+
+// ---- HIP events on a caller-named stream (bench.py times kernels on the stream they run on) ----
+extern "C" void *x264hip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void *)e;
+}
+extern "C" void x264hip_event_destroy(void *e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+extern "C" int x264hip_event_record(void *e, void *stream)
+{
+    HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)stream));
+    return 0;
+}
+extern "C" float x264hip_event_elapsed_ms(void *start, void *stop)
+{
+    float ms = -1.0f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
+    return ms;
+}

@@ -30,7 +30,7 @@ class MeParams(C.Structure):
 
 
 class ResidualParams(C.Structure):
-    _fields_ = [("qp", C.c_int), ("transform8x8", C.c_int), ("b_interlaced", C.c_int),
+    _fields_ = [("qp", C.c_int), ("qp_chroma", C.c_int), ("transform8x8", C.c_int), ("b_interlaced", C.c_int),
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p),
                 ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p)]
@@ -140,6 +140,37 @@ class FrameCtx:
         if self.h:
             self.lib.x264hip_frame_ctx_delete(self.h)
             self.h = None
+
+
+def chroma_qp(qp, offset=0):
+    """h->mb.i_chroma_qp: the H.264 chroma QP mapping (table 8-15; R/common/macroblock.h:241-251)."""
+    q = min(max(qp + offset, 0), 51)
+    return q if q < 30 else (29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39)[q - 30]
+
+
+class CqmDevice:
+    """Flat-matrix quantiser tables (x264_cqm_init's output) resident in HBM."""
+
+    def __init__(self, lib, cqm):
+        self.bufs = {
+            "quant4_mf": DeviceArray(lib, cqm["quant4_mf"].shape, np.uint16, cqm["quant4_mf"]),
+            "quant4_bias": DeviceArray(lib, cqm["quant4_bias"].shape, np.uint16, cqm["quant4_bias"]),
+            "quant8_mf": DeviceArray(lib, cqm["quant8_mf"].shape, np.uint16, cqm["quant8_mf"]),
+            "quant8_bias": DeviceArray(lib, cqm["quant8_bias"].shape, np.uint16, cqm["quant8_bias"]),
+            "dequant4_mf": DeviceArray(lib, cqm["dequant4_mf"].shape, np.int32, cqm["dequant4_mf"]),
+            "dequant8_mf": DeviceArray(lib, cqm["dequant8_mf"].shape, np.int32, cqm["dequant8_mf"]),
+        }
+
+    def params(self, qp, transform8x8=0, interlaced=0, chroma_offset=0):
+        b = self.bufs
+        return ResidualParams(qp=qp, qp_chroma=chroma_qp(qp, chroma_offset), transform8x8=transform8x8,
+                              b_interlaced=interlaced, quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr,
+                              quant8_mf=b["quant8_mf"].ptr, quant8_bias=b["quant8_bias"].ptr,
+                              dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr)
+
+    def free(self):
+        for v in self.bufs.values():
+            v.free()
 
 
 def host_plane(stride, lines, padh, padv):

@@ -191,15 +191,19 @@ int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_picture *fe
                                  const int16_t *mv_qpel_dev, int16_t *levels_y_dev, int16_t *levels_c_dev,
                                  int16_t *dc_c_dev, int32_t *cbp_dev, uint8_t *nnz_dev);
 
-/* x264_frame_deblock_row for every row (R/common/frame.c:621-792), inter
- * frame without B-specific rules: bS from intra flag / nnz / mv+ref
- * differences, alpha/beta/tc0 from the per-MB qp, vertical edges of the
- * whole frame first, then horizontal edges (the standard's order per MB is
- * preserved because every edge kernel reads only already-final neighbours).
- *   mb_type_intra : [mb] u8 ; qp : [mb] u8 ; nnz : [mb][24] ; mv : [mb][16][2]
- *   int16 qpel per 4x4 ; ref : [mb][4] int8 per 8x8 ; transform8x8 : [mb] u8 */
+/* x264_frame_deblock_row for every row of a progressive P frame
+ * (R/common/frame.c:621-792): bS from intra flags / nnz / mv+ref differences
+ * (no_sub8x8 partitions), alpha/beta/tc0 from the per-MB qp and the slice
+ * offsets, P_SKIP and low-qp macroblocks filter only their outer edge.
+ * Macroblocks are filtered in the standard's order (raster; vertical then
+ * horizontal edges): the frame is swept in 2:1 anti-diagonals, one launch per
+ * diagonal, because MB (x,y) needs (x-1,y) and (x+1,y-1) finished.
+ *   mb_type : [mb] u8, 0 inter, 1 intra, 2 P_SKIP ; qp : [mb] u8 ;
+ *   nnz : [mb][26] as x264hip_inter_residual_frame writes it ;
+ *   mv : [mb][16][2] int16 qpel per 4x4 block in raster order ;
+ *   ref : [mb][4] int8 per 8x8 ; transform8x8 : [mb] u8 (all device) */
 typedef struct {
-    const uint8_t *mb_intra, *qp, *nnz, *transform8x8;
+    const uint8_t *mb_type, *qp, *nnz, *transform8x8;
     const int16_t *mv;
     const int8_t  *ref;
     int alpha_c0_offset, beta_offset, chroma_qp_offset;

@@ -383,3 +383,102 @@ void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* sourc
         for (int y = 0; y < 8; y++) { memcpy(du + ocs + y * sc, fd_u + y * FDEC, 8); memcpy(dv + ocs + y * sc, fd_v + y * FDEC, 8); }
     }
 }
+
+/* ----------------------------------------------------------------- deblock
+ * x264_frame_deblock_row for every row of a progressive P frame
+ * (R/common/frame.c:621-792), macroblocks in raster order, vertical edges
+ * then horizontal edges of each.  Tables: the standard's alpha / beta / tc0
+ * (R/common/frame.c:377-417).
+ *   mb_type: 0 inter, 1 intra, 2 P_SKIP; nnz: [mb][26] in block z-order (as
+ *   x264hip_inter_residual_frame writes it); mv: [mb][16][2] qpel, 4x4
+ *   blocks in raster order; ref: [mb][4] per 8x8. */
+static const u8 db_alpha[52 + 24] = {
+    0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,4,4,5,6,7,8,9,10,12,13,15,17,20,22,25,28,32,36,40,45,50,56,63,71,
+    80,90,101,113,127,144,162,182,203,226,255,255, 255,255,255,255,255,255,255,255,255,255,255,255};
+static const u8 db_beta[52 + 24] = {
+    0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,2,2,3,3,3,3,4,4,4,6,6,7,7,8,8,9,9,10,10,11,11,12,12,
+    13,13,14,14,15,15,16,16,17,17,18,18, 18,18,18,18,18,18,18,18,18,18,18,18};
+static const int8_t db_tc0[52 + 24][3] = {   /* bS 1..3; bS 0 is -1 */
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+    {0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},{0,0,0},
+    {0,0,1},{0,0,1},{0,0,1},{0,0,1},{0,1,1},{0,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,1},{1,1,2},{1,1,2},{1,1,2},{1,1,2},{1,2,3},{1,2,3},
+    {2,2,3},{2,2,4},{2,3,4},{2,3,4},{3,3,5},{3,4,6},{3,4,6},{4,5,7},{4,5,8},{4,6,9},{5,7,10},{6,8,11},{6,8,13},{7,10,14},{8,11,16},
+    {9,12,18},{10,13,20},{11,15,23},{13,17,25},
+    {13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25},{13,17,25}};
+static const u8 db_chroma_qp[52 + 24] = {
+    0,0,0,0,0,0,0,0,0,0,0,0, 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,
+    29,30,31,32,32,33,34,34,35,35,36,36,37,37,37,38,38,38,39,39,39,39, 39,39,39,39,39,39,39,39,39,39,39,39};
+static int z_of(int x, int y) { return (y >> 1) * 8 + (x >> 1) * 4 + (y & 1) * 2 + (x & 1); }
+
+static void db_edge(u8 *p1, u8 *p2, int stride, const u8 bS[4], int qp, int chroma, int a_off, int b_off,
+                    x264hip_deblock_inter_t f)
+{   /* deblock_edge, R/common/frame.c:588-606 */
+    int ia = qp + a_off, alpha = db_alpha[ia + 12], beta = db_beta[qp + b_off + 12];
+    int8_t tc[4];
+    if (!alpha || !beta) return;
+    for (int i = 0; i < 4; i++) tc[i] = (bS[i] ? db_tc0[ia + 12][bS[i] - 1] : -1) + chroma;
+    f(p1, stride, alpha, beta, tc);
+    if (chroma) f(p2, stride, alpha, beta, tc);
+}
+static void db_edge_intra(u8 *p1, u8 *p2, int stride, int qp, int chroma, int a_off, int b_off, x264hip_deblock_intra_t f)
+{   /* deblock_edge_intra, :608-619 */
+    int alpha = db_alpha[qp + a_off + 12], beta = db_beta[qp + b_off + 12];
+    if (!alpha || !beta) return;
+    f(p1, stride, alpha, beta);
+    if (chroma) f(p2, stride, alpha, beta);
+}
+
+void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int sc,
+                         const u8 *mb_type, const u8 *qp, const u8 *nnz, const u8 *t8x8, const i16 *mv, const int8_t *ref,
+                         int a_off, int b_off, int cqp_off)
+{
+    init();
+    int qp_thresh = 15 - (a_off < b_off ? a_off : b_off) - (cqp_off > 0 ? cqp_off : 0);
+    const u8 *cqt = db_chroma_qp + 12 + cqp_off;
+    for (int mby = 0; mby < mb_h; mby++)
+        for (int mbx = 0; mbx < mb_w; mbx++) {
+            int mb = mby * mb_w + mbx, t8 = t8x8[mb], q = qp[mb];
+            int edge_end = (mb_type[mb] == 2 || q <= qp_thresh) ? 1 : 4;
+            u8 *piy = py + 16 * mby * sy + 16 * mbx, *piu = pu + 8 * mby * sc + 8 * mbx, *piv = pv + 8 * mby * sc + 8 * mbx;
+            for (int dir = 0; dir < 2; dir++) {
+                /* edge 0 (shared with the left / top macroblock) is filtered whenever that
+                 * neighbour exists; inner edges 1+t8, ... only below edge_end (:744-780) */
+                int at_border = dir ? mby == 0 : mbx == 0;
+                for (int edge = at_border ? 1 + t8 : 0; edge == 0 || edge < edge_end; edge = edge ? edge + t8 + 1 : t8 + 1) {
+                    int mbn = edge ? mb : (dir ? mb - mb_w : mb - 1), qn = qp[mbn];
+                    u8 bS[4] = {0, 0, 0, 0};
+                    int intra_edge = edge == 0 && (mb_type[mb] == 1 || mb_type[mbn] == 1);
+                    u8 *ly = dir ? piy + 4 * edge * sy : piy + 4 * edge;
+                    u8 *lu = dir ? piu + 2 * edge * sc : piu + 2 * edge, *lv = dir ? piv + 2 * edge * sc : piv + 2 * edge;
+                    int qpa = (q + qn + 1) >> 1, qpc = (cqt[q] + cqt[qn] + 1) >> 1;
+                    if (intra_edge) {
+                        db_edge_intra(ly, 0, sy, qpa, 0, a_off, b_off, dir ? dbf.deblock_v_luma_intra : dbf.deblock_h_luma_intra);
+                        if (!(edge & 1))
+                            db_edge_intra(lu, lv, sc, qpc, 1, a_off, b_off, dir ? dbf.deblock_v_chroma_intra : dbf.deblock_h_chroma_intra);
+                    } else {
+                        /* DEBLOCK_STRENGTH, :697-742 (P slice, 16x16 / 8x8 partitions: no_sub8x8 = 1) */
+                        if (mb_type[mb] == 1 || mb_type[mbn] == 1) bS[0] = bS[1] = bS[2] = bS[3] = 3;
+                        else
+                            for (int i = 0; i < 4; i++) {
+                                int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
+                                int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
+                                if (nnz[mb * 26 + z_of(x, y)] || nnz[mbn * 26 + z_of(xn, yn)]) bS[i] = 2;
+                                else if (!(edge & 1)) {
+                                    if ((i & 1) && bS[i - 1] != 2) bS[i] = bS[i - 1];
+                                    else {
+                                        const i16 *mp = mv + (mb * 16 + x + 4 * y) * 2, *mq = mv + (mbn * 16 + xn + 4 * yn) * 2;
+                                        int rp = ref[mb * 4 + (x >> 1) + (y >> 1) * 2], rq = ref[mbn * 4 + (xn >> 1) + (yn >> 1) * 2];
+                                        if (rp != rq || abs(mp[0] - mq[0]) >= 4 || abs(mp[1] - mq[1]) >= 4) bS[i] = 1;
+                                    }
+                                }
+                            }
+                        if (bS[0] | bS[1] | bS[2] | bS[3]) {
+                            db_edge(ly, 0, sy, bS, qpa, 0, a_off, b_off, dir ? dbf.deblock_v_luma : dbf.deblock_h_luma);
+                            if (!(edge & 1))
+                                db_edge(lu, lv, sc, bS, qpc, 1, a_off, b_off, dir ? dbf.deblock_v_chroma : dbf.deblock_h_chroma);
+                        }
+                    }
+                }
+            }
+        }
+}

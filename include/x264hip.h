@@ -76,9 +76,6 @@ int x264_predict_8x8c_init_hip(x264hip_predict_t pf[7]);            /* R/common/
 int x264_predict_4x4_init_hip(x264hip_predict_t pf[12]);            /* R/common/predict.c:818 */
 int x264_predict_8x8_init_hip(x264hip_predict8x8_t pf[12], x264hip_predict_8x8_filter_t *filter); /* predict.c:795 */
 int x264_deblock_init_hip(x264hip_deblock_function_t *pf);          /* R/common/frame.c:835 */
-/* plane drivers that take a table in the reference (R/common/pixel.c:98,471) */
-int64_t x264hip_pixel_ssd_wxh(uint8_t *pix1, int i_pix1, uint8_t *pix2, int i_pix2, int i_width, int i_height);
-float   x264hip_pixel_ssim_wxh(uint8_t *pix1, int i_pix1, uint8_t *pix2, int i_pix2, int i_width, int i_height, void *buf);
 
 /* ---- frame level -------------------------------------------------------------
  * Plane layout follows x264_frame_new (R/common/frame.c:29-152): every plane
@@ -130,6 +127,8 @@ int x264hip_lowres_init_frame(x264hip_frame_ctx *c, x264hip_picture *pic);
 int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, int32_t *out_dev);
 /* x264_pixel_ssd_wxh over the three planes (PSNR, R/encoder/encoder.c:1034-1045) */
 int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3]);
+/* same, stream-ordered with the three sums left in device memory (no host sync) */
+int x264hip_ssd_frame_async(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, uint64_t *ssd_dev3);
 
 /* Motion search, one wavefront per macroblock (x264_me_search_ref's full-pel
  * stage as an exhaustive +-range window, R/encoder/me.c:156-631 with the ESA
@@ -185,6 +184,10 @@ typedef struct {
     const uint16_t *quant8_mf, *quant8_bias;   /* device [2][52][64] */
     const int32_t  *dequant4_mf;               /* device [4][6][16]  */
     const int32_t  *dequant8_mf;               /* device [2][6][64]  */
+    /* optional (NULL = skip): the frame's mv / ref arrays as x264_macroblock_cache_save
+     * leaves them (R/common/macroblock.c:1264-1295): [mb][16][2] qpel, [mb][4] ref idx */
+    int16_t *mv4x4_out;
+    int8_t  *ref_out;
 } x264hip_residual_params;
 int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
                                  x264hip_picture *recon, const x264hip_residual_params *p,

@@ -1,41 +1,20 @@
-"""Helpers for frame-level parity tests: host images in the device layout and
-ctypes access to the CPU twin (oracle/frame_oracle.c)."""
-import ctypes as C
-
-import numpy as np
-
+"""Helpers for frame-level parity tests: host images in the device layout
+(oracle/hostpic.py) tied to a FrameCtx."""
+from oracle import hostpic
 from x264_vs2008_amd import synth
 
-u8p = C.POINTER(C.c_uint8)
 
+class HostPic(hostpic.HostPic):
+    """Host twin of x264hip_picture; geometry cross-checked against the device context."""
 
-class HostPic:
-    """Host twin of x264hip_picture with identical padded geometry."""
-
-    def __init__(self, ctx, pic):
+    def __init__(self, ctx, pic=None):
         d = ctx.dims
+        g = hostpic.Geometry(d.width, d.height)
+        assert (g.mb_w, g.mb_h, g.stride_y, g.stride_c) == (d.mb_w, d.mb_h, d.stride_y, d.stride_c)
+        if pic is not None:
+            assert (g.stride_lowres, g.width_lowres, g.lines_lowres) == (pic.stride_lowres, pic.width_lowres, pic.lines_lowres)
+        super().__init__(g)
         self.ctx, self.d = ctx, d
-        self.w16, self.h16 = d.mb_w * 16, d.lines_y
-        self.full = {}
-        for name in ("y", "u", "v", "h", "vv", "c", "l0", "lh", "lv", "lc"):
-            stride, w, h, padh, padv = ctx.geometry(pic, name)
-            self.full[name] = (np.zeros((h + 2 * padv + 1, stride), np.uint8), stride, w, h, padh, padv)
-
-    def arr(self, name):
-        """Full padded image, shaped like FrameCtx.download(padded=True)."""
-        a, stride, w, h, padh, padv = self.full[name]
-        return a[:h + 2 * padv]
-
-    def ptr(self, name, x=0, y=0):
-        a, stride, w, h, padh, padv = self.full[name]
-        return C.cast(a.ctypes.data + (padv + y) * stride + padh + x, u8p)
-
-    def stride(self, name):
-        return self.full[name][1]
-
-    def set_visible(self, name, img):
-        a, stride, w, h, padh, padv = self.full[name]
-        a[padv:padv + img.shape[0], padh:padh + img.shape[1]] = img
 
 
 def make_clip_frame(ctx, pic, t, ora):
@@ -45,8 +24,5 @@ def make_clip_frame(ctx, pic, t, ora):
     y, u, v = synth.frame(d.width, d.height, t)
     ctx.upload(pic, y, u, v)
     hp = HostPic(ctx, pic)
-    for name, img in (("y", y), ("u", u), ("v", v)):
-        hp.set_visible(name, img)
-        _, stride, w16, h16, _, _ = hp.full[name]
-        ora.x264o_plane_pad_mod16(hp.ptr(name), stride, img.shape[1], img.shape[0], w16, h16)
+    hp.load_yuv(ora, "x264o_", y, u, v)
     return hp

@@ -382,14 +382,22 @@ extern "C" int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture 
     return 0;
 }
 
-extern "C" int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3])
+extern "C" int x264hip_ssd_frame_async(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, uint64_t *ssd_dev)
 {
     const x264hip_frame_dims &d = c->d;
-    HIPCHK(hipMemsetAsync(c->ssd_dev, 0, 24, c->stream));
+    HIPCHK(hipMemsetAsync(ssd_dev, 0, 24, c->stream));
     for (int i = 0; i < 3; i++) {
         int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y;
-        hipLaunchKernelGGL(k_ssd, dim3(4, h < 256 ? h : 256), dim3(256), 0, c->stream, a->plane[i], st, b->plane[i], st, w, h, c->ssd_dev + i);
+        hipLaunchKernelGGL(k_ssd, dim3(4, h < 256 ? h : 256), dim3(256), 0, c->stream, a->plane[i], st, b->plane[i], st, w, h,
+                           (unsigned long long *)ssd_dev + i);
     }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3])
+{
+    if (x264hip_ssd_frame_async(c, a, b, (uint64_t *)c->ssd_dev)) return -1;
     HIPCHK(hipMemcpyAsync(ssd_host, c->ssd_dev, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

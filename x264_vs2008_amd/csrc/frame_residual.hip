@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
     u8 *__restrict__ dy, u8 *__restrict__ du, u8 *__restrict__ dv, ResGeom g,
     const u16 *__restrict__ q4mf, const u16 *__restrict__ q4bias, const u16 *__restrict__ q8mf, const u16 *__restrict__ q8bias,
     const int *__restrict__ dq4, const int *__restrict__ dq8, const i16 *__restrict__ mv,
-    i16 *__restrict__ levels_y, i16 *__restrict__ levels_c, i16 *__restrict__ dc_c, int *__restrict__ cbp_out, u8 *__restrict__ nnz_out)
+    i16 *__restrict__ levels_y, i16 *__restrict__ levels_c, i16 *__restrict__ dc_c, int *__restrict__ cbp_out, u8 *__restrict__ nnz_out,
+    i16 *__restrict__ mv4x4_out, signed char *__restrict__ ref_out)
 {
     __shared__ ResLds s_all[RS_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -321,6 +322,12 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
         cbp_out[mb] = s.keep8 | (cc << 4);
     }
     WAVE_SYNC();
+    // ---- per-frame mv / ref arrays as x264_macroblock_cache_save leaves them (R/common/macroblock.c:1264-1295) ----
+    if (mv4x4_out && lane < 16) {
+        mv4x4_out[((size_t)mb * 16 + lane) * 2] = (i16)mvx;
+        mv4x4_out[((size_t)mb * 16 + lane) * 2 + 1] = (i16)mvy;
+    }
+    if (ref_out && lane < 4) ref_out[(size_t)mb * 4 + lane] = 0;
     // ---- write the reconstruction ----
     {
         int r = lane >> 2, x = (lane & 3) * 4;
@@ -345,7 +352,8 @@ extern "C" int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_
     dim3 grid((n + RS_WAVES - 1) / RS_WAVES), block(64 * RS_WAVES);
 #define ARGS fenc->plane[0], fenc->plane[1], fenc->plane[2], ref->filtered[0], ref->filtered[1], ref->filtered[2], ref->filtered[3], \
         ref->plane[1], ref->plane[2], recon->plane[0], recon->plane[1], recon->plane[2], g, p->quant4_mf, p->quant4_bias, \
-        p->quant8_mf, p->quant8_bias, p->dequant4_mf, p->dequant8_mf, mv_qpel_dev, levels_y_dev, levels_c_dev, dc_c_dev, cbp_dev, nnz_dev
+        p->quant8_mf, p->quant8_bias, p->dequant4_mf, p->dequant8_mf, mv_qpel_dev, levels_y_dev, levels_c_dev, dc_c_dev, cbp_dev, nnz_dev, \
+        p->mv4x4_out, (signed char *)p->ref_out
     if (p->transform8x8) hipLaunchKernelGGL(k_inter_residual<1>, grid, block, 0, c->stream, ARGS);
     else hipLaunchKernelGGL(k_inter_residual<0>, grid, block, 0, c->stream, ARGS);
 #undef ARGS

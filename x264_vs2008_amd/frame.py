@@ -33,7 +33,8 @@ class ResidualParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("qp_chroma", C.c_int), ("transform8x8", C.c_int), ("b_interlaced", C.c_int),
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p),
                 ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
-                ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p)]
+                ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
+                ("mv4x4_out", C.c_void_p), ("ref_out", C.c_void_p)]
 
 
 class DeblockParams(C.Structure):

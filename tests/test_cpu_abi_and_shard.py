@@ -1,0 +1,117 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares
+(no compute, no GPU), host-side helpers, and the N > 1 frame-sharding path on
+two gloo ranks."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(path):
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    names = re.findall(r"\b(x264(?:hip)?_\w+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_t")))
+
+
+def test_library_exports_every_declared_symbol():
+    from x264_vs2008_amd import lib as L
+    if not os.path.exists(L.SO_PATH):
+        L.build()
+    lib = L.open_library()
+    declared = _declared_functions(os.path.join(ROOT, "include", "x264hip.h"))
+    assert len(declared) > 30
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, "declared in include/x264hip.h but not exported: %s" % missing
+
+
+def test_init_fails_loudly_without_gpu_or_inits_with_one():
+    """No CPU fallback: without a device x264hip_init returns < 0 with a message and the
+    table fillers refuse to fill; with a device it returns 0."""
+    from x264_vs2008_amd import lib as L
+    from x264_vs2008_amd.tables import PixelTable
+    lib = L.open_library()
+    n = lib.x264hip_device_count()
+    cfg = L.Cfg(0, 0)
+    rc = lib.x264hip_init(C.byref(cfg))
+    if n == 0:
+        assert rc < 0 and lib.x264hip_last_error()
+        t = PixelTable()
+        assert lib.x264_pixel_init_hip(C.byref(t)) == -1
+        assert not any(bool(f) for f in t.sad)
+    else:
+        assert rc == 0
+
+
+def test_table_struct_sizes_match_header():
+    """ctypes mirrors vs the C header: compile a tiny program printing sizeof() of each table."""
+    from x264_vs2008_amd import tables as T
+    prog = r'''
+#include <stdio.h>
+#include "x264hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_pixel_function_t), sizeof(x264hip_dct_function_t),
+ sizeof(x264hip_zigzag_function_t), sizeof(x264hip_quant_function_t), sizeof(x264hip_mc_functions_t),
+ sizeof(x264hip_deblock_function_t), sizeof(x264hip_run_level_t), sizeof(x264hip_picture), sizeof(x264hip_me_params)); return 0; }
+'''
+    exe = os.path.join(ROOT, "tests", "_sizes.bin")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog.encode(), check=True)
+    try:
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    finally:
+        os.remove(exe)
+    from x264_vs2008_amd.frame import MeParams, Picture
+    want = [C.sizeof(T.PixelTable), C.sizeof(T.DctTable), C.sizeof(T.ZigzagTable), C.sizeof(T.QuantTable), C.sizeof(T.McTable),
+            C.sizeof(T.DeblockTable), C.sizeof(T.RunLevel), C.sizeof(Picture), C.sizeof(MeParams)]
+    assert got == want
+
+
+def test_cost_mv_table_properties():
+    from x264_vs2008_amd.frame import cost_mv_table
+    t = cost_mv_table(4, 64).astype(np.int64)
+    assert t[64] == int(4 * 0.718 + 0.5) and np.array_equal(t, t[::-1]) and (np.diff(t[64:]) >= 0).all()
+
+
+def test_gop_sharding_covers_every_frame_once():
+    from x264_vs2008_amd import shard
+    for n, k, w in ((100, 12, 4), (24, 250, 8), (97, 10, 3), (8, 1, 8)):
+        seen = sorted(f for r in range(w) for f in shard.frames_for_rank(n, k, r, w))
+        assert seen == list(range(n))
+        for r in range(w):
+            for a, b in shard.gops_for_rank(n, k, r, w):
+                assert a % k == 0 and b - a <= k
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from x264_vs2008_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mine = shard.frames_for_rank(1000, 24, rank, world)
+mask = torch.zeros(1000, dtype=torch.int32); mask[mine] = 1
+dist.all_reduce(mask)                                   # every frame owned exactly once across ranks
+t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's timing reduce
+dist.barrier()
+assert int(mask.min()) == 1 and int(mask.max()) == 1 and float(t[0]) == world - 0.5
+print("rank", rank, "ok", len(mine))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

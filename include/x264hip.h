@@ -91,6 +91,7 @@ typedef struct {
     int mb_w, mb_h;           /* filled by x264hip_frame_ctx_new */
     int stride_y, stride_c;   /* filled by x264hip_frame_ctx_new */
     int lines_y, lines_c;     /* coded lines */
+    int batch;                /* in: independent frames processed per launch (one per GOP chain); 0 = 1 */
 } x264hip_frame_dims;
 
 /* one picture resident in HBM: source (fenc) or reconstruction (fdec/ref) */
@@ -108,6 +109,12 @@ void *x264hip_frame_ctx_stream(x264hip_frame_ctx *c);
 int   x264hip_picture_alloc(x264hip_frame_ctx *c, x264hip_picture *pic);
 void  x264hip_picture_free(x264hip_frame_ctx *c, x264hip_picture *pic);
 int   x264hip_sync(x264hip_frame_ctx *c);
+/* Batching: a context created with dims.batch = B holds B independent frames per picture (one per
+ * GOP chain); every *_frame call below processes all B in the same launches (blockIdx.z).  Each
+ * plane pointer of a picture addresses element 0; element b lies b * (padded plane size rounded to
+ * 256 B) further.  Per-macroblock device arrays are B consecutive [n_mb][...] blocks.  upload /
+ * download / x264hip_ssd_frame address the element chosen here (default 0).                      */
+int   x264hip_frame_ctx_select(x264hip_frame_ctx *c, int batch_index);
 
 /* x264_frame_copy_picture + border pad (R/common/frame.c:185-216, encoder.c:1406-1411):
  * host I420 -> device planes, then edges replicated into the padding.      */

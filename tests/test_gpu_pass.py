@@ -2,7 +2,9 @@
 three references, residual, deblock, borders, half-pel planes, SSD), chained
 over several frames so every reconstruction becomes the next frame's
 reference, against the same chain run on the CPU twin.  Every array and every
-plane -- padding included -- must be identical after each frame."""
+plane -- padding included -- must be identical after each frame.  With
+batch > 1 several independent chains (different content) ride in the same
+launches and each must match its own CPU chain."""
 import numpy as np
 import pytest
 
@@ -15,41 +17,52 @@ from x264_vs2008_amd.pipeline import PFramePass, setup_event_api
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("size,qp,t8,frames", [((352, 288), 26, 1, 4), ((200, 120), 32, 0, 3)])
-def test_chained_pass_matches_cpu_twin(hip_lib, oracle_lib, cqm, size, qp, t8, frames):
+@pytest.mark.parametrize("size,qp,t8,frames,batch", [((352, 288), 26, 1, 4, 1), ((200, 120), 32, 0, 3, 3),
+                                                   ((352, 288), 20, 1, 2, 2)])
+def test_chained_pass_matches_cpu_twin(hip_lib, oracle_lib, cqm, size, qp, t8, frames, batch):
     setup_event_api(hip_lib)
-    ctx = FrameCtx(hip_lib, *size)
+    ctx = FrameCtx(hip_lib, *size, batch=batch)
     try:
         d = ctx.dims
         g = hostpic.Geometry(d.width, d.height)
         pas = PFramePass(hip_lib, ctx, cqm, qp=qp, transform8x8=t8, n_refs=3)
+        t0 = lambda b: 17 * b          # every batch element is a different clip position
+
+        def load(pic, hps, t):
+            for b in range(batch):
+                y, u, v = synth.frame(d.width, d.height, t0(b) + t)
+                ctx.upload(pic, y, u, v, b=b)
+                hps[b].load_yuv(oracle_lib, "x264o_", y, u, v)
+
         # three initial references = source frames 0..2 (as if coded losslessly)
         dev_refs, host_refs = [], []
         for t in (2, 1, 0):
-            pic = ctx.new_picture(); hp = HostPic(ctx, pic)
-            y, u, v = synth.frame(d.width, d.height, t)
-            ctx.upload(pic, y, u, v); hp.load_yuv(oracle_lib, "x264o_", y, u, v)
-            pas.make_reference(pic); hostpic.make_reference(oracle_lib, "x264o_", hp)
-            dev_refs.append(pic); host_refs.append(hp)
+            pic = ctx.new_picture(); hps = [HostPic(ctx, pic) for _ in range(batch)]
+            load(pic, hps, t)
+            pas.make_reference(pic)
+            for hp in hps:
+                hostpic.make_reference(oracle_lib, "x264o_", hp)
+            dev_refs.append(pic); host_refs.append(hps)
         for t in range(3, 3 + frames):
-            cur = ctx.new_picture(); hcur = HostPic(ctx, cur)
-            y, u, v = synth.frame(d.width, d.height, t)
-            ctx.upload(cur, y, u, v); hcur.load_yuv(oracle_lib, "x264o_", y, u, v)
-            recon = ctx.new_picture(); hrec = HostPic(ctx, recon)
+            cur = ctx.new_picture(); hcur = [HostPic(ctx, cur) for _ in range(batch)]
+            load(cur, hcur, t)
+            recon = ctx.new_picture(); hrec = [HostPic(ctx, recon) for _ in range(batch)]
             pas.step(cur, dev_refs, recon)
-            got = pas.results()
-            want = hostpic.cpu_pframe_pass(oracle_lib, "x264o_", g, hcur, host_refs, hrec, cqm, qp, chroma_qp(qp),
-                                           pas.cost_tab, len(pas.cost_tab) // 2, pas.me_range, t8)
-            for k in ("aq", "cbp", "nnz", "levels_y", "levels_c", "dc_c", "ssd"):
-                assert np.array_equal(got[k], want[k]), "frame %d: %s" % (t, k)
-            for i in range(3):
-                for k in ("mv9", "cost9", "mvq", "costq"):
-                    assert np.array_equal(got[k][i], want[k][i]), "frame %d ref %d: %s" % (t, i, k)
-            for name in ("y", "u", "v", "h", "vv", "c"):
-                assert np.array_equal(ctx.download(recon, name), hrec.arr(name)), "frame %d recon plane %s" % (t, name)
-            for name in ("l0", "lh", "lv", "lc"):
-                assert np.array_equal(ctx.download(cur, name), hcur.arr(name)), "frame %d lowres %s" % (t, name)
+            for b in range(batch):
+                got = pas.results(b)
+                want = hostpic.cpu_pframe_pass(oracle_lib, "x264o_", g, hcur[b], [r[b] for r in host_refs], hrec[b], cqm, qp,
+                                               chroma_qp(qp), pas.cost_tab, len(pas.cost_tab) // 2, pas.me_range, t8)
+                tag = "frame %d batch %d: " % (t, b)
+                for k in ("aq", "cbp", "nnz", "levels_y", "levels_c", "dc_c", "ssd"):
+                    assert np.array_equal(got[k], want[k]), tag + k
+                for i in range(3):
+                    for k in ("mv9", "cost9", "mvq", "costq"):
+                        assert np.array_equal(got[k][i], want[k][i]), tag + "ref %d %s" % (i, k)
+                for name in ("y", "u", "v", "h", "vv", "c"):
+                    assert np.array_equal(ctx.download(recon, name, b=b), hrec[b].arr(name)), tag + "recon plane " + name
+                for name in ("l0", "lh", "lv", "lc"):
+                    assert np.array_equal(ctx.download(cur, name, b=b), hcur[b].arr(name)), tag + "lowres " + name
+                assert got["cbp"].any()
             dev_refs = [recon] + dev_refs[:2]; host_refs = [hrec] + host_refs[:2]
-        assert got["cbp"].any()
     finally:
         ctx.close()

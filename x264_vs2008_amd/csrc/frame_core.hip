@@ -34,8 +34,9 @@ __global__ void k_pad_mod16(u8 *p, int stride, int w, int h, int w16, int h16)
 // every padding byte takes the nearest interior pixel (left/right bands first,
 // then whole rows copied up/down, which is the same thing).
 // Grid: y over [-padv, height+padv), x in dwords over [-padh, width+padh).
-__global__ void k_expand_border(u8 *pix, int stride, int width, int height, int padh, int padv)
+__global__ void k_expand_border(u8 *pix, size_t bs, int stride, int width, int height, int padh, int padv)
 {
+    pix += bs * blockIdx.z;
     int xq = blockIdx.x * blockDim.x + threadIdx.x;      // dword index from -padh
     int y = (int)blockIdx.y - padv;
     int x = xq * 4 - padh;
@@ -62,8 +63,9 @@ __global__ void k_expand_border(u8 *pix, int stride, int width, int height, int 
 #define HP_TW 64
 #define HP_TH 16
 __global__ __launch_bounds__(256) void k_hpel(const u8 *__restrict__ src, u8 *__restrict__ dh, u8 *__restrict__ dv,
-                                              u8 *__restrict__ dc, int stride, int x_lo, int y_lo, int nx, int ny)
+                                              u8 *__restrict__ dc, size_t bs, int stride, int x_lo, int y_lo, int nx, int ny)
 {
+    src += bs * blockIdx.z; dh += bs * blockIdx.z; dv += bs * blockIdx.z; dc += bs * blockIdx.z;
     __shared__ u32 s_src[21 * 18];          // 21 rows x 72 bytes, column 0 = x0 - 4
     __shared__ i16 s_v[HP_TH * 72];         // raw vertical 6-tap, column 0 = x0 - 4
     const int tid = threadIdx.x;
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(256) void k_hpel(const u8 *__restrict__ src, u8 *__
 // frame_init_lowres_core (R/common/mc.c:333-357): four half-resolution planes.
 // Each thread makes 4 consecutive pixels of each plane from three source rows.
 __global__ __launch_bounds__(256) void k_lowres(const u8 *__restrict__ src, u8 *__restrict__ d0, u8 *__restrict__ dh,
-                                                u8 *__restrict__ dv, u8 *__restrict__ dc, int ss, int ds, int w, int h)
+                                                u8 *__restrict__ dv, u8 *__restrict__ dc, size_t bs_src, size_t bs_dst, int ss, int ds, int w, int h)
 {
+    src += bs_src * blockIdx.z; d0 += bs_dst * blockIdx.z; dh += bs_dst * blockIdx.z; dv += bs_dst * blockIdx.z; dc += bs_dst * blockIdx.z;
     int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w || y >= h) return;
     const u8 *r0 = src + (ptrdiff_t)2 * y * ss + 2 * x, *r1 = r0 + ss, *r2 = r1 + ss;
@@ -148,13 +151,15 @@ __global__ __launch_bounds__(256) void k_lowres(const u8 *__restrict__ src, u8 *
 }
 // x264_frame_init_lowres's edge duplication (R/common/mc.c:314-317): column
 // `width` := column width-1 for rows < height, then row `height` := row height-1.
-__global__ void k_dup_edge(u8 *p, int stride, int width, int height)
+__global__ void k_dup_edge(u8 *p, size_t bs, int stride, int width, int height)
 {
+    p += bs * blockIdx.z;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < height) p[(ptrdiff_t)i * stride + width] = p[(ptrdiff_t)i * stride + width - 1];
 }
-__global__ void k_dup_row(u8 *p, int stride, int width, int height)
+__global__ void k_dup_row(u8 *p, size_t bs, int stride, int width, int height)
 {
+    p += bs * blockIdx.z;
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x < width) p[(ptrdiff_t)height * stride + x] = p[(ptrdiff_t)(height - 1) * stride + x];
 }
@@ -163,8 +168,9 @@ __global__ void k_dup_row(u8 *p, int stride, int width, int height)
 // (ac_energy_mb, R/encoder/ratecontrol.c:171-195; pixel var R/common/pixel.c:142-161).
 // One wavefront per macroblock: lane = (row, 4-pixel group).
 __global__ __launch_bounds__(256) void k_aq_var(const u8 *__restrict__ py, const u8 *__restrict__ pu, const u8 *__restrict__ pv,
-                                                int sy, int sc, int mb_w, int mb_count, int *__restrict__ out)
+                                                size_t bs_y, size_t bs_c, int sy, int sc, int mb_w, int mb_count, int *__restrict__ out)
 {
+    py += bs_y * blockIdx.z; pu += bs_c * blockIdx.z; pv += bs_c * blockIdx.z; out += (size_t)mb_count * blockIdx.z;
     int mb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (mb >= mb_count) return;
     int mx = mb % mb_w, my = mb / mb_w;
@@ -190,8 +196,9 @@ __global__ __launch_bounds__(256) void k_aq_var(const u8 *__restrict__ py, const
 
 // sum of squared differences of two planes (x264_pixel_ssd_wxh, R/common/pixel.c:98-136)
 __global__ __launch_bounds__(256) void k_ssd(const u8 *__restrict__ a, int sa, const u8 *__restrict__ b, int sb,
-                                             int w, int h, unsigned long long *acc)
+                                             size_t bs, int w, int h, unsigned long long *acc)
 {
+    a += bs * blockIdx.z; b += bs * blockIdx.z; acc += 3 * blockIdx.z;
     unsigned long long part = 0;
     int nq = (w + 3) >> 2;
     for (int y = blockIdx.y; y < h; y += gridDim.y)
@@ -205,12 +212,11 @@ __global__ __launch_bounds__(256) void k_ssd(const u8 *__restrict__ a, int sa, c
 }
 
 // --------------------------------------------------------------------- host
-static int alloc_plane(u8 **out, int stride, int lines, int padh, int padv, hipStream_t s)
+static int alloc_plane(u8 **out, int stride, int lines, int padh, int padv, int batch, size_t bs, hipStream_t s)
 {
-    size_t bytes = (size_t)stride * (lines + 2 * padv);
     u8 *base = nullptr;
-    HIPCHK(hipMalloc((void **)&base, bytes + 256));
-    HIPCHK(hipMemsetAsync(base, 0, bytes + 256, s));
+    HIPCHK(hipMalloc((void **)&base, bs * batch + 256));
+    HIPCHK(hipMemsetAsync(base, 0, bs * batch + 256, s));
     *out = base + (size_t)stride * padv + padh;
     return 0;
 }
@@ -226,19 +232,27 @@ extern "C" x264hip_frame_ctx *x264hip_frame_ctx_new(x264hip_frame_dims *d, void 
         set_error("unsupported frame size %dx%d", d->width, d->height);
         return nullptr;
     }
+    if (d->batch < 0 || d->batch > 4096) { set_error("unsupported batch %d", d->batch); return nullptr; }
     x264hip_frame_ctx *c = (x264hip_frame_ctx *)calloc(1, sizeof(*c));
     if (!c) return nullptr;
+    if (d->batch == 0) d->batch = 1;
     d->mb_w = (d->width + 15) / 16; d->mb_h = (d->height + 15) / 16;
     d->stride_y = align_up(d->mb_w * 16 + 2 * PADH, 16);
     d->stride_c = align_up(d->stride_y >> 1, 16);
     d->lines_y = d->mb_h * 16; d->lines_c = d->lines_y / 2;
     c->d = *d;
+    c->batch = d->batch; c->sel = 0;
     c->width16 = d->mb_w * 16; c->lines16 = d->lines_y;
+    c->width_l = c->width16 / 2; c->lines_l = d->lines_y / 2; c->stride_l = align_up(c->width_l + 2 * PADH, 16);
+    // +stride slack: tile loaders may read a few dwords past the last padded row's end
+    c->bs_y = align_up_sz((size_t)d->stride_y * (d->lines_y + 2 * PADV + 1), 256);
+    c->bs_c = align_up_sz((size_t)d->stride_c * (d->lines_c + PADV + 1), 256);
+    c->bs_l = align_up_sz((size_t)c->stride_l * (c->lines_l + 2 * PADV + 1), 256);
     if (hipSetDevice(device_id()) != hipSuccess) { free(c); return nullptr; }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return nullptr; }
     else c->own_stream = true;
-    if (hipMalloc((void **)&c->ssd_dev, 64) != hipSuccess) { free(c); return nullptr; }
+    if (hipMalloc((void **)&c->ssd_dev, 24 * (size_t)c->batch + 64) != hipSuccess) { free(c); return nullptr; }
     return c;
 }
 extern "C" void x264hip_frame_ctx_delete(x264hip_frame_ctx *c)
@@ -251,22 +265,26 @@ extern "C" void x264hip_frame_ctx_delete(x264hip_frame_ctx *c)
 }
 extern "C" void *x264hip_frame_ctx_stream(x264hip_frame_ctx *c) { return (void *)c->stream; }
 extern "C" int x264hip_sync(x264hip_frame_ctx *c) { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int x264hip_frame_ctx_select(x264hip_frame_ctx *c, int batch_index)
+{
+    if (batch_index < 0 || batch_index >= c->batch) { set_error("batch index %d out of range", batch_index); return -1; }
+    c->sel = batch_index;
+    return 0;
+}
 
 extern "C" int x264hip_picture_alloc(x264hip_frame_ctx *c, x264hip_picture *pic)
 {
     memset(pic, 0, sizeof(*pic));
     const x264hip_frame_dims &d = c->d;
-    if (alloc_plane(&pic->plane[0], d.stride_y, d.lines_y, PADH, PADV, c->stream)) return -1;
+    if (alloc_plane(&pic->plane[0], d.stride_y, d.lines_y, PADH, PADV, c->batch, c->bs_y, c->stream)) return -1;
     for (int i = 1; i < 3; i++)
-        if (alloc_plane(&pic->plane[i], d.stride_c, d.lines_c, PADH / 2, PADV / 2, c->stream)) return -1;
+        if (alloc_plane(&pic->plane[i], d.stride_c, d.lines_c, PADH / 2, PADV / 2, c->batch, c->bs_c, c->stream)) return -1;
     pic->filtered[0] = pic->plane[0];
     for (int i = 1; i < 4; i++)
-        if (alloc_plane(&pic->filtered[i], d.stride_y, d.lines_y, PADH, PADV, c->stream)) return -1;
-    pic->width_lowres = c->width16 / 2;
-    pic->lines_lowres = d.lines_y / 2;
-    pic->stride_lowres = align_up(pic->width_lowres + 2 * PADH, 16);
+        if (alloc_plane(&pic->filtered[i], d.stride_y, d.lines_y, PADH, PADV, c->batch, c->bs_y, c->stream)) return -1;
+    pic->width_lowres = c->width_l; pic->lines_lowres = c->lines_l; pic->stride_lowres = c->stride_l;
     for (int i = 0; i < 4; i++)
-        if (alloc_plane(&pic->lowres[i], pic->stride_lowres, pic->lines_lowres, PADH, PADV, c->stream)) return -1;
+        if (alloc_plane(&pic->lowres[i], c->stride_l, c->lines_l, PADH, PADV, c->batch, c->bs_l, c->stream)) return -1;
     return 0;
 }
 extern "C" void x264hip_picture_free(x264hip_frame_ctx *c, x264hip_picture *pic)
@@ -288,10 +306,11 @@ extern "C" int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic
     const int ss[3] = {sy, su, sv};
     for (int i = 0; i < 3; i++) {
         int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y;
-        HIPCHK(hipMemcpy2DAsync(pic->plane[i], st, src[i], ss[i], w, h, hipMemcpyHostToDevice, c->stream));
+        u8 *dst = pic->plane[i] + (i ? c->bs_c : c->bs_y) * c->sel;
+        HIPCHK(hipMemcpy2DAsync(dst, st, src[i], ss[i], w, h, hipMemcpyHostToDevice, c->stream));
         int w16 = c->width16 >> !!i, h16 = c->lines16 >> !!i;
         if (w16 != w || h16 != h)
-            hipLaunchKernelGGL(k_pad_mod16, dim3((w16 + 255) / 256, h16), dim3(256), 0, c->stream, pic->plane[i], st, w, h, w16, h16);
+            hipLaunchKernelGGL(k_pad_mod16, dim3((w16 + 255) / 256, h16), dim3(256), 0, c->stream, dst, st, w, h, w16, h16);
     }
     HIPCHK(hipGetLastError());
     // the caller owns y/u/v and may release them on return (they are usually
@@ -303,10 +322,10 @@ extern "C" int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic
 static int plane_geometry(const x264hip_frame_ctx *c, const x264hip_picture *pic, int id, u8 **p, int *stride, int *w, int *h, int *padh, int *padv)
 {
     const x264hip_frame_dims &d = c->d;
-    if (id == 0)      { *p = pic->plane[0]; *stride = d.stride_y; *w = c->width16; *h = c->lines16; *padh = PADH; *padv = PADV; }
-    else if (id < 3)  { *p = pic->plane[id]; *stride = d.stride_c; *w = c->width16 / 2; *h = c->lines16 / 2; *padh = PADH / 2; *padv = PADV / 2; }
-    else if (id < 6)  { *p = pic->filtered[id - 2]; *stride = d.stride_y; *w = c->width16; *h = c->lines16; *padh = PADH; *padv = PADV; }
-    else if (id < 10) { *p = pic->lowres[id - 6]; *stride = pic->stride_lowres; *w = pic->width_lowres; *h = pic->lines_lowres; *padh = PADH; *padv = PADV; }
+    if (id == 0)      { *p = pic->plane[0] + c->bs_y * c->sel; *stride = d.stride_y; *w = c->width16; *h = c->lines16; *padh = PADH; *padv = PADV; }
+    else if (id < 3)  { *p = pic->plane[id] + c->bs_c * c->sel; *stride = d.stride_c; *w = c->width16 / 2; *h = c->lines16 / 2; *padh = PADH / 2; *padv = PADV / 2; }
+    else if (id < 6)  { *p = pic->filtered[id - 2] + c->bs_y * c->sel; *stride = d.stride_y; *w = c->width16; *h = c->lines16; *padh = PADH; *padv = PADV; }
+    else if (id < 10) { *p = pic->lowres[id - 6] + c->bs_l * c->sel; *stride = pic->stride_lowres; *w = pic->width_lowres; *h = pic->lines_lowres; *padh = PADH; *padv = PADV; }
     else return -1;
     return 0;
 }
@@ -325,24 +344,24 @@ extern "C" int x264hip_picture_download(x264hip_frame_ctx *c, const x264hip_pict
     return 0;
 }
 
-static void launch_expand(hipStream_t s, u8 *pix, int stride, int width, int height, int padh, int padv)
+static void launch_expand(const x264hip_frame_ctx *c, u8 *pix, size_t bs, int stride, int width, int height, int padh, int padv)
 {
     int nq = (width + 2 * padh + 3) / 4;
-    hipLaunchKernelGGL(k_expand_border, dim3((nq + 255) / 256, height + 2 * padv), dim3(256), 0, s, pix, stride, width, height, padh, padv);
+    hipLaunchKernelGGL(k_expand_border, dim3((nq + 255) / 256, height + 2 * padv, c->batch), dim3(256), 0, c->stream, pix, bs, stride, width, height, padh, padv);
 }
 
 extern "C" int x264hip_expand_border(x264hip_frame_ctx *c, x264hip_picture *pic, int which)
 {
     const x264hip_frame_dims &d = c->d;
     if (which == 0) {           // x264_frame_expand_border, R/common/frame.c:242-270
-        launch_expand(c->stream, pic->plane[0], d.stride_y, c->width16, c->lines16, PADH, PADV);
-        for (int i = 1; i < 3; i++) launch_expand(c->stream, pic->plane[i], d.stride_c, c->width16 / 2, c->lines16 / 2, PADH / 2, PADV / 2);
+        launch_expand(c, pic->plane[0], c->bs_y, d.stride_y, c->width16, c->lines16, PADH, PADV);
+        for (int i = 1; i < 3; i++) launch_expand(c, pic->plane[i], c->bs_c, d.stride_c, c->width16 / 2, c->lines16 / 2, PADH / 2, PADV / 2);
     } else if (which == 1) {    // x264_frame_expand_border_filtered, frame.c:272-296: image = cols [-4,w+4) rows [-8,h+8)
         for (int i = 1; i < 4; i++)
-            launch_expand(c->stream, pic->filtered[i] - 8 * (ptrdiff_t)d.stride_y - 4, d.stride_y, c->width16 + 8, c->lines16 + 16, PADH - 4, PADV - 8);
+            launch_expand(c, pic->filtered[i] - 8 * (ptrdiff_t)d.stride_y - 4, c->bs_y, d.stride_y, c->width16 + 8, c->lines16 + 16, PADH - 4, PADV - 8);
     } else if (which == 2) {    // x264_frame_expand_border_lowres, frame.c:298-301 (width = stride - 2*PADH)
         for (int i = 0; i < 4; i++)
-            launch_expand(c->stream, pic->lowres[i], pic->stride_lowres, pic->stride_lowres - 2 * PADH, pic->lines_lowres, PADH, PADV);
+            launch_expand(c, pic->lowres[i], c->bs_l, pic->stride_lowres, pic->stride_lowres - 2 * PADH, pic->lines_lowres, PADH, PADV);
     } else { set_error("bad border kind %d", which); return -1; }
     HIPCHK(hipGetLastError());
     return 0;
@@ -353,9 +372,9 @@ extern "C" int x264hip_hpel_filter_frame(x264hip_frame_ctx *c, x264hip_picture *
     const x264hip_frame_dims &d = c->d;
     // region kept by the reference after border expansion: x in [-4, w+4), y in [-8, h+8)
     int nx = c->width16 + 8, ny = c->lines16 + 16;
-    dim3 grid((nx + HP_TW - 1) / HP_TW, (ny + HP_TH - 1) / HP_TH);
+    dim3 grid((nx + HP_TW - 1) / HP_TW, (ny + HP_TH - 1) / HP_TH, c->batch);
     hipLaunchKernelGGL(k_hpel, grid, dim3(256), 0, c->stream, pic->plane[0], pic->filtered[1], pic->filtered[2], pic->filtered[3],
-                       d.stride_y, -4, -8, nx, ny);
+                       c->bs_y, d.stride_y, -4, -8, nx, ny);
     HIPCHK(hipGetLastError());
     return x264hip_expand_border(c, pic, 1);
 }
@@ -363,11 +382,11 @@ extern "C" int x264hip_hpel_filter_frame(x264hip_frame_ctx *c, x264hip_picture *
 extern "C" int x264hip_lowres_init_frame(x264hip_frame_ctx *c, x264hip_picture *pic)
 {
     const x264hip_frame_dims &d = c->d;
-    hipLaunchKernelGGL(k_dup_edge, dim3((c->lines16 + 255) / 256), dim3(256), 0, c->stream, pic->plane[0], d.stride_y, c->width16, c->lines16);
-    hipLaunchKernelGGL(k_dup_row, dim3((c->width16 + 255) / 256), dim3(256), 0, c->stream, pic->plane[0], d.stride_y, c->width16, c->lines16);
+    hipLaunchKernelGGL(k_dup_edge, dim3((c->lines16 + 255) / 256, 1, c->batch), dim3(256), 0, c->stream, pic->plane[0], c->bs_y, d.stride_y, c->width16, c->lines16);
+    hipLaunchKernelGGL(k_dup_row, dim3((c->width16 + 255) / 256, 1, c->batch), dim3(256), 0, c->stream, pic->plane[0], c->bs_y, d.stride_y, c->width16, c->lines16);
     int w = pic->width_lowres, h = pic->lines_lowres;
-    hipLaunchKernelGGL(k_lowres, dim3(((w + 3) / 4 + 255) / 256, h), dim3(256), 0, c->stream, pic->plane[0], pic->lowres[0], pic->lowres[1],
-                       pic->lowres[2], pic->lowres[3], d.stride_y, pic->stride_lowres, w, h);
+    hipLaunchKernelGGL(k_lowres, dim3(((w + 3) / 4 + 255) / 256, h, c->batch), dim3(256), 0, c->stream, pic->plane[0], pic->lowres[0], pic->lowres[1],
+                       pic->lowres[2], pic->lowres[3], c->bs_y, c->bs_l, d.stride_y, pic->stride_lowres, w, h);
     HIPCHK(hipGetLastError());
     return x264hip_expand_border(c, pic, 2);
 }
@@ -376,8 +395,8 @@ extern "C" int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture 
 {
     const x264hip_frame_dims &d = c->d;
     int n = d.mb_w * d.mb_h;
-    hipLaunchKernelGGL(k_aq_var, dim3((n + 3) / 4), dim3(256), 0, c->stream, pic->plane[0], pic->plane[1], pic->plane[2],
-                       d.stride_y, d.stride_c, d.mb_w, n, out_dev);
+    hipLaunchKernelGGL(k_aq_var, dim3((n + 3) / 4, 1, c->batch), dim3(256), 0, c->stream, pic->plane[0], pic->plane[1], pic->plane[2],
+                       c->bs_y, c->bs_c, d.stride_y, d.stride_c, d.mb_w, n, out_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -385,20 +404,21 @@ extern "C" int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture 
 extern "C" int x264hip_ssd_frame_async(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, uint64_t *ssd_dev)
 {
     const x264hip_frame_dims &d = c->d;
-    HIPCHK(hipMemsetAsync(ssd_dev, 0, 24, c->stream));
+    HIPCHK(hipMemsetAsync(ssd_dev, 0, 24 * (size_t)c->batch, c->stream));
     for (int i = 0; i < 3; i++) {
         int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y;
-        hipLaunchKernelGGL(k_ssd, dim3(4, h < 256 ? h : 256), dim3(256), 0, c->stream, a->plane[i], st, b->plane[i], st, w, h,
-                           (unsigned long long *)ssd_dev + i);
+        hipLaunchKernelGGL(k_ssd, dim3(4, h < 64 ? h : 64, c->batch), dim3(256), 0, c->stream, a->plane[i], st, b->plane[i], st,
+                           i ? c->bs_c : c->bs_y, w, h, (unsigned long long *)ssd_dev + i);
     }
     HIPCHK(hipGetLastError());
     return 0;
 }
 
+// blocking form for the selected batch element
 extern "C" int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3])
 {
     if (x264hip_ssd_frame_async(c, a, b, (uint64_t *)c->ssd_dev)) return -1;
-    HIPCHK(hipMemcpyAsync(ssd_host, c->ssd_dev, 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ssd_host, c->ssd_dev + 3 * c->sel, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

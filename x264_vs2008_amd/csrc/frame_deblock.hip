@@ -42,6 +42,7 @@ static __constant__ u8 c_chroma_qp[76] = {
 
 struct DbGeom {
     int mb_w, mb_h, sy, sc, a_off, b_off, cqp_off, diag, y_min, count;
+    size_t bs_y, bs_c;  // bytes between batch elements
 };
 
 __device__ __forceinline__ int z_of(int x, int y) { return (y >> 1) * 8 + (x >> 1) * 4 + (y & 1) * 2 + (x & 1); }
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * DB_WAVES + wave;
     if (k >= g.count) return;
+    {   // batch element
+        const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
+        py += g.bs_y * bz; pu += g.bs_c * bz; pv += g.bs_c * bz;
+        mb_type += nmb * bz; qp += nmb * bz; nnz += 26 * nmb * bz; t8x8 += nmb * bz; mv += 32 * nmb * bz; ref += 4 * nmb * bz;
+    }
     DbLds &s = s_all[wave];
     const int mby = g.y_min + k, mbx = g.diag - 2 * mby, mb = mby * g.mb_w + mbx;
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
@@ -222,6 +228,7 @@ extern "C" int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *reco
 {
     DbGeom g;
     g.mb_w = c->d.mb_w; g.mb_h = c->d.mb_h; g.sy = c->d.stride_y; g.sc = c->d.stride_c;
+    g.bs_y = c->bs_y; g.bs_c = c->bs_c;
     g.a_off = p->alpha_c0_offset; g.b_off = p->beta_offset; g.cqp_off = p->chroma_qp_offset;
     if (g.a_off < -12 || g.a_off > 12 || g.b_off < -12 || g.b_off > 12 || g.cqp_off < -12 || g.cqp_off > 12) {
         set_error("deblock: offsets out of range");
@@ -233,7 +240,7 @@ extern "C" int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *reco
         int y_max = t / 2 < g.mb_h - 1 ? t / 2 : g.mb_h - 1;
         if (y_max < y_min) continue;
         g.diag = t; g.y_min = y_min; g.count = y_max - y_min + 1;
-        hipLaunchKernelGGL(k_deblock_diag, dim3((g.count + DB_WAVES - 1) / DB_WAVES), dim3(64 * DB_WAVES), 0, c->stream,
+        hipLaunchKernelGGL(k_deblock_diag, dim3((g.count + DB_WAVES - 1) / DB_WAVES, c->batch), dim3(64 * DB_WAVES), 0, c->stream,
                            recon->plane[0], recon->plane[1], recon->plane[2], g, p->mb_type, p->qp, p->nnz, p->transform8x8,
                            p->mv, (const signed char *)p->ref);
     }

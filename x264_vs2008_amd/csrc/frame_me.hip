@@ -37,6 +37,7 @@ using namespace x264hip;
 
 struct MeGeom {
     int mb_w, mb_h, stride, width16, lines16, range, mv_range, cost_center;
+    size_t bs;          // bytes between batch elements of a luma-sized plane
 };
 
 // mv_min_fpel / mv_max_fpel of R/encoder/analyse.c:258-298 (single slice thread)
@@ -73,6 +74,14 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_fullpel(const u8 *__restri
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mb = blockIdx.x * ME_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;       // whole wave exits together; no block-wide barrier below
+    {   // batch element: shift every per-frame pointer once
+        const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
+        fenc += g.bs * bz; ref += g.bs * bz;
+        if (centers) centers += 2 * nmb * bz;
+        if (mvp_in) mvp_in += 2 * nmb * bz;
+        out_mv += 18 * nmb * bz; out_cost += 9 * nmb * bz;
+        if (surface) surface += (size_t)N * N * nmb * bz;
+    }
     const int mbx = mb % g.mb_w, mby = mb / g.mb_w;
     const int px = mbx * 16, py = mby * 16;
     int cx = 0, cy = 0, pvx = 0, pvy = 0;
@@ -208,6 +217,12 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_subpel(const u8 *__restric
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mb = blockIdx.x * ME_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;
+    {
+        const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
+        fenc += g.bs * bz; p0 += g.bs * bz; p1 += g.bs * bz; p2 += g.bs * bz; p3 += g.bs * bz;
+        if (mvp_in) mvp_in += 2 * nmb * bz;
+        mv_fullpel += 18 * nmb * bz; out_mv += 2 * nmb * bz; out_cost += nmb * bz;
+    }
     const int mbx = mb % g.mb_w, mby = mb / g.mb_w, px = mbx * 16, py = mby * 16;
     int pvx = 0, pvy = 0;
     if (mvp_in) { pvx = mvp_in[2 * mb]; pvy = mvp_in[2 * mb + 1]; }
@@ -287,6 +302,7 @@ static MeGeom make_geom(const x264hip_frame_ctx *c, const x264hip_me_params *p)
     g.width16 = c->width16; g.lines16 = c->lines16;
     g.range = p->range; g.mv_range = p->mv_range > 0 ? p->mv_range : 512;
     g.cost_center = p->cost_mv_range;
+    g.bs = c->bs_y;
     return g;
 }
 
@@ -296,7 +312,7 @@ extern "C" int x264hip_me_fullpel_frame(x264hip_frame_ctx *c, const x264hip_pict
     if (!p->cost_mv || p->cost_mv_range < 4 * (p->range + 8)) { set_error("me: cost_mv table missing or too short"); return -1; }
     MeGeom g = make_geom(c, p);
     int n = g.mb_w * g.mb_h;
-    dim3 grid((n + ME_WAVES - 1) / ME_WAVES), block(64 * ME_WAVES);
+    dim3 grid((n + ME_WAVES - 1) / ME_WAVES, c->batch), block(64 * ME_WAVES);
 #define LAUNCH_ME(RR) hipLaunchKernelGGL(k_me_fullpel<RR>, grid, block, 0, c->stream, fenc->plane[0], ref->plane[0], g, \
         p->cost_mv, p->centers, p->mvp, out_mv_dev, out_cost_dev, p->sad_surface)
     switch (p->range) {
@@ -316,7 +332,7 @@ extern "C" int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_pictu
     if (!p->cost_mv) { set_error("me: cost_mv table missing"); return -1; }
     MeGeom g = make_geom(c, p);
     int n = g.mb_w * g.mb_h;
-    hipLaunchKernelGGL(k_me_subpel, dim3((n + ME_WAVES - 1) / ME_WAVES), dim3(64 * ME_WAVES), 0, c->stream, fenc->plane[0],
+    hipLaunchKernelGGL(k_me_subpel, dim3((n + ME_WAVES - 1) / ME_WAVES, c->batch), dim3(64 * ME_WAVES), 0, c->stream, fenc->plane[0],
                        ref->filtered[0], ref->filtered[1], ref->filtered[2], ref->filtered[3], g, p->cost_mv, p->mvp,
                        mv_fullpel_dev, out_mv_qpel_dev, out_cost_dev);
     HIPCHK(hipGetLastError());

@@ -26,6 +26,7 @@ using namespace x264hip;
 
 struct ResGeom {
     int mb_w, mb_h, sy, sc, qp, qpc, field;
+    size_t bs_y, bs_c;  // bytes between batch elements
 };
 
 struct ResLds {
@@ -74,6 +75,15 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mb = blockIdx.x * RS_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;
+    {   // batch element
+        const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
+        fy += g.bs_y * bz; r0 += g.bs_y * bz; r1 += g.bs_y * bz; r2 += g.bs_y * bz; r3 += g.bs_y * bz; dy += g.bs_y * bz;
+        fu += g.bs_c * bz; fv += g.bs_c * bz; ru += g.bs_c * bz; rv += g.bs_c * bz; du += g.bs_c * bz; dv += g.bs_c * bz;
+        mv += 2 * nmb * bz; levels_y += 256 * nmb * bz; levels_c += 128 * nmb * bz; dc_c += 8 * nmb * bz;
+        cbp_out += nmb * bz; nnz_out += 26 * nmb * bz;
+        if (mv4x4_out) mv4x4_out += 32 * nmb * bz;
+        if (ref_out) ref_out += 4 * nmb * bz;
+    }
     ResLds &s = s_all[wave];
     const int mbx = mb % g.mb_w, mby = mb / g.mb_w;
     const int mvx = mv[2 * mb], mvy = mv[2 * mb + 1];
@@ -347,9 +357,9 @@ extern "C" int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_
                                             int16_t *dc_c_dev, int32_t *cbp_dev, uint8_t *nnz_dev)
 {
     if (p->qp < 0 || p->qp > 51 || p->qp_chroma < 0 || p->qp_chroma > 51) { set_error("residual: qp out of range"); return -1; }
-    ResGeom g = {c->d.mb_w, c->d.mb_h, c->d.stride_y, c->d.stride_c, p->qp, p->qp_chroma, !!p->b_interlaced};
+    ResGeom g = {c->d.mb_w, c->d.mb_h, c->d.stride_y, c->d.stride_c, p->qp, p->qp_chroma, !!p->b_interlaced, c->bs_y, c->bs_c};
     int n = g.mb_w * g.mb_h;
-    dim3 grid((n + RS_WAVES - 1) / RS_WAVES), block(64 * RS_WAVES);
+    dim3 grid((n + RS_WAVES - 1) / RS_WAVES, c->batch), block(64 * RS_WAVES);
 #define ARGS fenc->plane[0], fenc->plane[1], fenc->plane[2], ref->filtered[0], ref->filtered[1], ref->filtered[2], ref->filtered[3], \
         ref->plane[1], ref->plane[2], recon->plane[0], recon->plane[1], recon->plane[2], g, p->quant4_mf, p->quant4_bias, \
         p->quant8_mf, p->quant8_bias, p->dequant4_mf, p->dequant8_mf, mv_qpel_dev, levels_y_dev, levels_c_dev, dc_c_dev, cbp_dev, nnz_dev, \

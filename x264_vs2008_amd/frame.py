@@ -14,7 +14,8 @@ PADH = PADV = 32
 
 class Dims(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("mb_w", C.c_int), ("mb_h", C.c_int),
-                ("stride_y", C.c_int), ("stride_c", C.c_int), ("lines_y", C.c_int), ("lines_c", C.c_int)]
+                ("stride_y", C.c_int), ("stride_c", C.c_int), ("lines_y", C.c_int), ("lines_c", C.c_int),
+                ("batch", C.c_int)]
 
 
 class Picture(C.Structure):
@@ -82,11 +83,12 @@ PLANE_IDS = {"y": 0, "u": 1, "v": 2, "h": 3, "vv": 4, "c": 5, "l0": 6, "lh": 7, 
 class FrameCtx:
     """x264hip_frame_ctx + helpers to move numpy images in and out."""
 
-    def __init__(self, lib, width, height, stream=None):
+    def __init__(self, lib, width, height, stream=None, batch=1):
         self.lib = lib
         lib.x264hip_frame_ctx_new.restype = C.c_void_p
         lib.x264hip_frame_ctx_stream.restype = C.c_void_p
-        self.dims = Dims(width=width, height=height)
+        self.batch = batch
+        self.dims = Dims(width=width, height=height, batch=batch)
         self.h = lib.x264hip_frame_ctx_new(C.byref(self.dims), C.c_void_p(stream))
         if not self.h:
             raise RuntimeError("x264hip_frame_ctx_new failed: %s" % lib.x264hip_last_error().decode())
@@ -107,7 +109,13 @@ class FrameCtx:
         self.pictures.append(pic)
         return pic
 
-    def upload(self, pic, y, u, v):
+    def select(self, b):
+        """Choose the batch element that upload / download / x264hip_ssd_frame address."""
+        self.check(self.lib.x264hip_frame_ctx_select(self.h, b), "frame_ctx_select")
+
+    def upload(self, pic, y, u, v, b=None):
+        if b is not None:
+            self.select(b)
         y, u, v = (np.ascontiguousarray(a) for a in (y, u, v))
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         self.check(self.lib.x264hip_picture_upload(self.h, C.byref(pic), p(y), y.shape[1], p(u), u.shape[1],
@@ -122,7 +130,9 @@ class FrameCtx:
             return d.stride_c, d.mb_w * 8, d.lines_c, PADH // 2, PADV // 2
         return pic.stride_lowres, pic.width_lowres, pic.lines_lowres, PADH, PADV
 
-    def download(self, pic, name, padded=True):
+    def download(self, pic, name, padded=True, b=None):
+        if b is not None:
+            self.select(b)
         stride, w, h, padh, padv = self.geometry(pic, name)
         shape = (h + 2 * padv, stride) if padded else (h, w)
         out = np.zeros(shape, np.uint8)

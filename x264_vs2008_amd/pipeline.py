@@ -5,6 +5,10 @@ R/encoder/analyse.c:2228 motion search per reference, R/encoder/macroblock.c:
 planes + SSD).  Everything is enqueued on the context's stream; nothing here
 synchronises with the host.
 
+A context created with batch = B carries B independent frames (one per GOP
+chain) through every launch, so one call sequence advances B chains by one
+frame each.
+
 The pass decides nothing the reference decides serially (mode decision,
 entropy coding): it produces, for every macroblock at once, the arithmetic
 those decisions consume -- costs and vectors per reference, residual levels,
@@ -26,26 +30,27 @@ class PFramePass:
         self.lib, self.ctx, self.qp, self.t8, self.n_refs = lib, ctx, qp, transform8x8, n_refs
         d = ctx.dims
         n = self.n = d.mb_w * d.mb_h
+        B = self.B = ctx.batch
         self.me_range = me_range
         self.cost_tab = cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)
         self.cost_dev = DeviceArray(lib, self.cost_tab.shape, np.uint16, self.cost_tab)
         self.cqm = CqmDevice(lib, cqm)
-        self.aq = DeviceArray(lib, n, np.int32)
-        self.mv9 = [DeviceArray(lib, (n, 9, 2), np.int16) for _ in range(n_refs)]
-        self.cost9 = [DeviceArray(lib, (n, 9), np.int32) for _ in range(n_refs)]
-        self.mvq = [DeviceArray(lib, (n, 2), np.int16) for _ in range(n_refs)]
-        self.costq = [DeviceArray(lib, n, np.int32) for _ in range(n_refs)]
-        self.levels_y = DeviceArray(lib, (n, 256), np.int16)
-        self.levels_c = DeviceArray(lib, (n, 128), np.int16)
-        self.dc_c = DeviceArray(lib, (n, 8), np.int16)
-        self.cbp = DeviceArray(lib, n, np.int32)
-        self.nnz = DeviceArray(lib, (n, 26), np.uint8)
-        self.mv16 = DeviceArray(lib, (n, 16, 2), np.int16)
-        self.refi = DeviceArray(lib, (n, 4), np.int8)
-        self.mb_type = DeviceArray(lib, n, np.uint8)
-        self.qp_arr = DeviceArray(lib, n, np.uint8, np.full(n, qp, np.uint8))
-        self.t8_arr = DeviceArray(lib, n, np.uint8, np.full(n, transform8x8, np.uint8))
-        self.ssd = DeviceArray(lib, 3, np.uint64)
+        self.aq = DeviceArray(lib, (B, n), np.int32)
+        self.mv9 = [DeviceArray(lib, (B, n, 9, 2), np.int16) for _ in range(n_refs)]
+        self.cost9 = [DeviceArray(lib, (B, n, 9), np.int32) for _ in range(n_refs)]
+        self.mvq = [DeviceArray(lib, (B, n, 2), np.int16) for _ in range(n_refs)]
+        self.costq = [DeviceArray(lib, (B, n), np.int32) for _ in range(n_refs)]
+        self.levels_y = DeviceArray(lib, (B, n, 256), np.int16)
+        self.levels_c = DeviceArray(lib, (B, n, 128), np.int16)
+        self.dc_c = DeviceArray(lib, (B, n, 8), np.int16)
+        self.cbp = DeviceArray(lib, (B, n), np.int32)
+        self.nnz = DeviceArray(lib, (B, n, 26), np.uint8)
+        self.mv16 = DeviceArray(lib, (B, n, 16, 2), np.int16)
+        self.refi = DeviceArray(lib, (B, n, 4), np.int8)
+        self.mb_type = DeviceArray(lib, (B, n), np.uint8)
+        self.qp_arr = DeviceArray(lib, (B, n), np.uint8, np.full((B, n), qp, np.uint8))
+        self.t8_arr = DeviceArray(lib, (B, n), np.uint8, np.full((B, n), transform8x8, np.uint8))
+        self.ssd = DeviceArray(lib, (B, 3), np.uint64)
         self.me_p = MeParams(range=me_range, cost_mv=self.cost_dev.ptr, cost_mv_range=COST_SPAN, centers=None, mvp=None,
                              sad_surface=None, mv_range=512)
         self.res_p = self.cqm.params(qp, transform8x8, 0)
@@ -62,8 +67,8 @@ class PFramePass:
         c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(pic)), "hpel_filter_frame")
 
     def step(self, cur, refs, recon):
-        """Enqueue one P-frame pass: `cur` source picture, `refs` list of reference pictures
-        (nearest first), `recon` picture that receives the reconstruction and becomes a reference."""
+        """Enqueue one P-frame pass for every batch element: `cur` source picture, `refs` list of
+        reference pictures (nearest first), `recon` picture that receives the reconstruction."""
         L, c = self.lib, self.ctx
         h = c.h
         c.check(L.x264hip_lowres_init_frame(h, C.byref(cur)), "lowres_init_frame")
@@ -86,13 +91,14 @@ class PFramePass:
         self.make_reference(recon)
         c.check(L.x264hip_ssd_frame_async(h, C.byref(cur), C.byref(recon), self.ssd.p), "ssd_frame_async")
 
-    def results(self):
-        """Copy the last pass's arrays to the host (synchronises)."""
+    def results(self, b=0):
+        """Copy the last pass's arrays for batch element b to the host (synchronises)."""
         self.ctx.sync()
-        return {"aq": self.aq.get(), "mv9": [a.get() for a in self.mv9], "cost9": [a.get() for a in self.cost9],
-                "mvq": [a.get() for a in self.mvq], "costq": [a.get() for a in self.costq],
-                "levels_y": self.levels_y.get(), "levels_c": self.levels_c.get(), "dc_c": self.dc_c.get(),
-                "cbp": self.cbp.get(), "nnz": self.nnz.get(), "ssd": self.ssd.get().astype(np.int64)}
+        g = lambda a: a.get()[b]
+        return {"aq": g(self.aq), "mv9": [g(a) for a in self.mv9], "cost9": [g(a) for a in self.cost9],
+                "mvq": [g(a) for a in self.mvq], "costq": [g(a) for a in self.costq],
+                "levels_y": g(self.levels_y), "levels_c": g(self.levels_c), "dc_c": g(self.dc_c),
+                "cbp": g(self.cbp), "nnz": g(self.nnz), "ssd": g(self.ssd).astype(np.int64)}
 
 
 def setup_event_api(lib):

@@ -33,6 +33,7 @@ struct ResLds {
     u8  fe[384];          // source: Y 16x16, U 8x8, V 8x8
     u8  pr[384];          // prediction, then reconstruction
     i16 coef[16][16];     // dequantised luma coefficients (4x4 mode: [blk][16]; 8x8 mode: [4][64] flat)
+    i16 t8[256];          // 8x8 mode: intermediate of the forward transform between its two passes
     i16 ccoef[8][16];     // dequantised chroma AC (+ DC once decided)
     int score[16];        // luma decimate scores / nz flags packed: score | nz << 8
     int cscore[8];
@@ -142,38 +143,65 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
             s.score[lane] = (nz ? decimate_scan(lv, 16, c_decimate4) : 0) | ((nz != 0) << 8);
         }
     } else {
-        if (lane < 4) {
-            const u8 *p1 = s.fe + (lane >> 1) * 8 * 16 + (lane & 1) * 8, *p2 = s.pr + (lane >> 1) * 8 * 16 + (lane & 1) * 8;
-            i16 *co = &s.coef[0][0] + 64 * lane;
-            i16 t[64];
+        // 8x8 transform spread over the wavefront: lane = (block b, column / row k) for the two
+        // 1-D passes (32 lanes), then all 64 lanes quantise / scan 4 coefficients each.
+        i16 *tmp = s.t8;                               // [4][64] intermediate, int16 as in the reference (dct.c:266-276)
+        const int b = lane >> 3, k8 = lane & 7;
+        if (lane < 32) {
+            const u8 *p1 = s.fe + (b >> 1) * 8 * 16 + (b & 1) * 8 + k8, *p2 = s.pr + (b >> 1) * 8 * 16 + (b & 1) * 8 + k8;
             int a[8], o[8];
-            for (int c = 0; c < 8; c++) {
-                for (int k = 0; k < 8; k++) a[k] = (int)p1[k * 16 + c] - (int)p2[k * 16 + c];
-                fwd8_1d(o, a);
-                for (int k = 0; k < 8; k++) t[k * 8 + c] = (i16)o[k];
-            }
-            for (int r = 0; r < 8; r++) {
-                for (int k = 0; k < 8; k++) a[k] = t[r * 8 + k];
-                fwd8_1d(o, a);
-                for (int k = 0; k < 8; k++) co[k * 8 + r] = (i16)o[k];
-            }
-            const u16 *mf = q8mf + (1 * 52 + g.qp) * 64, *bs = q8bias + (1 * 52 + g.qp) * 64;
-            int nz = 0;
-            for (int i = 0; i < 64; i++) { int q = quant_one(co[i], mf[i], bs[i]); co[i] = (i16)q; nz |= q; }
-            i16 *lv = ly + 64 * lane;
-            for (int i = 0; i < 64; i++) lv[i] = nz ? co[c_scan8[g.field][i]] : (i16)0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = (int)p1[k * 16] - (int)p2[k * 16];
+            fwd8_1d(o, a);                             // column k8
+#pragma unroll
+            for (int k = 0; k < 8; k++) tmp[64 * b + k * 8 + k8] = (i16)o[k];
+        }
+        WAVE_SYNC();
+        i16 *coef = &s.coef[0][0];
+        if (lane < 32) {
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = tmp[64 * b + k8 * 8 + k];
+            fwd8_1d(o, a);                             // row k8, stored transposed (dct.c:278-283)
+#pragma unroll
+            for (int k = 0; k < 8; k++) coef[64 * b + k * 8 + k8] = (i16)o[k];
+        }
+        WAVE_SYNC();
+        // quantise: lane handles coefficients lane, lane+64, ... i.e. block j, position lane
+        const u16 *mf = q8mf + (1 * 52 + g.qp) * 64, *bs = q8bias + (1 * 52 + g.qp) * 64;
+        const int mfl = mf[lane], bsl = bs[lane];
+        unsigned long long nzmask[4], bigmask[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int q = quant_one(coef[64 * j + lane], mfl, bsl);
+            coef[64 * j + lane] = (i16)q;
+            nzmask[j] = __ballot(q != 0);
+        }
+        WAVE_SYNC();
+        // scan order: level i of block j = coef[scan[i]]; masks of the scanned levels for the score
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int lvv = nzmask[j] ? (int)coef[64 * j + c_scan8[g.field][lane]] : 0;
+            ly[64 * j + lane] = (i16)lvv;
+            nzmask[j] = __ballot(lvv != 0);
+            bigmask[j] = __ballot((unsigned)(lvv + 1) > 2u);
+        }
+        if (lane < 4) {
+            // decimate_score64 from the bit mask of non-zero scanned levels (quant.c:213-239)
+            unsigned long long m = lane == 0 ? nzmask[0] : lane == 1 ? nzmask[1] : lane == 2 ? nzmask[2] : nzmask[3];
+            unsigned long long bg = lane == 0 ? bigmask[0] : lane == 1 ? bigmask[1] : lane == 2 ? bigmask[2] : bigmask[3];
             int sc = 0;
-            if (nz) {   // decimate_score64 on the scanned levels (read back from the coefficient order)
-                int i = 63;
-                while (i >= 0 && co[c_scan8[g.field][i]] == 0) i--;
-                while (i >= 0) {
-                    if ((unsigned)(co[c_scan8[g.field][i--]] + 1) > 2u) { sc = 9; break; }
-                    int run = 0;
-                    while (i >= 0 && co[c_scan8[g.field][i]] == 0) { i--; run++; }
-                    sc += c_decimate8[run];
+            if (bg) sc = 9;
+            else {
+                int idx = m ? 63 - __clzll(m) : -1;
+                while (idx >= 0) {
+                    unsigned long long below = idx ? (m & ((1ull << idx) - 1)) : 0ull;
+                    int prev = below ? 63 - __clzll(below) : -1;
+                    sc += c_decimate8[idx - prev - 1];
+                    idx = prev;
                 }
             }
-            s.score[lane] = sc | ((nz != 0) << 8);
+            s.score[lane] = sc | ((m != 0) << 8);
         }
     }
     WAVE_SYNC();
@@ -224,25 +252,39 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
                 }
         }
     } else {
-        if (lane < 4 && ((s.keep8 >> lane) & 1)) {
-            i16 *d = &s.coef[0][0] + 64 * lane;
-            u8 *dst = s.pr + (lane >> 1) * 8 * 16 + (lane & 1) * 8;
-            const int *dq = dq8 + 1 * 384 + (g.qp % 6) * 64;
-            int bits = g.qp / 6 - 6, a[8], o[8];
-            for (int i = 0; i < 64; i++) d[i] = (i16)dequant_one(d[i], dq[i], bits);
-            d[0] = (i16)(d[0] + 32);
-            for (int c = 0; c < 8; c++) {
-                for (int k = 0; k < 8; k++) a[k] = d[k * 8 + c];
-                inv8_1d(o, a);
-                for (int k = 0; k < 8; k++) d[k * 8 + c] = (i16)o[k];
+        // dequant (64 lanes x 4 coefficients), then the two inverse 1-D passes on 32 lanes;
+        // blocks dropped by decimation skip the arithmetic but every lane reaches the syncs
+        i16 *coef = &s.coef[0][0];
+        const int keep = s.keep8, b = lane >> 3, k8 = lane & 7;
+        const int *dq = dq8 + 1 * 384 + (g.qp % 6) * 64;
+        const int bits = g.qp / 6 - 6, dql = dq[lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((keep >> j) & 1) {
+                int v = dequant_one(coef[64 * j + lane], dql, bits);
+                if (lane == 0) v = (int)(i16)(v + 32);           // rounding term, dct.c:326
+                coef[64 * j + lane] = (i16)v;
             }
-            for (int r = 0; r < 8; r++) {
-                for (int k = 0; k < 8; k++) a[k] = d[r * 8 + k];
-                inv8_1d(o, a);
-                for (int k = 0; k < 8; k++) {
-                    u8 *p = dst + r + k * 16;
-                    *p = (u8)clip_u8((int)*p + (o[k] >> 6));
-                }
+        WAVE_SYNC();
+        if (lane < 32 && ((keep >> b) & 1)) {
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = coef[64 * b + k * 8 + k8];
+            inv8_1d(o, a);                             // column k8, in place, narrowed to int16 (dct.c:328-333)
+#pragma unroll
+            for (int k = 0; k < 8; k++) coef[64 * b + k * 8 + k8] = (i16)o[k];
+        }
+        WAVE_SYNC();
+        if (lane < 32 && ((keep >> b) & 1)) {
+            u8 *dst = s.pr + (b >> 1) * 8 * 16 + (b & 1) * 8;
+            int a[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = coef[64 * b + k8 * 8 + k];
+            inv8_1d(o, a);                             // row k8 -> picture column k8 (dct.c:335-340)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                u8 *p = dst + k8 + k * 16;
+                *p = (u8)clip_u8((int)*p + (o[k] >> 6));
             }
         }
     }

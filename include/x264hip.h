@@ -128,6 +128,12 @@ int x264hip_expand_border(x264hip_frame_ctx *c, x264hip_picture *pic, int which 
 int x264hip_hpel_filter_frame(x264hip_frame_ctx *c, x264hip_picture *pic);
 /* x264_frame_init_lowres (R/common/mc.c:306-357) */
 int x264hip_lowres_init_frame(x264hip_frame_ctx *c, x264hip_picture *pic);
+/* Lookahead intra cost of every macroblock (the intra half of x264_slicetype_mb_cost,
+ * R/encoder/slicetype.c:186-245): on the half-resolution plane produced by
+ * x264hip_lowres_init_frame, each 8x8 block is predicted from its source neighbours with the
+ * four 8x8c predictors and the six directional 8x8 predictors on the filtered edge, scored with
+ * SATD 8x8; out[mb] = min + 5 = frame->i_intra_cost[mb].                                      */
+int x264hip_lookahead_intra_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, int32_t *out_cost_dev);
 /* AQ energy: pixf.var of Y 16x16 and U,V 8x8 per macroblock
  * (x264_adaptive_quant_frame's ac_energy_mb, R/encoder/ratecontrol.c:171-195).
  * out[mb] = var16(Y) + var8(U) + var8(V)                                    */

@@ -56,6 +56,7 @@ int64_t x264_pixel_ssd_wxh(x264hip_pixel_function_t *, u8 *, int, u8 *, int, int
 #define x264o_frame_me_subpel x264r_frame_me_subpel
 #define x264o_frame_inter_residual x264r_frame_inter_residual
 #define x264o_frame_deblock x264r_frame_deblock
+#define x264o_frame_lookahead_intra x264r_frame_lookahead_intra
 #endif
 static void init(void)
 {
@@ -144,6 +145,51 @@ void x264o_frame_aq_var(u8 *py, u8 *pu, u8 *pv, int sy, int sc, int mb_w, int mb
 }
 
 int64_t x264o_frame_ssd(u8 *a, int sa, u8 *b, int sb, int w, int h) { return x264o_pixel_ssd_wxh(a, sa, b, sb, w, h); }
+
+/* ---------------------------------------------------------------- lookahead
+ * intra half of x264_slicetype_mb_cost, R/encoder/slicetype.c:186-245 */
+#ifdef X264O_USE_REF
+void x264_predict_8x8c_init(int, x264hip_predict_t pf[7]);
+void x264_predict_8x8_init(int, x264hip_predict8x8_t pf[12], x264hip_predict_8x8_filter_t *);
+#else
+void x264o_predict_8x8c_init(x264hip_predict_t pf[7]);
+void x264o_predict_8x8_init(x264hip_predict8x8_t pf[12], x264hip_predict_8x8_filter_t *);
+#endif
+void x264o_frame_lookahead_intra(u8 *low, int stride, int mb_w, int mb_h, int32_t *out)
+{
+    init();
+    x264hip_predict_t p8c[7];
+    x264hip_predict8x8_t p8[12];
+    x264hip_predict_8x8_filter_t filt;
+#ifdef X264O_USE_REF
+    x264_predict_8x8c_init(0, p8c); x264_predict_8x8_init(0, p8, &filt);
+#else
+    x264o_predict_8x8c_init(p8c); x264o_predict_8x8_init(p8, &filt);
+#endif
+    for (int my = 0; my < mb_h; my++)
+        for (int mx = 0; mx < mb_w; mx++) {
+            u8 fenc[8 * 16], pix1[9 * 32], edge[33];
+            u8 *src = low + 8 * (mx + my * stride) - 1;
+            u8 *pix = &pix1[8 + 32 - 1];
+            for (int y = 0; y < 8; y++) memcpy(fenc + y * 16, src + 1 + y * stride, 8);
+            memcpy(pix - 32, src - stride, 17);
+            for (int i = 0; i < 8; i++) pix[i * 32] = src[i * stride];
+            pix++;
+            int best = 0x7fffffff;
+            for (int i = 0; i < 4; i++) {
+                p8c[i](pix);
+                int s = pixf.satd[X264HIP_PIXEL_8x8](pix, 32, fenc, 16);
+                if (s < best) best = s;
+            }
+            filt(pix, edge, 0xf, 0xf);
+            for (int i = 3; i < 9; i++) {
+                p8[i](pix, edge);
+                int s = pixf.satd[X264HIP_PIXEL_8x8](pix, 32, fenc, 16);
+                if (s < best) best = s;
+            }
+            out[mx + my * mb_w] = best + 5;
+        }
+}
 
 /* ------------------------------------------------------------------ motion
  * mv_min_fpel / mv_max_fpel and the spel limits, R/encoder/analyse.c:258-298 */

@@ -64,6 +64,19 @@ def test_lowres_planes(ctx, hip_lib, oracle_lib):
         _eq(got, want, "lowres " + name)
     # the source plane gets its last column / row duplicated (mc.c:314-317)
     _eq(ctx.download(pic, "y"), hp.arr("y"), "source after lowres")
+    # lookahead intra cost on the lowres plane (slicetype.c:186-245)
+    from x264_vs2008_amd.frame import DeviceArray
+    d = ctx.dims
+    n = d.mb_w * d.mb_h
+    out = DeviceArray(hip_lib, n, np.int32)
+    assert hip_lib.x264hip_lookahead_intra_frame(ctx.h, C.byref(pic), out.p) == 0
+    ctx.sync()
+    want = np.zeros(n, np.int32)
+    oracle_lib.x264o_frame_lookahead_intra(hp.ptr("l0"), pic.stride_lowres, d.mb_w, d.mb_h, want.ctypes.data_as(C.c_void_p))
+    got = out.get()
+    assert np.array_equal(got, want), "lookahead intra cost differs at %s" % np.argwhere(got != want)[:5]
+    assert got.min() >= 5 and len(np.unique(got)) > 10
+    out.free()
 
 
 def test_aq_var_and_ssd(ctx, hip_lib, oracle_lib):

@@ -39,6 +39,18 @@ __device__ __forceinline__ int group_sum(int v, int g)
     return v;
 }
 
+// ---- XCD-aware block order -----------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Per-macroblock kernels re-read their neighbours' pixels (search
+// windows, filter context), so each XCD gets one contiguous run of logical
+// block ids = one horizontal band of the frame, instead of every 8th group of
+// macroblocks.  A bijection for any grid size; affects speed / HBM traffic only.
+__device__ __forceinline__ int xcd_band_order(int bid, int nb)
+{
+    int q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 // ---- 4 packed bytes at a time ----------------------------------------------
 // sum |a_i - b_i| over the 4 bytes of two dwords: one v_sad_u8.
 __device__ __forceinline__ u32 sad4(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_aq_var(const u8 *__restrict__ py, const
                                                 size_t bs_y, size_t bs_c, int sy, int sc, int mb_w, int mb_count, int *__restrict__ out)
 {
     py += bs_y * blockIdx.z; pu += bs_c * blockIdx.z; pv += bs_c * blockIdx.z; out += (size_t)mb_count * blockIdx.z;
-    int mb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int mb = xcd_band_order(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (mb >= mb_count) return;
     int mx = mb % mb_w, my = mb / mb_w;
     u32 w = *(const u32 *)(py + (ptrdiff_t)(my * 16 + (lane >> 2)) * sy + mx * 16 + (lane & 3) * 4);

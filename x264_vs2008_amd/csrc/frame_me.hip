@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_fullpel(const u8 *__restri
     __shared__ u16 s_cost[ME_WAVES][2][4 * G];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int mb = blockIdx.x * ME_WAVES + wave;
+    const int mb = xcd_band_order(blockIdx.x, gridDim.x) * ME_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;       // whole wave exits together; no block-wide barrier below
     {   // batch element: shift every per-frame pointer once
         const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_subpel(const u8 *__restric
     __shared__ u8 s_ref[ME_WAVES][4][18 * SP_W];
     __shared__ u8 s_fe[ME_WAVES][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int mb = blockIdx.x * ME_WAVES + wave;
+    const int mb = xcd_band_order(blockIdx.x, gridDim.x) * ME_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;
     {
         const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_inter_residual(
 {
     __shared__ ResLds s_all[RS_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int mb = blockIdx.x * RS_WAVES + wave;
+    const int mb = xcd_band_order(blockIdx.x, gridDim.x) * RS_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;
     {   // batch element
         const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;

@@ -207,6 +207,28 @@ int x264hip_inter_residual_frame(x264hip_frame_ctx *c, const x264hip_picture *fe
                                  const int16_t *mv_qpel_dev, int16_t *levels_y_dev, int16_t *levels_c_dev,
                                  int16_t *dc_c_dev, int32_t *cbp_dev, uint8_t *nnz_dev);
 
+/* General P form of the same pipeline: any partition shape and several references.
+ * x264_mb_mc (R/common/macroblock.c:462-546) is mc_luma + mc_chroma per partition with its own
+ * vector and reference, which per pixel depends only on the 4x4 block it lies in, so the
+ * partitioning is given as one vector per 4x4 block (raster order inside the macroblock, the
+ * layout of x264_frame_t.mv) and one reference index per 8x8 (x264_frame_t.ref); refs[] lists
+ * up to 8 reference pictures (list0 order).  mv4x4 : [mb][16][2], ref8x8 : [mb][4] or NULL (= 0).
+ * Must not alias params->mv4x4_out / ref_out.                                                */
+int x264hip_inter_residual_frame_mp(x264hip_frame_ctx *c, const x264hip_picture *fenc,
+                                    const x264hip_picture *const *refs, int n_refs, x264hip_picture *recon,
+                                    const x264hip_residual_params *p, const int16_t *mv4x4_dev, const int8_t *ref8x8_dev,
+                                    int16_t *levels_y_dev, int16_t *levels_c_dev, int16_t *dc_c_dev, int32_t *cbp_dev,
+                                    uint8_t *nnz_dev);
+
+/* x264_macroblock_probe_skip for every macroblock (R/encoder/macroblock.c:797-883, P path):
+ * skip_out[mb] = 1 iff the macroblock predicted with its P-skip vector (clipped to mv_min/mv_max)
+ * quantises to nothing: summed luma decimate scores < 6 and, per chroma plane whose SSD reaches
+ * (lambda2_chroma + 32) >> 6, a zero 2x2 DC and summed AC scores < 7.  lambda2_chroma =
+ * x264_lambda2_tab[qp_chroma] (R/encoder/analyse.c:151-159).  pskip_mv : [mb][2] qpel.       */
+int x264hip_probe_skip_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *ref,
+                             const x264hip_residual_params *p, int lambda2_chroma, const int16_t *pskip_mv_dev,
+                             uint8_t *skip_out_dev);
+
 /* x264_frame_deblock_row for every row of a progressive P frame
  * (R/common/frame.c:621-792): bS from intra flags / nnz / mv+ref differences
  * (no_sub8x8 partitions), alpha/beta/tc0 from the per-MB qp and the slice

@@ -57,6 +57,8 @@ int64_t x264_pixel_ssd_wxh(x264hip_pixel_function_t *, u8 *, int, u8 *, int, int
 #define x264o_frame_inter_residual x264r_frame_inter_residual
 #define x264o_frame_deblock x264r_frame_deblock
 #define x264o_frame_lookahead_intra x264r_frame_lookahead_intra
+#define x264o_frame_inter_residual_mp x264r_frame_inter_residual_mp
+#define x264o_frame_probe_skip x264r_frame_probe_skip
 #endif
 static void init(void)
 {
@@ -297,6 +299,16 @@ void x264o_frame_me_subpel(u8 *fenc, u8 *p0, u8 *p1, u8 *p2, u8 *p3, int mb_w, i
 static const u8 blk_x[16] = {0, 4, 0, 4, 8, 12, 8, 12, 0, 4, 0, 4, 8, 12, 8, 12};
 static const u8 blk_y[16] = {0, 0, 4, 4, 0, 0, 4, 4, 8, 8, 12, 12, 8, 8, 12, 12};
 
+/* general form: any P partition (one vector per 4x4 block, raster order) and several references.
+ * refs[i] = {full, H, V, HV, U, V} planes of reference i; ref8 = per-8x8 index or NULL (all 0);
+ * mv_per_mb = 1 (one 16x16 vector) or 16. */
+void x264o_frame_inter_residual_mp(u8 *fy, u8 *fu, u8 *fv, u8 *const *refs /* [n][6] */, int n_refs,
+                                   u8 *dy, u8 *du, u8 *dv,
+                                   int mb_w, int mb_h, int sy, int sc, int qp, int qpc, int transform8x8, int interlaced,
+                                   const u16 *q4mf, const u16 *q4bias, const u16 *q8mf, const u16 *q8bias,
+                                   const int32_t *dq4, const int32_t *dq8, const i16 *mv, int mv_per_mb, const int8_t *ref8,
+                                   i16 *levels_y, i16 *levels_c, i16 *dc_c, int32_t *cbp_out, u8 *nnz_out);
+
 void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* source planes */
                                 u8 *r0, u8 *r1, u8 *r2, u8 *r3, u8 *ru, u8 *rv,   /* reference: 4 luma planes + chroma */
                                 u8 *dy, u8 *du, u8 *dv,                 /* reconstruction planes */
@@ -305,7 +317,37 @@ void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* sourc
                                 const int32_t *dq4, const int32_t *dq8, const i16 *mv,
                                 i16 *levels_y, i16 *levels_c, i16 *dc_c, int32_t *cbp_out, u8 *nnz_out)
 {
+    u8 *one[6] = {r0, r1, r2, r3, ru, rv};
+    x264o_frame_inter_residual_mp(fy, fu, fv, one, 1, dy, du, dv, mb_w, mb_h, sy, sc, qp, qpc, transform8x8, interlaced,
+                                  q4mf, q4bias, q8mf, q8bias, dq4, dq8, mv, 1, 0, levels_y, levels_c, dc_c, cbp_out, nnz_out);
+}
+
+/* x264_mb_mc for a P macroblock given per-4x4 vectors and per-8x8 reference indices
+ * (R/common/macroblock.c:462-546: every partition is mc_luma + mc_chroma with its own vector) */
+static void mb_mc(u8 *fd_y, u8 *fd_u, u8 *fd_v, u8 *const *refs, int oy, int ocs, int sy, int sc,
+                  const i16 *mv, int mv_per_mb, const int8_t *ref8)
+{
+    for (int by = 0; by < 4; by++)
+        for (int bx = 0; bx < 4; bx++) {
+            const i16 *m = mv_per_mb == 1 ? mv : mv + (bx + 4 * by) * 2;
+            u8 *const *r = refs + 6 * (ref8 ? ref8[(by >> 1) * 2 + (bx >> 1)] : 0);
+            int o = oy + 4 * by * sy + 4 * bx, oc = ocs + 2 * by * sc + 2 * bx;
+            u8 *src4[4] = {r[0] + o, r[1] + o, r[2] + o, r[3] + o};
+            mcf.mc_luma(fd_y + 4 * by * FDEC + 4 * bx, FDEC, src4, sy, m[0], m[1], 4, 4);
+            mcf.mc_chroma(fd_u + 2 * by * FDEC + 2 * bx, FDEC, r[4] + oc, sc, m[0], m[1], 2, 2);
+            mcf.mc_chroma(fd_v + 2 * by * FDEC + 2 * bx, FDEC, r[5] + oc, sc, m[0], m[1], 2, 2);
+        }
+}
+
+void x264o_frame_inter_residual_mp(u8 *fy, u8 *fu, u8 *fv, u8 *const *refs, int n_refs,
+                                   u8 *dy, u8 *du, u8 *dv,
+                                   int mb_w, int mb_h, int sy, int sc, int qp, int qpc, int transform8x8, int interlaced,
+                                   const u16 *q4mf, const u16 *q4bias, const u16 *q8mf, const u16 *q8bias,
+                                   const int32_t *dq4, const int32_t *dq8, const i16 *mv, int mv_per_mb, const int8_t *ref8,
+                                   i16 *levels_y, i16 *levels_c, i16 *dc_c, int32_t *cbp_out, u8 *nnz_out)
+{
     init();
+    (void)n_refs;
     u8 fenc[24 * FENC], fdec[27 * FDEC];
     u8 *fe_y = fenc, *fe_u = fenc + 16 * FENC, *fe_v = fenc + 16 * FENC + 8;
     u8 *fd_y = fdec + 2 * FDEC, *fd_u = fdec + 19 * FDEC, *fd_v = fdec + 19 * FDEC + 16;
@@ -316,18 +358,14 @@ void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* sourc
     int (*dq8y)[8][8] = (int (*)[8][8])(dq8 + 1 * 384);
     x264hip_zigzag_function_t *zz = &zigf[!!interlaced];
     for (int mb = 0; mb < mb_w * mb_h; mb++) {
-        int mbx = mb % mb_w, mby = mb / mb_w, mvx = mv[2 * mb], mvy = mv[2 * mb + 1];
+        int mbx = mb % mb_w, mby = mb / mb_w;
         int oy = 16 * mby * sy + 16 * mbx, ocs = 8 * mby * sc + 8 * mbx;
         i16 *ly = levels_y + mb * 256, *lc = levels_c + mb * 128, *ldc = dc_c + mb * 8;
         u8 *nnz = nnz_out + mb * 26;
         memset(ly, 0, 512); memset(lc, 0, 256); memset(ldc, 0, 16); memset(nnz, 0, 26);
         for (int y = 0; y < 16; y++) memcpy(fe_y + y * FENC, fy + oy + y * sy, 16);
         for (int y = 0; y < 8; y++) { memcpy(fe_u + y * FENC, fu + ocs + y * sc, 8); memcpy(fe_v + y * FENC, fv + ocs + y * sc, 8); }
-        /* x264_mb_mc_0xywh for a 16x16 partition, R/common/macroblock.c:462-487 */
-        u8 *src4[4] = {r0 + oy, r1 + oy, r2 + oy, r3 + oy};
-        mcf.mc_luma(fd_y, FDEC, src4, sy, mvx, mvy, 16, 16);
-        mcf.mc_chroma(fd_u, FDEC, ru + ocs, sc, mvx, mvy, 8, 8);
-        mcf.mc_chroma(fd_v, FDEC, rv + ocs, sc, mvx, mvy, 8, 8);
+        mb_mc(fd_y, fd_u, fd_v, refs, oy, ocs, sy, sc, mv + 2 * mv_per_mb * mb, mv_per_mb, ref8 ? ref8 + 4 * mb : 0);
         int cbp_luma = 0, decimate_mb = 0;
         if (transform8x8) {
             i16 dct8[4][8][8];
@@ -427,6 +465,62 @@ void x264o_frame_inter_residual(u8 *fy, u8 *fu, u8 *fv,                 /* sourc
         (void)blk_x; (void)blk_y;
         for (int y = 0; y < 16; y++) memcpy(dy + oy + y * sy, fd_y + y * FDEC, 16);
         for (int y = 0; y < 8; y++) { memcpy(du + ocs + y * sc, fd_u + y * FDEC, 8); memcpy(dv + ocs + y * sc, fd_v + y * FDEC, 8); }
+    }
+}
+
+/* x264_macroblock_probe_skip (P path), R/encoder/macroblock.c:797-883, for every macroblock */
+void x264o_frame_probe_skip(u8 *fy, u8 *fu, u8 *fv, u8 *r0, u8 *r1, u8 *r2, u8 *r3, u8 *ru, u8 *rv,
+                            int mb_w, int mb_h, int sy, int sc, int qp, int qpc, int lambda2_chroma, int interlaced,
+                            const u16 *q4mf, const u16 *q4bias, const i16 *pskip_mv, u8 *skip_out)
+{
+    init();
+    u8 fenc[24 * FENC], fdec[27 * FDEC];
+    u8 *fe_y = fenc, *fe_c[2] = {fenc + 16 * FENC, fenc + 16 * FENC + 8};
+    u8 *fd_y = fdec + 2 * FDEC, *fd_c[2] = {fdec + 19 * FDEC, fdec + 19 * FDEC + 16};
+    u16 *mf4y = (u16 *)q4mf + (1 * 52 + qp) * 16, *b4y = (u16 *)q4bias + (1 * 52 + qp) * 16;
+    u16 *mf4c = (u16 *)q4mf + (3 * 52 + qpc) * 16, *b4c = (u16 *)q4bias + (3 * 52 + qpc) * 16;
+    x264hip_zigzag_function_t *zz = &zigf[!!interlaced];
+    int thresh = (lambda2_chroma + 32) >> 6;
+    for (int mb = 0; mb < mb_w * mb_h; mb++) {
+        int mbx = mb % mb_w, mby = mb / mb_w;
+        int oy = 16 * mby * sy + 16 * mbx, ocs = 8 * mby * sc + 8 * mbx;
+        int mvx = clip3i(pskip_mv[2 * mb], 4 * (-16 * mbx - 24), 4 * (16 * (mb_w - mbx - 1) + 24));
+        int mvy = clip3i(pskip_mv[2 * mb + 1], 4 * (-16 * mby - 24), 4 * (16 * (mb_h - mby - 1) + 24));
+        u8 *pc[2] = {fu, fv}, *rc[2] = {ru, rv};
+        for (int y = 0; y < 16; y++) memcpy(fe_y + y * FENC, fy + oy + y * sy, 16);
+        for (int ch = 0; ch < 2; ch++)
+            for (int y = 0; y < 8; y++) memcpy(fe_c[ch] + y * FENC, pc[ch] + ocs + y * sc, 8);
+        u8 *src4[4] = {r0 + oy, r1 + oy, r2 + oy, r3 + oy};
+        mcf.mc_luma(fd_y, FDEC, src4, sy, mvx, mvy, 16, 16);
+        int ok = 1, dec = 0;
+        i16 d4[4][4][4], d2[2][2], scan[16];
+        for (int i8 = 0; i8 < 4 && ok; i8++) {
+            dctf.sub8x8_dct(d4, fe_y + (i8 & 1) * 8 + (i8 >> 1) * 8 * FENC, fd_y + (i8 & 1) * 8 + (i8 >> 1) * 8 * FDEC);
+            for (int i4 = 0; i4 < 4; i4++) {
+                if (!quantf.quant_4x4(d4[i4], mf4y, b4y)) continue;
+                zz->scan_4x4(scan, d4[i4]);
+                dec += quantf.decimate_score16(scan);
+                if (dec >= 6) { ok = 0; break; }
+            }
+        }
+        for (int ch = 0; ch < 2 && ok; ch++) {
+            mcf.mc_chroma(fd_c[ch], FDEC, rc[ch] + ocs, sc, mvx, mvy, 8, 8);
+            if (pixf.ssd[X264HIP_PIXEL_8x8](fd_c[ch], FDEC, fe_c[ch], FENC) < thresh) continue;
+            dctf.sub8x8_dct(d4, fe_c[ch], fd_c[ch]);
+            int a = d4[0][0][0] + d4[1][0][0], b = d4[2][0][0] + d4[3][0][0];
+            int c = d4[0][0][0] - d4[1][0][0], d = d4[2][0][0] - d4[3][0][0];
+            d2[0][0] = a + b; d2[1][0] = c + d; d2[0][1] = a - b; d2[1][1] = c - d;
+            d4[0][0][0] = d4[1][0][0] = d4[2][0][0] = d4[3][0][0] = 0;
+            if (quantf.quant_2x2_dc(d2, mf4c[0] >> 1, b4c[0] << 1)) { ok = 0; break; }
+            dec = 0;
+            for (int i4 = 0; i4 < 4; i4++) {
+                if (!quantf.quant_4x4(d4[i4], mf4c, b4c)) continue;
+                zz->scan_4x4(scan, d4[i4]);
+                dec += quantf.decimate_score15(scan);
+                if (dec >= 7) { ok = 0; break; }
+            }
+        }
+        skip_out[mb] = (u8)ok;
     }
 }
 

@@ -85,3 +85,116 @@ def test_inter_residual(hip_lib, oracle_lib, cqm, size, qp, t8, field):
         cq.free()
     finally:
         ctx.close()
+
+
+LAMBDA2_TAB = (14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1161, 1462, 1843, 2322,
+               2925, 3686, 4644, 5851, 7372, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628,
+               117964, 148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436)
+
+
+def _two_refs(hip_lib, oracle_lib, size):
+    """cur = frame 6; references = frames 6 (perfect) and 4, both with borders + half-pel planes."""
+    ctx, cur, ref0, hc, hr0 = _setup(hip_lib, oracle_lib, size[0], size[1], 6, 6)
+    ref1 = ctx.new_picture()
+    hr1 = make_clip_frame(ctx, ref1, 4, oracle_lib)
+    assert hip_lib.x264hip_expand_border(ctx.h, C.byref(ref1), 0) == 0
+    assert hip_lib.x264hip_hpel_filter_frame(ctx.h, C.byref(ref1)) == 0
+    from oracle import hostpic
+    hostpic.make_reference(oracle_lib, "x264o_", hr1)
+    for name in ("u", "v"):
+        _, stride, w, h, padh, padv = hr0.full[name]
+        oracle_lib.x264o_plane_expand_border(hr0.ptr(name), stride, w, h, padh, padv)
+    return ctx, cur, (ref0, ref1), hc, (hr0, hr1)
+
+
+@pytest.mark.parametrize("size,qp,t8", [((352, 288), 24, 0), ((200, 120), 30, 1)])
+def test_inter_residual_partitions_and_multiref(hip_lib, oracle_lib, cqm, size, qp, t8):
+    """One vector per 4x4 block (any P partition) and a reference index per 8x8, two references."""
+    ctx, cur, refs, hc, hrefs = _two_refs(hip_lib, oracle_lib, size)
+    try:
+        d = ctx.dims
+        n = d.mb_w * d.mb_h
+        r = np.random.RandomState(qp)
+        mv16 = np.zeros((n, 16, 2), np.int16)
+        ref8 = r.randint(0, 2, (n, 4)).astype(np.int8)
+        for mb in range(n):
+            shape = r.randint(0, 4)          # 0: 16x16, 1: 16x8, 2: 8x16, 3: 8x8 with 4x4 sub-blocks
+            for by in range(4):
+                for bx in range(4):
+                    key = {0: 0, 1: by >> 1, 2: bx >> 1, 3: bx + 4 * by}[shape]
+                    rs = np.random.RandomState(1000 * mb + key)
+                    mv16[mb, bx + 4 * by] = rs.randint(-9, 10, 2)
+            if shape == 0:
+                ref8[mb] = ref8[mb, 0]
+            elif shape == 1:
+                ref8[mb, 1] = ref8[mb, 0]; ref8[mb, 3] = ref8[mb, 2]
+            elif shape == 2:
+                ref8[mb, 2] = ref8[mb, 0]; ref8[mb, 3] = ref8[mb, 1]
+        mv16[r.rand(n) < 0.3] = 0
+        recon = ctx.new_picture(); hrec = HostPic(ctx, recon)
+        cq = CqmDevice(hip_lib, cqm)
+        p = cq.params(qp, t8, 0)
+        mvo = DeviceArray(hip_lib, (n, 16, 2), np.int16); refo = DeviceArray(hip_lib, (n, 4), np.int8)
+        p.mv4x4_out = mvo.ptr; p.ref_out = refo.ptr
+        mv_dev = DeviceArray(hip_lib, mv16.shape, np.int16, mv16); ref_dev = DeviceArray(hip_lib, ref8.shape, np.int8, ref8)
+        ly = DeviceArray(hip_lib, (n, 256), np.int16); lc = DeviceArray(hip_lib, (n, 128), np.int16)
+        dc = DeviceArray(hip_lib, (n, 8), np.int16); cbp = DeviceArray(hip_lib, n, np.int32); nnz = DeviceArray(hip_lib, (n, 26), np.uint8)
+        from x264_vs2008_amd.frame import Picture
+        arr = (C.POINTER(Picture) * 2)(C.pointer(refs[0]), C.pointer(refs[1]))
+        rc = hip_lib.x264hip_inter_residual_frame_mp(ctx.h, C.byref(cur), arr, 2, C.byref(recon), C.byref(p), mv_dev.p, ref_dev.p,
+                                                     ly.p, lc.p, dc.p, cbp.p, nnz.p)
+        assert rc == 0, hip_lib.x264hip_last_error()
+        ctx.sync()
+        w_ly = np.zeros((n, 256), np.int16); w_lc = np.zeros((n, 128), np.int16); w_dc = np.zeros((n, 8), np.int16)
+        w_cbp = np.zeros(n, np.int32); w_nnz = np.zeros((n, 26), np.uint8)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        tabs = {k: np.ascontiguousarray(v) for k, v in cqm.items()}
+        dq4 = tabs["dequant4_mf"].astype(np.int32); dq8 = tabs["dequant8_mf"].astype(np.int32)
+        u8p = C.POINTER(C.c_uint8)
+        planes = (u8p * 12)(*[hr.ptr(nm) for hr in hrefs for nm in ("y", "h", "vv", "c", "u", "v")])
+        oracle_lib.x264o_frame_inter_residual_mp(
+            hc.ptr("y"), hc.ptr("u"), hc.ptr("v"), planes, 2, hrec.ptr("y"), hrec.ptr("u"), hrec.ptr("v"), d.mb_w, d.mb_h,
+            d.stride_y, d.stride_c, qp, chroma_qp(qp), t8, 0, vp(tabs["quant4_mf"]), vp(tabs["quant4_bias"]), vp(tabs["quant8_mf"]),
+            vp(tabs["quant8_bias"]), vp(dq4), vp(dq8), vp(mv16), 16, vp(ref8), vp(w_ly), vp(w_lc), vp(w_dc), vp(w_cbp), vp(w_nnz))
+        for name in ("y", "u", "v"):
+            got = ctx.download(recon, name, padded=False)
+            assert np.array_equal(got, hrec.visible(name)), "recon %s differs at %s" % (name, np.argwhere(got != hrec.visible(name))[:4])
+        for g_, w_, nm in ((cbp, w_cbp, "cbp"), (nnz, w_nnz, "nnz"), (ly, w_ly, "levels_y"), (lc, w_lc, "levels_c"), (dc, w_dc, "dc")):
+            assert np.array_equal(g_.get(), w_), nm
+        assert np.array_equal(mvo.get(), mv16) and np.array_equal(refo.get(), ref8)
+        cq.free()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("size,qp", [((352, 288), 26), ((200, 120), 18), ((352, 288), 40)])
+def test_probe_skip(hip_lib, oracle_lib, cqm, size, qp):
+    ctx, cur, refs, hc, hrefs = _two_refs(hip_lib, oracle_lib, size)
+    try:
+        d = ctx.dims
+        n = d.mb_w * d.mb_h
+        r = np.random.RandomState(qp)
+        mv = r.randint(-3, 4, (n, 2)).astype(np.int16)
+        mv[r.rand(n) < 0.4] = 0
+        mv[:3] = (-400, 300)                     # far outside mv_min/mv_max: exercises the clip
+        which = 1 if qp == 18 else 0             # against the identical frame most blocks skip; against frame 4 few do
+        cq = CqmDevice(hip_lib, cqm)
+        p = cq.params(qp, 0, 0)
+        mv_dev = DeviceArray(hip_lib, mv.shape, np.int16, mv); out = DeviceArray(hip_lib, n, np.uint8)
+        l2 = LAMBDA2_TAB[chroma_qp(qp)]
+        assert hip_lib.x264hip_probe_skip_frame(ctx.h, C.byref(cur), C.byref(refs[which]), C.byref(p), l2, mv_dev.p, out.p) == 0
+        ctx.sync()
+        want = np.zeros(n, np.uint8)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        tabs = {k: np.ascontiguousarray(v) for k, v in cqm.items()}
+        hr = hrefs[which]
+        oracle_lib.x264o_frame_probe_skip(hc.ptr("y"), hc.ptr("u"), hc.ptr("v"), hr.ptr("y"), hr.ptr("h"), hr.ptr("vv"), hr.ptr("c"),
+                                          hr.ptr("u"), hr.ptr("v"), d.mb_w, d.mb_h, d.stride_y, d.stride_c, qp, chroma_qp(qp), l2, 0,
+                                          vp(tabs["quant4_mf"]), vp(tabs["quant4_bias"]), vp(mv), vp(want))
+        got = out.get()
+        assert np.array_equal(got, want), "skip flags differ at %s" % np.argwhere(got != want)[:6]
+        if which == 0:
+            assert got.any() and not got.all()
+        cq.free()
+    finally:
+        ctx.close()

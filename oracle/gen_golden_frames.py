@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- golden vectors for the per-frame DRIVERS.
+
+Runs the reference's own x264_frame_expand_border_mod16, x264_frame_init_lowres,
+x264_frame_deblock_row, x264_frame_expand_border, x264_frame_filter and
+x264_frame_expand_border_filtered (compiled from R/common/*.c into
+oracle/_ref/libx264ref.so; oracle/ref_shim.c only builds the structs they
+read) on seeded inputs and stores inputs + resulting padded planes under
+tests/golden/.  tests/test_oracle_frame_golden.py then holds the CPU twin
+(oracle/frame_oracle.c) to these outputs, which pins the twins' driver logic
+(band bounds, border rules, bS derivation, alpha/beta/tc0 tables, array
+layouts) to the reference, not just to our reading of it.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import hostpic  # noqa: E402
+from x264_vs2008_amd import synth  # noqa: E402
+
+CASES = [((352, 288), 1, 0, 0, 0, 18, 44), ((200, 120), 2, 3, -2, 2, 8, 51)]
+
+
+class RefFrame(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("stride_y", C.c_int), ("stride_c", C.c_int),
+                ("stride_lowres", C.c_int), ("plane", hostpic.u8p * 3), ("filtered", hostpic.u8p * 4),
+                ("lowres", hostpic.u8p * 4)]
+
+
+def ref_frame(pic):
+    g = pic.g
+    f = RefFrame(g.width, g.height, g.stride_y, g.stride_c, g.stride_lowres)
+    for i, n in enumerate(("y", "u", "v")):
+        f.plane[i] = pic.ptr(n)
+    for i, n in enumerate(("y", "h", "vv", "c")):
+        f.filtered[i] = pic.ptr(n)
+    for i, n in enumerate(("l0", "lh", "lv", "lc")):
+        f.lowres[i] = pic.ptr(n)
+    return f
+
+
+def blocky(img, r, step, amp):
+    h, w = img.shape
+    off = r.randint(-amp, amp + 1, ((h + step - 1) // step, (w + step - 1) // step))
+    big = np.kron(off, np.ones((step, step), np.int64))[:h, :w]
+    return np.clip(img.astype(np.int64) + big, 0, 255).astype(np.uint8)
+
+
+def make_case(size, seed, qlo, qhi):
+    """Seeded inputs: a blocky frame and random per-macroblock side information."""
+    g = hostpic.Geometry(*size)
+    n = g.mb_w * g.mb_h
+    r = np.random.RandomState(seed)
+    y, u, v = synth.frame(size[0], size[1], seed)
+    y, u, v = blocky(blocky(y, r, 4, 3), r, 16, 6), blocky(u, r, 4, 4), blocky(v, r, 4, 4)
+    mb_type = r.choice([0, 0, 0, 1, 2, 3], n).astype(np.uint8)
+    qp = r.randint(qlo, qhi + 1, n).astype(np.uint8)
+    t8 = (r.rand(n) < 0.4).astype(np.uint8)
+    nnz = (r.rand(n, 26) < 0.3).astype(np.uint8)
+    nnz[mb_type == 2] = 0
+    nnz[r.rand(n) < 0.3] = 0
+    for mb in np.nonzero(t8)[0]:
+        for b in range(4):
+            nnz[mb, 4 * b:4 * b + 4] = nnz[mb, 4 * b]
+    mv = np.repeat(r.randint(-6, 7, (n, 1, 2)).astype(np.int16), 16, axis=1)
+    ref = np.repeat(r.randint(0, 2, (n, 1)).astype(np.int8), 4, axis=1)
+    for mb in np.nonzero(mb_type == 3)[0]:
+        m8 = r.randint(-6, 7, (2, 2, 2)); r8 = r.randint(0, 2, 4)
+        for by in range(4):
+            for bx in range(4):
+                mv[mb, bx + 4 * by] = m8[by >> 1, bx >> 1]
+        ref[mb] = r8
+    mv[mb_type == 1] = 0; ref[mb_type == 1] = -1
+    return g, dict(y=y, u=u, v=v, mb_type=mb_type, qp=qp, t8=t8, nnz=nnz, mv=np.ascontiguousarray(mv), ref=np.ascontiguousarray(ref))
+
+
+def main():
+    lib = C.CDLL(os.path.join(HERE, "_ref", "libx264ref.so"))
+    vp = hostpic.vp
+    for size, seed, a_off, b_off, c_off, qlo, qhi in CASES:
+        g, inp = make_case(size, seed, qlo, qhi)
+        out = {}
+        # source side: mod-16 edge replication + lowres planes
+        src = hostpic.HostPic(g)
+        for nm in ("y", "u", "v"):
+            src.set_visible(nm, inp[nm])
+        f = ref_frame(src)
+        lib.refshim_source_prepare(C.byref(f), 1)
+        for nm in ("y", "u", "v", "l0", "lh", "lv", "lc"):
+            out["src." + nm] = src.arr(nm).copy()
+        # reconstruction side: deblock + border + half-pel planes, row by row as the reference does
+        rec = hostpic.HostPic(g)
+        for nm in ("y", "u", "v"):
+            rec.set_visible(nm, inp[nm])
+        f = ref_frame(rec)
+        lib.refshim_source_prepare(C.byref(f), 0)          # coded area beyond the visible picture
+        lib.refshim_fdec_filter(C.byref(f), 1, vp(inp["mb_type"]), vp(inp["qp"]), vp(inp["nnz"]), vp(inp["t8"]), vp(inp["mv"]),
+                                vp(inp["ref"]), a_off, b_off, c_off, 1)
+        for nm in ("y", "u", "v", "h", "vv", "c"):
+            out["rec." + nm] = rec.arr(nm).copy()
+        changed = int((rec.visible("y")[:size[1], :size[0]] != inp["y"]).sum())
+        name = "frame_drivers_%dx%d.npz" % size
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name), offsets=np.array([a_off, b_off, c_off]),
+                            **{"in." + k: v for k, v in inp.items()}, **{"out." + k: v for k, v in out.items()})
+        print("wrote", name, "deblock changed", changed, "luma pixels")
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,7 @@ def cpu_baseline(args, cqm):
     from oracle import hostpic
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libframe_ref.so")
     if os.path.exists(ref_so):
-        lib, prefix, kind = C.CDLL(ref_so), "x264r_", "reference"
+        lib, prefix, kind = hostpic.load_lazy(ref_so), "x264r_", "reference"
     else:
         lib, prefix, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "x264o_", "port"
     g = hostpic.Geometry(args.width, args.height)

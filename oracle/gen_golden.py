@@ -27,7 +27,8 @@ SEEDS = (1234, 20090216)
 
 
 def load_ref():
-    lib = C.CDLL(os.path.join(HERE, "_ref", "libx264ref.so"))
+    from oracle import hostpic
+    lib = hostpic.load_lazy(os.path.join(HERE, "_ref", "libx264ref.so"))
     for n in ("refshim_quant4_mf", "refshim_quant4_bias", "refshim_quant8_mf", "refshim_quant8_bias"):
         getattr(lib, n).restype = C.POINTER(C.c_uint16)
     for n in ("refshim_dequant4_mf", "refshim_dequant8_mf"):

@@ -80,9 +80,90 @@ def make_case(size, seed, qlo, qhi):
     return g, dict(y=y, u=u, v=v, mb_type=mb_type, qp=qp, t8=t8, nnz=nnz, mv=np.ascontiguousarray(mv), ref=np.ascontiguousarray(ref))
 
 
-def main():
-    lib = C.CDLL(os.path.join(HERE, "_ref", "libx264ref.so"))
+class RefRef(C.Structure):
+    _fields_ = [("y", hostpic.u8p * 4), ("u", hostpic.u8p), ("v", hostpic.u8p)]
+
+
+ENC_CASES = [((352, 288), 24, 0, 0), ((352, 288), 27, 1, 0), ((200, 120), 33, 1, 1), ((200, 120), 14, 0, 0)]
+
+
+def encode_inputs(size, qp):
+    """Seeded vectors (one per 4x4 block, mixed partition shapes) and reference indices for two references."""
+    g = hostpic.Geometry(*size)
+    n = g.mb_w * g.mb_h
+    r = np.random.RandomState(qp)
+    mv16 = np.zeros((n, 16, 2), np.int16)
+    ref8 = r.randint(0, 2, (n, 4)).astype(np.int8)
+    for mb in range(n):
+        shape = r.randint(0, 4)
+        for by in range(4):
+            for bx in range(4):
+                key = {0: 0, 1: by >> 1, 2: bx >> 1, 3: bx + 4 * by}[shape]
+                mv16[mb, bx + 4 * by] = np.random.RandomState(1000 * mb + key).randint(-9, 10, 2)
+        if shape == 0:
+            ref8[mb] = ref8[mb, 0]
+        elif shape == 1:
+            ref8[mb, 1] = ref8[mb, 0]; ref8[mb, 3] = ref8[mb, 2]
+        elif shape == 2:
+            ref8[mb, 2] = ref8[mb, 0]; ref8[mb, 3] = ref8[mb, 1]
+    mv16[r.rand(n) < 0.3] = 0
+    pskip = r.randint(-3, 4, (n, 2)).astype(np.int16)
+    pskip[r.rand(n) < 0.4] = 0
+    pskip[:3] = (-400, 300)
+    return g, mv16, ref8, pskip
+
+
+def encode_cases(lib):
+    """Golden outputs of the reference's x264_macroblock_encode and x264_macroblock_probe_skip.
+    Source = synthetic frame 6; references = frames 6 and 4 with the reference's own borders and
+    half-pel planes.  Frames are regenerated from x264_vs2008_amd/synth.py by the test, so only the
+    side information and the outputs are stored."""
+    from x264_vs2008_amd.frame import chroma_qp
     vp = hostpic.vp
+    lib.refshim_lambda2.restype = C.c_int
+    for size, qp, t8, field in ENC_CASES:
+        g, mv16, ref8, pskip = encode_inputs(size, qp)
+        n = g.mb_w * g.mb_h
+        pics = []
+        for t in (6, 6, 4):
+            hp = hostpic.HostPic(g)
+            y, u, v = synth.frame(size[0], size[1], t)
+            for nm, img in (("y", y), ("u", u), ("v", v)):
+                hp.set_visible(nm, img)
+            f = ref_frame(hp)
+            lib.refshim_source_prepare(C.byref(f), 0)
+            pics.append(hp)
+        cur, refs = pics[0], pics[1:]
+        for hp in refs:
+            f = ref_frame(hp)
+            lib.refshim_fdec_filter(C.byref(f), 0, None, None, None, None, None, None, 0, 0, 0, 1)
+        rr = (RefRef * 2)()
+        for i, hp in enumerate(refs):
+            for k, nm in enumerate(("y", "h", "vv", "c")):
+                rr[i].y[k] = hp.ptr(nm)
+            rr[i].u = hp.ptr("u"); rr[i].v = hp.ptr("v")
+        rec = hostpic.HostPic(g)
+        ly = np.zeros((n, 256), np.int16); lc = np.zeros((n, 128), np.int16); dc = np.zeros((n, 8), np.int16)
+        cbp = np.zeros(n, np.int32); nnz = np.zeros((n, 26), np.uint8)
+        qpc = chroma_qp(qp)
+        lib.refshim_inter_encode_frame(cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), rr, 2, rec.ptr("y"), rec.ptr("u"), rec.ptr("v"),
+                                       size[0], size[1], g.stride_y, g.stride_c, qp, qpc, t8, field, vp(mv16), vp(ref8),
+                                       vp(ly), vp(lc), vp(dc), vp(cbp), vp(nnz))
+        skip = np.zeros((2, n), np.uint8)
+        for w in range(2):
+            lib.refshim_probe_skip_frame(cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), C.byref(rr[w]), size[0], size[1], g.stride_y,
+                                         g.stride_c, qp, qpc, field, vp(pskip), vp(skip[w]))
+        name = "encode_%dx%d_qp%d_t%d_f%d.npz" % (size[0], size[1], qp, t8, field)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name), mv16=mv16, ref8=ref8, pskip=pskip,
+                            lambda2=np.array([lib.refshim_lambda2(qpc)]), levels_y=ly, levels_c=lc, dc_c=dc, cbp=cbp, nnz=nnz,
+                            skip=skip, rec_y=rec.visible("y").copy(), rec_u=rec.visible("u").copy(), rec_v=rec.visible("v").copy())
+        print("wrote", name, "coded MBs", int((cbp != 0).sum()), "of", n, "skippable", skip.sum(axis=1))
+
+
+def main():
+    lib = hostpic.load_lazy(os.path.join(HERE, "_ref", "libx264ref.so"))
+    vp = hostpic.vp
+    encode_cases(lib)
     for size, seed, a_off, b_off, c_off, qlo, qhi in CASES:
         g, inp = make_case(size, seed, qlo, qhi)
         out = {}

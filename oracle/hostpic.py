@@ -15,6 +15,20 @@ def align_up(v, a):
     return (v + a - 1) // a * a
 
 
+def load_lazy(path):
+    """ctypes.CDLL with RTLD_LAZY (ctypes itself always binds eagerly): the reference build leaves one
+    never-called function undefined (oracle/Makefile)."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    ora = C.CDLL(os.path.join(here, "liboracle.so"))
+    ora.x264o_dlopen_lazy.restype = C.c_void_p
+    ora.x264o_dlerror.restype = C.c_char_p
+    h = ora.x264o_dlopen_lazy(path.encode())
+    if not h:
+        raise OSError("dlopen(%s): %s" % (path, ora.x264o_dlerror().decode()))
+    return C.CDLL(path, handle=h)
+
+
 class Geometry:
     """Same numbers x264hip_frame_ctx_new computes (x264_frame_new, R/common/frame.c:29-152)."""
 

@@ -166,3 +166,133 @@ void refshim_fdec_filter(const refshim_frame *f, int do_deblock, const uint8_t *
     }
     rm_h(h, &fr);
 }
+
+/* ---------------------------------------------------------------------------
+ * The reference's own x264_macroblock_encode / x264_macroblock_probe_skip
+ * (R/encoder/macroblock.c:475-883) run macroblock by macroblock over a frame.
+ * Each macroblock is presented as P_8x8 with four D_L0_4x4 sub-partitions, so
+ * x264_mb_mc motion-compensates every 4x4 block with its own vector and the
+ * reference index of its 8x8 (R/common/macroblock.c:489-546): the general P
+ * case.  The shim fills the fields of x264_t those functions read (what
+ * x264_macroblock_cache_load would have filled) and copies the results out.   */
+#define SENTINEL 0x7f7f
+typedef struct {
+    uint8_t *y[4], *u, *v;         /* full, H, V, HV planes + chroma of one reference (pixel 0,0) */
+} refshim_ref;
+
+static x264_t *enc_h(int width, int height, int stride_y, int stride_c, int qp, int qpc, int t8, int interlaced)
+{
+    x264_t *h;
+    refshim_cqm_flat_init();
+    h = g_h;
+    h->sps = &h->sps_array[0];
+    h->param.i_width = width; h->param.i_height = height;
+    h->sps->i_mb_width = (width + 15) / 16; h->sps->i_mb_height = (height + 15) / 16;
+    h->mb.i_mb_stride = h->sps->i_mb_width;
+    h->mb.i_mb_count = h->sps->i_mb_width * h->sps->i_mb_height;
+    x264_pixel_init(0, &h->pixf); x264_dct_init(0, &h->dctf); x264_zigzag_init(0, &h->zigzagf, interlaced);
+    x264_quant_init(h, 0, &h->quantf); x264_mc_init(0, &h->mc);
+    x264_predict_16x16_init(0, h->predict_16x16); x264_predict_8x8c_init(0, h->predict_8x8c);
+    x264_predict_8x8_init(0, h->predict_8x8, &h->predict_8x8_filter); x264_predict_4x4_init(0, h->predict_4x4);
+    h->param.analyse.b_dct_decimate = 1;
+    h->param.b_cabac = 1;
+    h->sh.i_type = SLICE_TYPE_P;
+    h->mb.b_trellis = 0; h->mb.b_noise_reduction = 0; h->mb.b_lossless = 0; h->mb.b_interlaced = 0;
+    h->mb.i_qp = qp; h->mb.i_chroma_qp = qpc; h->mb.b_transform_8x8 = t8;
+    h->mb.pic.i_stride[0] = stride_y; h->mb.pic.i_stride[1] = h->mb.pic.i_stride[2] = stride_c;
+    h->mb.pic.p_fenc[0] = h->mb.pic.fenc_buf;
+    h->mb.pic.p_fenc[1] = h->mb.pic.fenc_buf + 16 * FENC_STRIDE;
+    h->mb.pic.p_fenc[2] = h->mb.pic.fenc_buf + 16 * FENC_STRIDE + 8;
+    h->mb.pic.p_fdec[0] = h->mb.pic.fdec_buf + 2 * FDEC_STRIDE;
+    h->mb.pic.p_fdec[1] = h->mb.pic.fdec_buf + 19 * FDEC_STRIDE;
+    h->mb.pic.p_fdec[2] = h->mb.pic.fdec_buf + 19 * FDEC_STRIDE + 16;
+    if (!h->mb.cbp) h->mb.cbp = calloc(1 << 20, sizeof(int16_t));
+    return h;
+}
+static void enc_load_mb(x264_t *h, int mb, uint8_t *fy, uint8_t *fu, uint8_t *fv, const refshim_ref *refs, int n_refs)
+{
+    int mbx = mb % h->sps->i_mb_width, mby = mb / h->sps->i_mb_width, y, r, k;
+    int sy = h->mb.pic.i_stride[0], sc = h->mb.pic.i_stride[1];
+    int oy = 16 * mby * sy + 16 * mbx, oc = 8 * mby * sc + 8 * mbx;
+    h->mb.i_mb_x = mbx; h->mb.i_mb_y = mby; h->mb.i_mb_xy = mb;
+    h->mb.mv_min[0] = 4 * (-16 * mbx - 24); h->mb.mv_max[0] = 4 * (16 * (h->sps->i_mb_width - mbx - 1) + 24);
+    h->mb.mv_min[1] = 4 * (-16 * mby - 24); h->mb.mv_max[1] = 4 * (16 * (h->sps->i_mb_height - mby - 1) + 24);
+    for (y = 0; y < 16; y++) memcpy(h->mb.pic.p_fenc[0] + y * FENC_STRIDE, fy + oy + y * sy, 16);
+    for (y = 0; y < 8; y++) {
+        memcpy(h->mb.pic.p_fenc[1] + y * FENC_STRIDE, fu + oc + y * sc, 8);
+        memcpy(h->mb.pic.p_fenc[2] + y * FENC_STRIDE, fv + oc + y * sc, 8);
+    }
+    for (r = 0; r < n_refs; r++) {
+        for (k = 0; k < 4; k++) h->mb.pic.p_fref[0][r][k] = refs[r].y[k] + oy;
+        h->mb.pic.p_fref[0][r][4] = refs[r].u + oc;
+        h->mb.pic.p_fref[0][r][5] = refs[r].v + oc;
+    }
+}
+
+void refshim_inter_encode_frame(uint8_t *fy, uint8_t *fu, uint8_t *fv, const refshim_ref *refs, int n_refs,
+                                uint8_t *dy, uint8_t *du, uint8_t *dv, int width, int height, int stride_y, int stride_c,
+                                int qp, int qpc, int t8, int interlaced, const int16_t *mv16, const int8_t *ref4,
+                                int16_t *levels_y, int16_t *levels_c, int16_t *dc_c, int32_t *cbp_out, uint8_t *nnz_out)
+{
+    x264_t *h = enc_h(width, height, stride_y, stride_c, qp, qpc, t8, interlaced);
+    int n = h->mb.i_mb_count, mb, i, ch, y;
+    for (mb = 0; mb < n; mb++) {
+        int mbx = mb % h->sps->i_mb_width, mby = mb / h->sps->i_mb_width;
+        int oy = 16 * mby * stride_y + 16 * mbx, oc = 8 * mby * stride_c + 8 * mbx;
+        int16_t *ly = levels_y + mb * 256, *lc = levels_c + mb * 128, *ldc = dc_c + mb * 8, *p;
+        enc_load_mb(h, mb, fy, fu, fv, refs, n_refs);
+        h->mb.i_type = P_8x8; h->mb.i_partition = D_8x8; h->mb.b_skip_mc = 0;
+        h->mb.b_transform_8x8 = t8;
+        for (i = 0; i < 4; i++) h->mb.i_sub_partition[i] = D_L0_4x4;
+        for (i = 0; i < 16; i++) {
+            int x = i & 3, yy = i >> 2, c8 = x264_scan8[0] + x + 8 * yy;
+            h->mb.cache.mv[0][c8][0] = mv16[(mb * 16 + i) * 2]; h->mb.cache.mv[0][c8][1] = mv16[(mb * 16 + i) * 2 + 1];
+            h->mb.cache.ref[0][c8] = ref4 ? ref4[mb * 4 + (yy >> 1) * 2 + (x >> 1)] : 0;
+        }
+        for (p = &h->dct.luma4x4[0][0], i = 0; i < 24 * 16; i++) p[i] = SENTINEL;
+        for (p = &h->dct.luma8x8[0][0], i = 0; i < 4 * 64; i++) p[i] = SENTINEL;
+        for (p = &h->dct.chroma_dc[0][0], i = 0; i < 8; i++) p[i] = SENTINEL;
+        x264_macroblock_encode(h);
+        /* scanned levels; blocks the encoder never wrote (they quantised to nothing) read as zero */
+        if (t8)
+            for (i = 0; i < 4; i++) {
+                int w = h->dct.luma8x8[i][0] != SENTINEL || h->dct.luma8x8[i][63] != SENTINEL;
+                for (y = 0; y < 64; y++) ly[64 * i + y] = w ? h->dct.luma8x8[i][y] : 0;
+            }
+        else
+            for (i = 0; i < 16; i++) {
+                int w = h->dct.luma4x4[i][0] != SENTINEL || h->dct.luma4x4[i][15] != SENTINEL;
+                for (y = 0; y < 16; y++) ly[16 * i + y] = w ? h->dct.luma4x4[i][y] : 0;
+            }
+        for (i = 0; i < 8; i++) {
+            int w = h->dct.luma4x4[16 + i][0] != SENTINEL || h->dct.luma4x4[16 + i][15] != SENTINEL;
+            for (y = 0; y < 16; y++) lc[16 * i + y] = w ? h->dct.luma4x4[16 + i][y] : 0;
+        }
+        for (ch = 0; ch < 2; ch++)
+            for (i = 0; i < 4; i++) ldc[4 * ch + i] = h->dct.chroma_dc[ch][i] == SENTINEL ? 0 : h->dct.chroma_dc[ch][i];
+        for (i = 0; i < 24; i++) nnz_out[mb * 26 + i] = h->mb.cache.non_zero_count[x264_scan8[i]];
+        nnz_out[mb * 26 + 24] = h->mb.cache.non_zero_count[x264_scan8[25]];
+        nnz_out[mb * 26 + 25] = h->mb.cache.non_zero_count[x264_scan8[26]];
+        cbp_out[mb] = h->mb.i_cbp_luma | (h->mb.i_cbp_chroma << 4);
+        for (y = 0; y < 16; y++) memcpy(dy + oy + y * stride_y, h->mb.pic.p_fdec[0] + y * FDEC_STRIDE, 16);
+        for (y = 0; y < 8; y++) {
+            memcpy(du + oc + y * stride_c, h->mb.pic.p_fdec[1] + y * FDEC_STRIDE, 8);
+            memcpy(dv + oc + y * stride_c, h->mb.pic.p_fdec[2] + y * FDEC_STRIDE, 8);
+        }
+    }
+}
+
+void refshim_probe_skip_frame(uint8_t *fy, uint8_t *fu, uint8_t *fv, const refshim_ref *ref, int width, int height,
+                              int stride_y, int stride_c, int qp, int qpc, int interlaced, const int16_t *pskip_mv,
+                              uint8_t *skip_out)
+{
+    x264_t *h = enc_h(width, height, stride_y, stride_c, qp, qpc, 0, interlaced);
+    int n = h->mb.i_mb_count, mb;
+    for (mb = 0; mb < n; mb++) {
+        enc_load_mb(h, mb, fy, fu, fv, ref, 1);
+        h->mb.cache.pskip_mv[0] = pskip_mv[2 * mb]; h->mb.cache.pskip_mv[1] = pskip_mv[2 * mb + 1];
+        skip_out[mb] = (uint8_t)x264_macroblock_probe_skip(h, 0);
+    }
+}
+extern const int x264_lambda2_tab[52];   /* R/encoder/analyse.c:151-159 */
+int refshim_lambda2(int qp) { return x264_lambda2_tab[qp]; }

@@ -1206,6 +1206,13 @@ void x264o_deblock_init(x264hip_deblock_function_t *f)
     f->deblock_v_chroma_intra = o_db_v_chroma_i; f->deblock_h_chroma_intra = o_db_h_chroma_i;
 }
 
+/* dlopen with lazy binding, for the Python harness: oracle/_ref/libx264ref.so
+ * leaves one function (x264_encoder_reconfig, only reachable from rate-control
+ * zones) undefined, and ctypes always asks for RTLD_NOW. */
+#include <dlfcn.h>
+void *x264o_dlopen_lazy(const char *path) { return dlopen(path, RTLD_LAZY | RTLD_GLOBAL); }
+const char *x264o_dlerror(void) { return dlerror(); }
+
 /* size tables exported for the harness */
 int x264o_block_w(int i) { return blk_w[i]; }
 int x264o_block_h(int i) { return blk_h[i]; }

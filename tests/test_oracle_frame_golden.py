@@ -13,6 +13,55 @@ from conftest import GOLDEN
 from oracle import hostpic
 
 SIZES = [(352, 288), (200, 120)]
+ENC_CASES = [((352, 288), 24, 0, 0), ((352, 288), 27, 1, 0), ((200, 120), 33, 1, 1), ((200, 120), 14, 0, 0)]
+
+
+@pytest.mark.parametrize("size,qp,t8,field", ENC_CASES)
+def test_residual_and_probe_skip_twins_match_reference_encode(oracle_lib, cqm, size, qp, t8, field):
+    """Twin vs the reference's own x264_macroblock_encode (general P partitions, two references)
+    and x264_macroblock_probe_skip, run by oracle/ref_shim.c (oracle/gen_golden_frames.py)."""
+    from x264_vs2008_amd import synth
+    from x264_vs2008_amd.frame import chroma_qp
+    with np.load(os.path.join(GOLDEN, "encode_%dx%d_qp%d_t%d_f%d.npz" % (size[0], size[1], qp, t8, field))) as z:
+        gold = {k: z[k] for k in z.files}
+    g = hostpic.Geometry(*size)
+    n = g.mb_w * g.mb_h
+    vp = hostpic.vp
+    pics = []
+    for t in (6, 6, 4):
+        hp = hostpic.HostPic(g)
+        hp.load_yuv(oracle_lib, "x264o_", *synth.frame(size[0], size[1], t))
+        pics.append(hp)
+    cur, refs = pics[0], pics[1:]
+    for hp in refs:
+        hostpic.make_reference(oracle_lib, "x264o_", hp)
+    planes = (hostpic.u8p * 12)(*[hp.ptr(nm) for hp in refs for nm in ("y", "h", "vv", "c", "u", "v")])
+    rec = hostpic.HostPic(g)
+    ly = np.zeros((n, 256), np.int16); lc = np.zeros((n, 128), np.int16); dc = np.zeros((n, 8), np.int16)
+    cbp = np.zeros(n, np.int32); nnz = np.zeros((n, 26), np.uint8)
+    tabs = {k: np.ascontiguousarray(v) for k, v in cqm.items()}
+    dq4 = tabs["dequant4_mf"].astype(np.int32); dq8 = tabs["dequant8_mf"].astype(np.int32)
+    mv16 = np.ascontiguousarray(gold["mv16"]); ref8 = np.ascontiguousarray(gold["ref8"])
+    oracle_lib.x264o_frame_inter_residual_mp(
+        cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), planes, 2, rec.ptr("y"), rec.ptr("u"), rec.ptr("v"), g.mb_w, g.mb_h,
+        g.stride_y, g.stride_c, qp, chroma_qp(qp), t8, field, vp(tabs["quant4_mf"]), vp(tabs["quant4_bias"]), vp(tabs["quant8_mf"]),
+        vp(tabs["quant8_bias"]), vp(dq4), vp(dq8), vp(mv16), 16, vp(ref8), vp(ly), vp(lc), vp(dc), vp(cbp), vp(nnz))
+    for nm in ("y", "u", "v"):
+        assert np.array_equal(rec.visible(nm), gold["rec_" + nm]), "reconstruction " + nm
+    assert np.array_equal(cbp, gold["cbp"]), "cbp"
+    assert np.array_equal(nnz, gold["nnz"]), "nnz"
+    assert np.array_equal(dc, gold["dc_c"]), "chroma dc"
+    assert np.array_equal(lc, gold["levels_c"]), "chroma levels"
+    assert np.array_equal(ly, gold["levels_y"]), "luma levels"
+    assert (cbp != 0).any()
+    pskip = np.ascontiguousarray(gold["pskip"])
+    for w, hp in enumerate(refs):
+        out = np.zeros(n, np.uint8)
+        oracle_lib.x264o_frame_probe_skip(cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), hp.ptr("y"), hp.ptr("h"), hp.ptr("vv"),
+                                          hp.ptr("c"), hp.ptr("u"), hp.ptr("v"), g.mb_w, g.mb_h, g.stride_y, g.stride_c, qp,
+                                          chroma_qp(qp), int(gold["lambda2"][0]), field, vp(tabs["quant4_mf"]),
+                                          vp(tabs["quant4_bias"]), vp(pskip), vp(out))
+        assert np.array_equal(out, gold["skip"][w]), "probe_skip vs reference %d" % w
 
 
 @pytest.mark.parametrize("size", SIZES, ids=lambda s: "%dx%d" % s)

@@ -59,6 +59,7 @@ int64_t x264_pixel_ssd_wxh(x264hip_pixel_function_t *, u8 *, int, u8 *, int, int
 #define x264o_frame_lookahead_intra x264r_frame_lookahead_intra
 #define x264o_frame_inter_residual_mp x264r_frame_inter_residual_mp
 #define x264o_frame_probe_skip x264r_frame_probe_skip
+#define x264o_frame_me_search16 x264r_frame_me_search16
 #endif
 static void init(void)
 {
@@ -284,6 +285,204 @@ void x264o_frame_me_subpel(u8 *fenc, u8 *p0, u8 *p1, u8 *p2, u8 *p3, int mb_w, i
             bmx = wx; bmy = wy; bcost = best;
         }
         out_mv[2 * mb] = bmx; out_mv[2 * mb + 1] = bmy; out_cost[mb] = bcost;
+    }
+}
+
+/* ------------------------------------------------------- x264_me_search_ref
+ * The reference's own search for a 16x16 block (R/encoder/me.c:156-778) run for every
+ * macroblock and every reference with caller-supplied predictors, in the loop of
+ * x264_mb_analyse_inter_p16x16 (R/encoder/analyse.c:1077-1127): predictor tests, DIA or
+ * HEX walk + square refine, sub-pel refinement (refine_subpel, subpel_iterations[subme][2..3]),
+ * chroma ME, the half-pel early-termination threshold carried from reference to reference, and
+ * the choice of the best reference (cost + ref cost, first minimum).
+ * method: 0 = DIA, 1 = HEX (X264_ME_DIA / X264_ME_HEX).  cost_mv: int16 table, cost of qpel
+ * delta d at cost_mv[cost_center + d].  mvp: [mb][n_refs][2]; mvc: [mb][n_refs][8][2] with
+ * n_mvc: [mb][n_refs]; ref_cost: [n_refs].
+ * out_mv: [mb][n_refs][2] qpel, out_cost: [mb][n_refs] (ref cost included), best: [mb][4] =
+ * {ref, mvx, mvy, cost}. */
+typedef struct {
+    u8 *fenc, *fenc_u, *fenc_v;       /* source block pointers (plane stride) */
+    u8 *fref[6];                      /* 4 luma planes + U + V at the block position */
+    int sy, sc;
+    const i16 *cmx, *cmy;             /* cost tables already offset by the predictor */
+    int fmin[2], fmax[2], smin[2], smax[2];
+} me_ctx;
+static const int me_subpel_iters[10][4] = {{0,0,0,0},{1,1,0,0},{0,1,1,0},{0,2,1,0},{0,2,1,1},{0,2,1,2},{0,0,2,2},{0,0,2,2},{0,0,4,10},{0,0,4,10}};
+static const int me_hex2[8][2] = {{-1,-2},{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2},{-2,0}};
+static const int me_mod6m1[8] = {5,0,1,2,3,4,5,0};
+#define ME_COST_MAX (1 << 28)
+
+static int me_fpel_cost(const me_ctx *c, int mx, int my)
+{   /* COST_MV's cost, me.c:54-62 */
+    return pixf.sad[X264HIP_PIXEL_16x16](c->fenc, c->sy, c->fref[0] + my * c->sy + mx, c->sy) + c->cmx[mx << 2] + c->cmy[my << 2];
+}
+static int me_qpel_cmp(const me_ctx *c, int mx, int my, int satd)
+{   /* get_ref + fpelcmp / mbcmp_unaligned, me.c:64-71,644-652 */
+    u8 pix[16 * 16];
+    int stride = 16;
+    u8 *src = mcf.get_ref(pix, &stride, (u8 **)c->fref, c->sy, mx, my, 16, 16);
+    return (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_16x16](c->fenc, c->sy, src, stride) + c->cmx[mx] + c->cmy[my];
+}
+static int me_satd_chroma(const me_ctx *c, int mx, int my, int bcost, int chroma_me, int satd)
+{   /* COST_MV_SATD's cost with the chroma terms, me.c:654-677 */
+    int cost = me_qpel_cmp(c, mx, my, satd);
+    if (chroma_me && cost < bcost) {
+        u8 pix[8 * 8];
+        mcf.mc_chroma(pix, 8, c->fref[4], c->sc, mx, my, 8, 8);
+        cost += (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](c->fenc_u, c->sc, pix, 8);
+        if (cost < bcost) {
+            mcf.mc_chroma(pix, 8, c->fref[5], c->sc, mx, my, 8, 8);
+            cost += (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](c->fenc_v, c->sc, pix, 8);
+        }
+    }
+    return cost;
+}
+
+/* returns cost; *pmvx,*pmvy the vector; *thresh the half-pel threshold (NULL = none) */
+static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], int n_mvc, int method, int me_range, int subme,
+                       int chroma_me, int *thresh, int *pmvx, int *pmvy)
+{
+    const int satd = subme > 1;       /* mbcmp = SATD above subme 1; fpelcmp stays SAD (encoder.c:608-618) */
+    int bmx = clip3i(mvp[0], c->fmin[0] * 4, c->fmax[0] * 4), bmy = clip3i(mvp[1], c->fmin[1] * 4, c->fmax[1] * 4);
+    int pmx = (bmx + 2) >> 2, pmy = (bmy + 2) >> 2;
+    int bcost = ME_COST_MAX, bpx = 0, bpy = 0, bpcost = ME_COST_MAX, cost, i;
+#define TRY(mx, my) do { cost = me_fpel_cost(c, mx, my); if (cost < bcost) { bcost = cost; bmx = mx; bmy = my; } } while (0)
+#define INRANGE(x, y) ((x) >= c->fmin[0] && (x) <= c->fmax[0] && (y) >= c->fmin[1] && (y) <= c->fmax[1])
+    if (subme >= 3) {
+        int px = bmx, py = bmy;
+        cost = me_qpel_cmp(c, px, py, 0);
+        if (cost < bpcost) { bpcost = cost; bpx = px; bpy = py; }
+        for (i = 0; i < n_mvc; i++)
+            if ((mvc[i][0] | mvc[i][1]) && (mvc[i][0] != (i16)px || mvc[i][1] != (i16)py)) {
+                int mx = clip3i(mvc[i][0], c->fmin[0] * 4, c->fmax[0] * 4), my = clip3i(mvc[i][1], c->fmin[1] * 4, c->fmax[1] * 4);
+                cost = me_qpel_cmp(c, mx, my, 0);
+                if (cost < bpcost) { bpcost = cost; bpx = mx; bpy = my; }
+            }
+        bmx = (bpx + 2) >> 2; bmy = (bpy + 2) >> 2;
+        { int tx = bmx, ty = bmy; TRY(tx, ty); }
+    } else {
+        TRY(pmx, pmy);
+        bcost -= c->cmx[pmx << 2] + c->cmy[pmy << 2];
+        for (i = 0; i < n_mvc; i++) {
+            int mx = (mvc[i][0] + 2) >> 2, my = (mvc[i][1] + 2) >> 2;
+            if ((mx | my) && ((mx - bmx) | (my - bmy))) {
+                mx = clip3i(mx, c->fmin[0], c->fmax[0]); my = clip3i(my, c->fmin[1], c->fmax[1]);
+                TRY(mx, my);
+            }
+        }
+    }
+    TRY(0, 0);
+    if (method == 0) {                                           /* diamond, me.c:233-244 */
+        i = 0;
+        do {
+            int ox = bmx, oy = bmy;
+            TRY(ox, oy - 1); TRY(ox, oy + 1); TRY(ox - 1, oy); TRY(ox + 1, oy);
+            if (bmx == ox && bmy == oy) break;
+            if (!INRANGE(bmx, bmy)) break;
+        } while (++i < me_range);
+    } else {                                                     /* hexagon, me.c:246-305 */
+        int dir = -2, costs[6], ox, oy;
+        static const int first[6][2] = {{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2}};
+        for (i = 0; i < 6; i++) costs[i] = me_fpel_cost(c, bmx + first[i][0], bmy + first[i][1]);
+        for (i = 0; i < 6; i++) if (costs[i] < bcost) { bcost = costs[i]; dir = i; }
+        if (dir != -2) {
+            bmx += me_hex2[dir + 1][0]; bmy += me_hex2[dir + 1][1];
+            for (i = 1; i < me_range / 2 && INRANGE(bmx, bmy); i++) {
+                int odir = me_mod6m1[dir + 1], k;
+                for (k = 0; k < 3; k++) costs[k] = me_fpel_cost(c, bmx + me_hex2[odir + k][0], bmy + me_hex2[odir + k][1]);
+                dir = -2;
+                for (k = 0; k < 3; k++) if (costs[k] < bcost) { bcost = costs[k]; dir = odir - 1 + k; }
+                if (dir == -2) break;
+                bmx += me_hex2[dir + 1][0]; bmy += me_hex2[dir + 1][1];
+            }
+        }
+        ox = bmx; oy = bmy;                                      /* square refine */
+        TRY(ox, oy - 1); TRY(ox, oy + 1); TRY(ox - 1, oy); TRY(ox + 1, oy);
+        TRY(ox - 1, oy - 1); TRY(ox - 1, oy + 1); TRY(ox + 1, oy - 1); TRY(ox + 1, oy + 1);
+    }
+    int mvx, mvy, mcost;
+    if (bpcost < bcost) { mvx = bpx; mvy = bpy; mcost = bpcost; }
+    else { mvx = bmx << 2; mvy = bmy << 2; mcost = bcost; }
+    if (bmx == pmx && bmy == pmy && subme < 3) mcost += c->cmx[mvx] + c->cmy[mvy];
+    if (subme >= 2) {                                            /* refine_subpel(.., b_refine_qpel = 0), me.c:680-778 */
+        int hpel = me_subpel_iters[subme][2], qpel = me_subpel_iters[subme][3];
+        int bx = mvx, by = mvy, bc = mcost, odir = -1, bdir;
+        if (hpel && subme < 3) {
+            int mx = clip3i(mvp[0], c->smin[0], c->smax[0]), my = clip3i(mvp[1], c->smin[1], c->smax[1]);
+            if ((mx - bx) | (my - by)) { cost = me_qpel_cmp(c, mx, my, 0); if (cost < bc) { bc = cost; bx = mx; by = my; } }
+        }
+        for (i = hpel; i > 0; i--) {
+            int ox = bx, oy = by, c0 = me_qpel_cmp(c, ox, oy - 2, 0), c1 = me_qpel_cmp(c, ox, oy + 2, 0);
+            int c2 = me_qpel_cmp(c, ox - 2, oy, 0), c3 = me_qpel_cmp(c, ox + 2, oy, 0);
+            if (c0 < bc) { bc = c0; by = oy - 2; }
+            if (c1 < bc) { bc = c1; by = oy + 2; }
+            if (c2 < bc) { bc = c2; bx = ox - 2; by = oy; }
+            if (c3 < bc) { bc = c3; bx = ox + 2; by = oy; }
+            if (bx == ox && by == oy) break;
+        }
+        if (by > c->smax[1]) by = c->smax[1];
+        bc = ME_COST_MAX;
+        cost = me_satd_chroma(c, bx, by, bc, chroma_me, satd);
+        if (cost < bc) bc = cost;
+        if (thresh) {
+            if (((bc * 7) >> 3) > *thresh) { *pmvx = bx; *pmvy = by; return bc; }
+            if (bc < *thresh) *thresh = bc;
+        }
+        bdir = -1;
+        for (i = qpel; i > 0; i--) {
+            static const int dq[4][2] = {{0,-1},{0,1},{-1,0},{1,0}};
+            int ox = bx, oy = by, d;
+            odir = bdir;
+            for (d = 0; d < 4; d++)
+                if ((d ^ 1) != odir) {
+                    cost = me_satd_chroma(c, ox + dq[d][0], oy + dq[d][1], bc, chroma_me, satd);
+                    if (cost < bc) { bc = cost; bx = ox + dq[d][0]; by = oy + dq[d][1]; bdir = d; }
+                }
+            if (bx == ox && by == oy) break;
+        }
+        if (by > c->smax[1]) {
+            by = c->smax[1]; bc = ME_COST_MAX;
+            cost = me_satd_chroma(c, bx, by, bc, chroma_me, satd);
+            if (cost < bc) bc = cost;
+        }
+        mvx = bx; mvy = by; mcost = bc;
+    } else if (mvy > c->smax[1]) mvy = c->smax[1];
+#undef TRY
+#undef INRANGE
+    *pmvx = mvx; *pmvy = mvy;
+    return mcost;
+}
+
+void x264o_frame_me_search16(u8 *fy, u8 *fu, u8 *fv, u8 *const *refs /* [n][6] */, int n_refs, int mb_w, int mb_h, int sy, int sc,
+                             int method, int me_range, int subme, int chroma_me, int mv_range, const i16 *cost_mv, int cost_center,
+                             const i16 *mvp, const i16 *mvc, const u8 *n_mvc, const int32_t *ref_cost,
+                             i16 *out_mv, int32_t *out_cost, int32_t *best)
+{
+    init();
+    for (int mb = 0; mb < mb_w * mb_h; mb++) {
+        int mbx = mb % mb_w, mby = mb / mb_w, sp[4], fp[4];
+        int oy = 16 * mby * sy + 16 * mbx, oc = 8 * mby * sc + 8 * mbx;
+        int thresh = 0x7fffffff, bestc = 0x7fffffff;
+        mv_limits(mb_w, mb_h, mbx, mby, mv_range, sp, fp);
+        for (int r = 0; r < n_refs; r++) {
+            me_ctx c;
+            const i16 *p = mvp + ((size_t)mb * n_refs + r) * 2;
+            c.fenc = fy + oy; c.fenc_u = fu + oc; c.fenc_v = fv + oc; c.sy = sy; c.sc = sc;
+            for (int k = 0; k < 4; k++) c.fref[k] = refs[6 * r + k] + oy;
+            c.fref[4] = refs[6 * r + 4] + oc; c.fref[5] = refs[6 * r + 5] + oc;
+            c.cmx = cost_mv + cost_center - p[0]; c.cmy = cost_mv + cost_center - p[1];
+            c.fmin[0] = fp[0]; c.fmax[0] = fp[1]; c.fmin[1] = fp[2]; c.fmax[1] = fp[3];
+            c.smin[0] = sp[0]; c.smax[0] = sp[1]; c.smin[1] = sp[2]; c.smax[1] = sp[3];
+            int mvx, mvy, cost;
+            thresh -= ref_cost[r];
+            cost = me_search16(&c, p, (const i16 (*)[2])(mvc + ((size_t)mb * n_refs + r) * 16), n_mvc[mb * n_refs + r], method, me_range,
+                               subme, chroma_me, n_refs > 1 ? &thresh : 0, &mvx, &mvy);
+            cost += ref_cost[r];
+            thresh += ref_cost[r];
+            out_mv[((size_t)mb * n_refs + r) * 2] = mvx; out_mv[((size_t)mb * n_refs + r) * 2 + 1] = mvy;
+            out_cost[(size_t)mb * n_refs + r] = cost;
+            if (cost < bestc) { bestc = cost; best[4 * mb] = r; best[4 * mb + 1] = mvx; best[4 * mb + 2] = mvy; best[4 * mb + 3] = cost; }
+        }
     }
 }
 

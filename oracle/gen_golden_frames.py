@@ -160,9 +160,82 @@ def encode_cases(lib):
         print("wrote", name, "coded MBs", int((cbp != 0).sum()), "of", n, "skippable", skip.sum(axis=1))
 
 
+ME_CASES = [((352, 288), 1, 16, 7, 1, 26), ((352, 288), 0, 16, 5, 1, 30), ((200, 120), 1, 16, 2, 0, 22), ((200, 120), 1, 8, 1, 0, 36),
+            ((352, 288), 1, 16, 3, 1, 40), ((200, 120), 0, 16, 0, 0, 26)]
+ME_LAMBDA = (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+             6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91)
+
+
+def me_inputs(size, seed, n_refs=3):
+    """Seeded predictors: mvp per (mb, ref) and up to 5 extra candidates (zeros, duplicates of mvp,
+    far-away vectors that the search has to clip)."""
+    g = hostpic.Geometry(*size)
+    n = g.mb_w * g.mb_h
+    r = np.random.RandomState(seed)
+    mvp = r.randint(-14, 15, (n, n_refs, 2)).astype(np.int16)
+    mvp[r.rand(n) < 0.25] = 0
+    mvp[r.rand(n) < 0.05] = (300, -260)
+    mvc = r.randint(-40, 41, (n, n_refs, 8, 2)).astype(np.int16)
+    mvc[:, :, 1] = 0
+    mvc[:, :, 3] = mvp
+    mvc[r.rand(n) < 0.1, :, 2] = (-700, 500)
+    n_mvc = r.randint(0, 6, (n, n_refs)).astype(np.uint8)
+    return g, mvp, mvc, n_mvc
+
+
+def me_frames(lib_prepare, size):
+    """cur = synthetic frame 7, refs = frames 6, 5, 4 made into references by `lib_prepare`."""
+    g = hostpic.Geometry(*size)
+    pics = []
+    for t in (7, 6, 5, 4):
+        hp = hostpic.HostPic(g)
+        lib_prepare(hp, synth.frame(size[0], size[1], t), t != 7)
+        pics.append(hp)
+    return pics[0], pics[1:]
+
+
+def me_cases(lib):
+    """Golden outputs of the reference's x264_me_search_ref (16x16) over whole frames."""
+    from x264_vs2008_amd.frame import cost_mv_table
+    vp = hostpic.vp
+
+    def prep(hp, yuv, is_ref):
+        for nm, img in zip(("y", "u", "v"), yuv):
+            hp.set_visible(nm, img)
+        f = ref_frame(hp)
+        lib.refshim_source_prepare(C.byref(f), 0)
+        if is_ref:
+            lib.refshim_fdec_filter(C.byref(f), 0, None, None, None, None, None, None, 0, 0, 0, 1)
+
+    for size, method, me_range, subme, chroma_me, qp in ME_CASES:
+        g, mvp, mvc, n_mvc = me_inputs(size, 100 * subme + qp)
+        n = g.mb_w * g.mb_h
+        cur, refs = me_frames(prep, size)
+        rr = (RefRef * 3)()
+        for i, hp in enumerate(refs):
+            for k, nm in enumerate(("y", "h", "vv", "c")):
+                rr[i].y[k] = hp.ptr(nm)
+            rr[i].u = hp.ptr("u"); rr[i].v = hp.ptr("v")
+        lam = ME_LAMBDA[qp]
+        span = 4 * 2048
+        tab = cost_mv_table(lam, span).view(np.int16)
+        ref_cost = (lam * np.array([1, 3, 3])).astype(np.int32)
+        out_mv = np.zeros((n, 3, 2), np.int16); out_cost = np.zeros((n, 3), np.int32); best = np.zeros((n, 4), np.int32)
+        center = C.cast(tab.ctypes.data + 2 * span, C.c_void_p)
+        lib.refshim_me_search16_frame(cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), rr, 3, size[0], size[1], g.stride_y, g.stride_c,
+                                      method, me_range, subme, chroma_me, 512, center, vp(mvp), vp(mvc), vp(n_mvc), vp(ref_cost),
+                                      vp(out_mv), vp(out_cost), vp(best))
+        name = "me16_%dx%d_m%d_r%d_s%d_c%d_qp%d.npz" % (size[0], size[1], method, me_range, subme, chroma_me, qp)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name), mvp=mvp, mvc=mvc, n_mvc=n_mvc, ref_cost=ref_cost,
+                            out_mv=out_mv, out_cost=out_cost, best=best)
+        print("wrote", name, "best-ref histogram", np.bincount(best[:, 0], minlength=3), "fractional mvs",
+              int((out_mv % 4 != 0).any(axis=2).sum()))
+
+
 def main():
     lib = hostpic.load_lazy(os.path.join(HERE, "_ref", "libx264ref.so"))
     vp = hostpic.vp
+    me_cases(lib)
     encode_cases(lib)
     for size, seed, a_off, b_off, c_off, qlo, qhi in CASES:
         g, inp = make_case(size, seed, qlo, qhi)

@@ -294,5 +294,68 @@ void refshim_probe_skip_frame(uint8_t *fy, uint8_t *fu, uint8_t *fv, const refsh
         skip_out[mb] = (uint8_t)x264_macroblock_probe_skip(h, 0);
     }
 }
+/* ---------------------------------------------------------------------------
+ * The reference's own x264_me_search_ref (R/encoder/me.c:156-631, with its
+ * refine_subpel) for the 16x16 block of every macroblock and every reference,
+ * in the loop of x264_mb_analyse_inter_p16x16 (R/encoder/analyse.c:1077-1127):
+ * the half-pel threshold is carried from reference to reference and the best
+ * reference is the first minimum of cost + ref cost.  Predictors (mvp, mvc)
+ * are inputs.  mbcmp / fpelcmp are selected as mbcmp_init does
+ * (R/encoder/encoder.c:608-618; that function is static there).              */
+#include <limits.h>
+#include "encoder/me.h"
+void refshim_me_search16_frame(uint8_t *fy, uint8_t *fu, uint8_t *fv, const refshim_ref *refs, int n_refs, int width, int height,
+                               int stride_y, int stride_c, int method, int me_range, int subme, int chroma_me, int mv_range,
+                               int16_t *cost_mv_center, const int16_t *mvp, const int16_t *mvc, const uint8_t *n_mvc,
+                               const int32_t *ref_cost, int16_t *out_mv, int32_t *out_cost, int32_t *best)
+{
+    x264_t *h = enc_h(width, height, stride_y, stride_c, 26, 26, 0, 0);
+    int n = h->mb.i_mb_count, mb, r, satd = subme > 1;
+    int mb_w = h->sps->i_mb_width, mb_h = h->sps->i_mb_height;
+    memcpy(h->pixf.mbcmp, satd ? h->pixf.satd : h->pixf.sad_aligned, sizeof(h->pixf.mbcmp));
+    memcpy(h->pixf.mbcmp_unaligned, satd ? h->pixf.satd : h->pixf.sad, sizeof(h->pixf.mbcmp_unaligned));
+    memcpy(h->pixf.fpelcmp, h->pixf.sad, sizeof(h->pixf.fpelcmp));
+    memcpy(h->pixf.fpelcmp_x3, h->pixf.sad_x3, sizeof(h->pixf.fpelcmp_x3));
+    memcpy(h->pixf.fpelcmp_x4, h->pixf.sad_x4, sizeof(h->pixf.fpelcmp_x4));
+    h->mb.i_me_method = method ? X264_ME_HEX : X264_ME_DIA;
+    h->mb.i_subpel_refine = subme;
+    h->mb.b_chroma_me = chroma_me;
+    h->param.analyse.i_me_range = me_range;
+    for (mb = 0; mb < n; mb++) {
+        int mbx = mb % mb_w, mby = mb / mb_w;
+        int fr = 4 * mv_range, lo = 4 * (-512 + 8) > -fr ? 4 * (-512 + 8) : -fr;
+        int thresh = INT_MAX, bestc = INT_MAX;
+        enc_load_mb(h, mb, fy, fu, fv, refs, n_refs);
+        /* x264_mb_analyse_init, R/encoder/analyse.c:258-298 */
+        h->mb.mv_min_spel[0] = x264_clip3(h->mb.mv_min[0], -fr, fr - 1);
+        h->mb.mv_max_spel[0] = x264_clip3(h->mb.mv_max[0], -fr, fr - 1);
+        h->mb.mv_min_spel[1] = x264_clip3(h->mb.mv_min[1], lo, fr);
+        h->mb.mv_max_spel[1] = x264_clip3(h->mb.mv_max[1], -fr, fr - 1);
+        h->mb.mv_min_fpel[0] = (h->mb.mv_min_spel[0] >> 2) + 5; h->mb.mv_max_fpel[0] = (h->mb.mv_max_spel[0] >> 2) - 5;
+        h->mb.mv_min_fpel[1] = (h->mb.mv_min_spel[1] >> 2) + 5; h->mb.mv_max_fpel[1] = (h->mb.mv_max_spel[1] >> 2) - 5;
+        for (r = 0; r < n_refs; r++) {
+            x264_me_t m;
+            DECLARE_ALIGNED_4(int16_t cand[8][2]);
+            int k, nc = n_mvc[mb * n_refs + r];
+            memset(&m, 0, sizeof(m));
+            m.i_pixel = PIXEL_16x16;
+            m.p_cost_mv = cost_mv_center;
+            m.i_ref_cost = ref_cost[r]; m.i_ref = r;
+            for (k = 0; k < 3; k++) m.p_fenc[k] = h->mb.pic.p_fenc[k];
+            for (k = 0; k < 6; k++) m.p_fref[k] = h->mb.pic.p_fref[0][r][k];
+            m.i_stride[0] = stride_y; m.i_stride[1] = stride_c;
+            m.mvp[0] = mvp[(mb * n_refs + r) * 2]; m.mvp[1] = mvp[(mb * n_refs + r) * 2 + 1];
+            for (k = 0; k < 8; k++) { cand[k][0] = mvc[((mb * n_refs + r) * 8 + k) * 2]; cand[k][1] = mvc[((mb * n_refs + r) * 8 + k) * 2 + 1]; }
+            thresh -= ref_cost[r];
+            x264_me_search_ref(h, &m, cand, nc, n_refs > 1 ? &thresh : NULL);
+            m.cost += ref_cost[r];
+            thresh += ref_cost[r];
+            out_mv[(mb * n_refs + r) * 2] = m.mv[0]; out_mv[(mb * n_refs + r) * 2 + 1] = m.mv[1];
+            out_cost[mb * n_refs + r] = m.cost;
+            if (m.cost < bestc) { bestc = m.cost; best[4 * mb] = r; best[4 * mb + 1] = m.mv[0]; best[4 * mb + 2] = m.mv[1]; best[4 * mb + 3] = m.cost; }
+        }
+    }
+}
+
 extern const int x264_lambda2_tab[52];   /* R/encoder/analyse.c:151-159 */
 int refshim_lambda2(int qp) { return x264_lambda2_tab[qp]; }

@@ -16,6 +16,49 @@ SIZES = [(352, 288), (200, 120)]
 ENC_CASES = [((352, 288), 24, 0, 0), ((352, 288), 27, 1, 0), ((200, 120), 33, 1, 1), ((200, 120), 14, 0, 0)]
 
 
+ME_CASES = [((352, 288), 1, 16, 7, 1, 26), ((352, 288), 0, 16, 5, 1, 30), ((200, 120), 1, 16, 2, 0, 22), ((200, 120), 1, 8, 1, 0, 36),
+            ((352, 288), 1, 16, 3, 1, 40), ((200, 120), 0, 16, 0, 0, 26)]
+
+
+def me_setup(lib, prefix, size):
+    """cur = synthetic frame 7; references = frames 6, 5, 4 with borders and half-pel planes."""
+    from x264_vs2008_amd import synth
+    g = hostpic.Geometry(*size)
+    pics = []
+    for t in (7, 6, 5, 4):
+        hp = hostpic.HostPic(g)
+        hp.load_yuv(lib, prefix, *synth.frame(size[0], size[1], t))
+        if t != 7:
+            hostpic.make_reference(lib, prefix, hp)
+        pics.append(hp)
+    return g, pics[0], pics[1:]
+
+
+@pytest.mark.parametrize("size,method,me_range,subme,chroma_me,qp", ME_CASES)
+def test_me_search_twin_matches_reference_me_search_ref(oracle_lib, size, method, me_range, subme, chroma_me, qp):
+    """Twin vs the reference's own x264_me_search_ref + refine_subpel on whole frames, three
+    references with the half-pel threshold chain (oracle/ref_shim.c, gen_golden_frames.py)."""
+    from x264_vs2008_amd.frame import cost_mv_table
+    from x264_vs2008_amd.pipeline import LAMBDA_TAB
+    name = "me16_%dx%d_m%d_r%d_s%d_c%d_qp%d.npz" % (size[0], size[1], method, me_range, subme, chroma_me, qp)
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        gold = {k: z[k] for k in z.files}
+    g, cur, refs = me_setup(oracle_lib, "x264o_", size)
+    n = g.mb_w * g.mb_h
+    vp = hostpic.vp
+    span = 4 * 2048
+    tab = np.ascontiguousarray(cost_mv_table(LAMBDA_TAB[qp], span).view(np.int16))
+    planes = (hostpic.u8p * 18)(*[hp.ptr(nm) for hp in refs for nm in ("y", "h", "vv", "c", "u", "v")])
+    out_mv = np.zeros((n, 3, 2), np.int16); out_cost = np.zeros((n, 3), np.int32); best = np.zeros((n, 4), np.int32)
+    a = {k: np.ascontiguousarray(gold[k]) for k in ("mvp", "mvc", "n_mvc", "ref_cost")}
+    oracle_lib.x264o_frame_me_search16(cur.ptr("y"), cur.ptr("u"), cur.ptr("v"), planes, 3, g.mb_w, g.mb_h, g.stride_y, g.stride_c,
+                                       method, me_range, subme, chroma_me, 512, vp(tab), span, vp(a["mvp"]), vp(a["mvc"]),
+                                       vp(a["n_mvc"]), vp(a["ref_cost"]), vp(out_mv), vp(out_cost), vp(best))
+    assert np.array_equal(out_mv, gold["out_mv"]), "vectors differ at %s" % np.argwhere(out_mv != gold["out_mv"])[:5]
+    assert np.array_equal(out_cost, gold["out_cost"]), "costs differ at %s" % np.argwhere(out_cost != gold["out_cost"])[:5]
+    assert np.array_equal(best, gold["best"]), "best reference differs"
+
+
 @pytest.mark.parametrize("size,qp,t8,field", ENC_CASES)
 def test_residual_and_probe_skip_twins_match_reference_encode(oracle_lib, cqm, size, qp, t8, field):
     """Twin vs the reference's own x264_macroblock_encode (general P partitions, two references)

@@ -175,6 +175,30 @@ int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, c
                             const x264hip_me_params *p, const int16_t *mv_fullpel_dev /* [mb][9][2], uses entry 0 */,
                             int16_t *out_mv_qpel_dev /* [mb][2] */, int32_t *out_cost_dev /* [mb] */);
 
+/* The reference's own search, exactly: x264_me_search_ref + refine_subpel for the 16x16 block
+ * (R/encoder/me.c:156-778) for every macroblock and every reference, inside the loop of
+ * x264_mb_analyse_inter_p16x16 (R/encoder/analyse.c:1077-1127): predictor tests, DIA / HEX walk,
+ * square refine, half-pel + quarter-pel diamonds (SAD / SATD per subme, chroma ME), the half-pel
+ * early-termination threshold carried across references, best reference = first minimum of
+ * cost + ref_cost.  Predictors are inputs (the caller derives them from neighbours / lookahead).
+ *   cost_mv  : device int16 table, cost of qpel delta d at cost_mv[cost_mv_range + d] (p_cost_mv)
+ *   mvp      : [mb][n_refs][2] qpel;  mvc : [mb][n_refs][8][2];  n_mvc : [mb][n_refs] (0..8)
+ *   out_mv   : [mb][n_refs][2] qpel;  out_cost : [mb][n_refs] (ref cost included)
+ *   best     : [mb][4] = {ref, mvx, mvy, cost}                                             */
+typedef struct {
+    int me_method;             /* 0 = X264_ME_DIA, 1 = X264_ME_HEX */
+    int me_range, subme, chroma_me;
+    int mv_range;              /* pixels; 0 = 512 */
+    const int16_t *cost_mv;    /* device */
+    int cost_mv_range;
+    const int16_t *mvp, *mvc;  /* device */
+    const uint8_t *n_mvc;      /* device */
+    int ref_cost[8];           /* REF_COST(0, i) = lambda * bs_size_te(n_refs - 1, i) */
+} x264hip_me16_params;
+int x264hip_me_search16_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs,
+                              int n_refs, const x264hip_me16_params *p, int16_t *out_mv_dev, int32_t *out_cost_dev,
+                              int32_t *best_dev);
+
 /* Inter residual pipeline for every macroblock (x264_macroblock_encode's
  * inter branch, R/encoder/macroblock.c:596-768, without trellis/denoise):
  * x264_mb_mc 16x16 (mc_luma + mc_chroma) -> sub16x16_dct(8) -> quant ->

@@ -30,6 +30,12 @@ class MeParams(C.Structure):
                 ("mv_range", C.c_int)]
 
 
+class Me16Params(C.Structure):
+    _fields_ = [("me_method", C.c_int), ("me_range", C.c_int), ("subme", C.c_int), ("chroma_me", C.c_int),
+                ("mv_range", C.c_int), ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int),
+                ("mvp", C.c_void_p), ("mvc", C.c_void_p), ("n_mvc", C.c_void_p), ("ref_cost", C.c_int * 8)]
+
+
 class ResidualParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("qp_chroma", C.c_int), ("transform8x8", C.c_int), ("b_interlaced", C.c_int),
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p),

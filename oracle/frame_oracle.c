@@ -340,7 +340,7 @@ static int me_satd_chroma(const me_ctx *c, int mx, int my, int bcost, int chroma
 
 /* returns cost; *pmvx,*pmvy the vector; *thresh the half-pel threshold (NULL = none) */
 static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], int n_mvc, int method, int me_range, int subme,
-                       int chroma_me, int *thresh, int *pmvx, int *pmvy)
+                       int chroma_me, int *thresh, int *pmvx, int *pmvy, int *pcost_mv)
 {
     const int satd = subme > 1;       /* mbcmp = SATD above subme 1; fpelcmp stays SAD (encoder.c:608-618) */
     int bmx = clip3i(mvp[0], c->fmin[0] * 4, c->fmax[0] * 4), bmy = clip3i(mvp[1], c->fmin[1] * 4, c->fmax[1] * 4);
@@ -403,6 +403,7 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
     int mvx, mvy, mcost;
     if (bpcost < bcost) { mvx = bpx; mvy = bpy; mcost = bpcost; }
     else { mvx = bmx << 2; mvy = bmy << 2; mcost = bcost; }
+    if (pcost_mv) *pcost_mv = c->cmx[mvx] + c->cmy[mvy];          /* m->cost_mv, me.c:615 */
     if (bmx == pmx && bmy == pmy && subme < 3) mcost += c->cmx[mvx] + c->cmy[mvy];
     if (subme >= 2) {                                            /* refine_subpel(.., b_refine_qpel = 0), me.c:680-778 */
         int hpel = me_subpel_iters[subme][2], qpel = me_subpel_iters[subme][3];
@@ -446,6 +447,7 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
             if (cost < bc) bc = cost;
         }
         mvx = bx; mvy = by; mcost = bc;
+        if (pcost_mv) *pcost_mv = c->cmx[bx] + c->cmy[by];       /* me.c:777 */
     } else if (mvy > c->smax[1]) mvy = c->smax[1];
 #undef TRY
 #undef INRANGE
@@ -476,7 +478,7 @@ void x264o_frame_me_search16(u8 *fy, u8 *fu, u8 *fv, u8 *const *refs /* [n][6] *
             int mvx, mvy, cost;
             thresh -= ref_cost[r];
             cost = me_search16(&c, p, (const i16 (*)[2])(mvc + ((size_t)mb * n_refs + r) * 16), n_mvc[mb * n_refs + r], method, me_range,
-                               subme, chroma_me, n_refs > 1 ? &thresh : 0, &mvx, &mvy);
+                               subme, chroma_me, n_refs > 1 ? &thresh : 0, &mvx, &mvy, 0);
             cost += ref_cost[r];
             thresh += ref_cost[r];
             out_mv[((size_t)mb * n_refs + r) * 2] = mvx; out_mv[((size_t)mb * n_refs + r) * 2 + 1] = mvy;
@@ -821,3 +823,7 @@ void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int
             }
         }
 }
+
+#ifndef X264O_USE_REF
+#include "slice_oracle.c"     /* the per-macroblock sweep twin; shares the helpers above */
+#endif

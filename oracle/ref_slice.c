@@ -1,0 +1,234 @@
+/* ref_slice.c -- TEST INFRASTRUCTURE.  Compiled only into oracle/_ref/libx264ref.so against the
+ * reference's headers where they lie.  It contains no reference code.
+ *
+ * Runs the reference's OWN per-macroblock hot loop over a chain of frames (I then P, every frame
+ * kept as reference): x264_macroblock_cache_load -> x264_macroblock_analyse ->
+ * x264_macroblock_encode -> x264_macroblock_cache_save, with the row-delayed
+ * x264_frame_deblock_row / x264_frame_expand_border / x264_frame_filter, i.e. what
+ * x264_slice_write + x264_fdec_filter_row do (R/encoder/encoder.c:983-1056,1141-1291; both are
+ * static in encoder.c, which cannot be built here, so their dozen lines of sequencing are restated
+ * below).  The entropy writer is not called: without RD (subme < 6) nothing it computes feeds back
+ * into analysis.  Frames come from x264_frame_new, tables from the x264_*_init functions, the QP
+ * from x264_ratecontrol_new/start (CQP).  Every decision and every pixel is produced by reference
+ * code; this file only sequences calls and copies results out.                                     */
+#include "common/common.h"
+#include "encoder/ratecontrol.h"
+#include "encoder/analyse.h"
+#include "encoder/macroblock.h"
+
+typedef struct {
+    int width, height, n_frames, qp;
+    int me_method, me_range, subme, n_refs;
+    int inter, intra;                        /* X264_ANALYSE_* */
+    int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
+    int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
+} refslice_params;
+
+typedef struct {
+    int8_t *mb_type, *partition, *sub_partition;     /* [F][n], [F][n], [F][n][4] */
+    int16_t *mv;                                      /* [F][n][16][2] */
+    int8_t *ref;                                      /* [F][n][4] */
+    int16_t *mvr;                                     /* [F][n_refs][n][2] */
+    uint8_t *nnz;                                     /* [F][n][27] in x264_scan8 index order */
+    int8_t *i4mode, *i16mode, *chroma_mode, *qp;      /* [F][n][16], [F][n] ... */
+    int16_t *cbp;                                     /* [F][n] */
+    int8_t *t8;                                       /* [F][n] */
+    int16_t *luma, *luma_dc, *chroma_dc, *chroma_ac;  /* [F][n][256], [16], [8], [128] */
+    uint8_t *rec_y, *rec_u, *rec_v;                   /* [F][16 mb_h][16 mb_w] ... before deblocking */
+    uint8_t *fin_y, *fin_u, *fin_v;                   /* after x264_fdec_filter_row */
+    int32_t *frame_info;                              /* [F][4] slice type, qp, i_ref0, poc */
+    int64_t *stat;                                    /* [F][4] i_intra_cost, i_inter_cost, i_mbs_analysed, 0 */
+} refslice_out;
+
+static void sel_cmp(x264_t *h)        /* what mbcmp_init selects (R/encoder/encoder.c:608-618) */
+{
+    int satd = h->param.analyse.i_subpel_refine > 1;
+    memcpy(h->pixf.mbcmp, satd ? h->pixf.satd : h->pixf.sad_aligned, sizeof(h->pixf.mbcmp));
+    memcpy(h->pixf.mbcmp_unaligned, satd ? h->pixf.satd : h->pixf.sad, sizeof(h->pixf.mbcmp_unaligned));
+    h->pixf.intra_mbcmp_x3_16x16 = satd ? h->pixf.intra_satd_x3_16x16 : h->pixf.intra_sad_x3_16x16;
+    memcpy(h->pixf.fpelcmp, h->pixf.sad, sizeof(h->pixf.fpelcmp));
+    memcpy(h->pixf.fpelcmp_x3, h->pixf.sad_x3, sizeof(h->pixf.fpelcmp_x3));
+    memcpy(h->pixf.fpelcmp_x4, h->pixf.sad_x4, sizeof(h->pixf.fpelcmp_x4));
+}
+
+static void filter_row(x264_t *h, int mb_y)        /* x264_fdec_filter_row's sequencing, no mbaff, one thread */
+{
+    int b_end = mb_y == h->sps->i_mb_height, min_y = mb_y - 1, i;
+    if (min_y < 0)
+        return;
+    if (!b_end)
+        for (i = 0; i < 3; i++)
+            memcpy(h->mb.intra_border_backup[0][i], h->fdec->plane[i] + ((mb_y * 16 >> !!i) - 1) * h->fdec->i_stride[i],
+                   h->sps->i_mb_width * 16 >> !!i);
+    if (!h->sh.i_disable_deblocking_filter_idc)
+        x264_frame_deblock_row(h, min_y);
+    x264_frame_expand_border(h, h->fdec, min_y, b_end);
+    if (h->param.analyse.i_subpel_refine) {
+        x264_frame_filter(h, h->fdec, min_y, b_end);
+        x264_frame_expand_border_filtered(h, h->fdec, min_y, b_end);
+    }
+}
+
+static const uint8_t flat16[64] = {
+    16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,
+    16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16 };
+
+int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
+                          refslice_out *o)
+{
+    x264_t *h = calloc(1, sizeof(x264_t));
+    x264_frame_t *refs[16] = {0};
+    int n_avail = 0, f, i, k, y, mb_w, mb_h, n, last_idr = 0;
+    int cw = p->width / 2, ch = p->height / 2;
+
+    x264_param_default(&h->param);
+    h->param.i_width = p->width; h->param.i_height = p->height;
+    h->param.i_threads = 1; h->param.b_cabac = p->cabac; h->param.i_frame_reference = p->n_refs; h->param.i_bframe = 0;
+    h->param.i_log_level = X264_LOG_NONE;
+    h->param.analyse.inter = p->inter; h->param.analyse.intra = p->intra;
+    h->param.analyse.i_me_method = p->me_method; h->param.analyse.i_me_range = p->me_range;
+    h->param.analyse.i_mv_range = 512; h->param.analyse.i_subpel_refine = p->subme;
+    h->param.analyse.b_chroma_me = p->chroma_me; h->param.analyse.b_mixed_references = p->mixed_refs;
+    h->param.analyse.b_fast_pskip = p->fast_pskip; h->param.analyse.b_dct_decimate = p->dct_decimate;
+    h->param.analyse.b_transform_8x8 = p->transform8x8; h->param.analyse.i_trellis = 0;
+    h->param.analyse.i_noise_reduction = 0; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
+    h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
+    h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
+    h->param.rc.i_qp_min = 0; h->param.rc.i_qp_max = 51;
+    h->thread[0] = h;
+    h->sps = &h->sps_array[0]; h->pps = &h->pps_array[0];
+    mb_w = h->sps->i_mb_width = (p->width + 15) / 16; mb_h = h->sps->i_mb_height = (p->height + 15) / 16;
+    h->sps->b_frame_mbs_only = 1;
+    n = h->mb.i_mb_count = mb_w * mb_h;
+    h->pps->b_cabac = p->cabac; h->pps->b_transform_8x8_mode = p->transform8x8;
+    for (i = 0; i < 6; i++) h->pps->scaling_list[i] = flat16;
+    h->chroma_qp_table = i_chroma_qp_table + 12 + p->chroma_qp_offset;
+    if (x264_cqm_init(h) < 0) return -1;
+    x264_pixel_init(0, &h->pixf); x264_dct_init(0, &h->dctf); x264_zigzag_init(0, &h->zigzagf, 0);
+    x264_quant_init(h, 0, &h->quantf); x264_mc_init(0, &h->mc); x264_deblock_init(0, &h->loopf);
+    x264_predict_16x16_init(0, h->predict_16x16); x264_predict_8x8c_init(0, h->predict_8x8c);
+    x264_predict_8x8_init(0, h->predict_8x8, &h->predict_8x8_filter); x264_predict_4x4_init(0, h->predict_4x4);
+    sel_cmp(h);
+    h->frames.b_have_lowres = 0;
+    h->fenc = x264_frame_new(h);
+    h->fdec = x264_frame_new(h);
+    if (x264_macroblock_cache_init(h) < 0 || x264_ratecontrol_new(h) < 0) return -2;
+
+    for (f = 0; f < p->n_frames; f++) {
+        int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
+        size_t F = f;
+        if (idr) {
+            for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
+            n_avail = 0; last_idr = f;
+        }
+        /* x264_frame_copy_picture + x264_frame_expand_border_mod16 (R/encoder/encoder.c:1406-1413) */
+        for (y = 0; y < p->height; y++)
+            memcpy(h->fenc->plane[0] + y * h->fenc->i_stride[0], src_y + (F * p->height + y) * p->width, p->width);
+        for (y = 0; y < ch; y++) {
+            memcpy(h->fenc->plane[1] + y * h->fenc->i_stride[1], src_u + (F * ch + y) * cw, cw);
+            memcpy(h->fenc->plane[2] + y * h->fenc->i_stride[2], src_v + (F * ch + y) * cw, cw);
+        }
+        x264_frame_expand_border_mod16(h, h->fenc);
+        h->fenc->i_frame = f; h->fenc->i_poc = 2 * (f - last_idr);
+        h->fenc->i_type = idr ? X264_TYPE_IDR : X264_TYPE_P;
+        h->fdec->i_frame = f; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type; h->fdec->b_kept_as_ref = 1;
+        h->i_ref0 = n_avail < p->n_refs ? n_avail : p->n_refs;
+        for (i = 0; i < h->i_ref0; i++) h->fref0[i] = refs[i];
+        h->i_ref1 = 0;
+        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = 0;
+        memset(&h->sh, 0, sizeof(h->sh));
+        h->sh.i_type = idr ? SLICE_TYPE_I : SLICE_TYPE_P;
+        h->sh.i_first_mb = 0; h->sh.i_last_mb = n;
+        h->sh.i_num_ref_idx_l0_active = h->i_ref0 <= 0 ? 1 : h->i_ref0;
+        h->sh.i_num_ref_idx_l1_active = 1;
+        h->sh.i_disable_deblocking_filter_idc = !p->deblock;
+        h->sh.i_alpha_c0_offset = p->alpha_c0; h->sh.i_beta_offset = p->beta;
+        x264_ratecontrol_start(h, 0);
+        h->sh.i_qp = x264_ratecontrol_qp(h);
+        x264_macroblock_slice_init(h);
+        memset(&h->stat.frame, 0, sizeof(h->stat.frame));
+        h->mb.i_last_qp = h->sh.i_qp; h->mb.i_last_dqp = 0;
+        o->frame_info[4 * F] = h->sh.i_type; o->frame_info[4 * F + 1] = h->sh.i_qp;
+        o->frame_info[4 * F + 2] = h->i_ref0; o->frame_info[4 * F + 3] = h->fdec->i_poc;
+
+        for (int mb = 0; mb < n; mb++) {
+            int mx = mb % mb_w, my = mb / mb_w;
+            size_t M = F * n + mb;
+            int16_t *ly = o->luma + M * 256, *ldc = o->luma_dc + M * 16, *cdc = o->chroma_dc + M * 8, *cac = o->chroma_ac + M * 128;
+            uint8_t *nz = o->nnz + M * 27;
+            if (mx == 0) filter_row(h, my);
+            x264_macroblock_cache_load(h, mx, my);
+            x264_macroblock_analyse(h);
+            x264_macroblock_encode(h);
+            /* reconstruction before deblocking */
+            for (y = 0; y < 16; y++)
+                memcpy(o->rec_y + (F * 16 * mb_h + 16 * my + y) * 16 * mb_w + 16 * mx, h->mb.pic.p_fdec[0] + y * FDEC_STRIDE, 16);
+            for (y = 0; y < 8; y++) {
+                memcpy(o->rec_u + (F * 8 * mb_h + 8 * my + y) * 8 * mb_w + 8 * mx, h->mb.pic.p_fdec[1] + y * FDEC_STRIDE, 8);
+                memcpy(o->rec_v + (F * 8 * mb_h + 8 * my + y) * 8 * mb_w + 8 * mx, h->mb.pic.p_fdec[2] + y * FDEC_STRIDE, 8);
+            }
+            x264_macroblock_cache_save(h);
+            h->stat.frame.i_mb_count[h->mb.i_type]++;
+
+            o->mb_type[M] = h->mb.i_type;
+            o->partition[M] = IS_INTRA(h->mb.i_type) || h->mb.i_type == P_SKIP ? D_16x16 : h->mb.i_partition;
+            for (i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = h->mb.i_type == P_8x8 ? h->mb.i_sub_partition[i] : 0;
+            for (i = 0; i < 27; i++) nz[i] = h->mb.cache.non_zero_count[x264_scan8[i]];
+            if (h->mb.i_type == I_PCM) memset(nz, 16, 27);
+            o->qp[M] = h->mb.qp[mb]; o->cbp[M] = h->mb.cbp[mb]; o->t8[M] = h->mb.mb_transform_size[mb];
+            o->i16mode[M] = h->mb.i_type == I_16x16 ? h->mb.i_intra16x16_pred_mode : 0;
+            o->chroma_mode[M] = IS_INTRA(h->mb.i_type) ? h->mb.i_chroma_pred_mode : 0;
+            for (i = 0; i < 16; i++)
+                o->i4mode[M * 16 + i] = h->mb.i_type == I_4x4 || h->mb.i_type == I_8x8 ? h->mb.cache.intra4x4_pred_mode[x264_scan8[i]] : I_PRED_4x4_DC;
+            if (h->sh.i_type != SLICE_TYPE_I) {
+                for (i = 0; i < 16; i++) {
+                    int o4 = h->mb.i_b4_xy + (i & 3) + (i >> 2) * h->mb.i_b4_stride;
+                    o->mv[(M * 16 + i) * 2] = h->mb.mv[0][o4][0]; o->mv[(M * 16 + i) * 2 + 1] = h->mb.mv[0][o4][1];
+                }
+                for (i = 0; i < 4; i++) o->ref[M * 4 + i] = h->mb.ref[0][h->mb.i_b8_xy + (i & 1) + (i >> 1) * h->mb.i_b8_stride];
+                for (k = 0; k < h->i_ref0; k++) {
+                    o->mvr[((F * p->n_refs + k) * n + mb) * 2] = h->mb.mvr[0][k][mb][0];
+                    o->mvr[((F * p->n_refs + k) * n + mb) * 2 + 1] = h->mb.mvr[0][k][mb][1];
+                }
+            } else
+                for (i = 0; i < 4; i++) o->ref[M * 4 + i] = -1;
+            /* coefficient levels, masked by what the entropy coder would read (cbp, then nnz) */
+            memset(ly, 0, 512); memset(ldc, 0, 32); memset(cdc, 0, 16); memset(cac, 0, 256);
+            if (!IS_SKIP(h->mb.i_type) && h->mb.i_type != I_PCM) {
+                if (h->mb.i_type == I_16x16 && nz[24]) memcpy(ldc, h->dct.luma16x16_dc, 32);
+                if (h->mb.b_transform_8x8) {
+                    for (i = 0; i < 4; i++)
+                        if ((h->mb.i_cbp_luma >> i & 1) && nz[4 * i]) memcpy(ly + 64 * i, h->dct.luma8x8[i], 128);
+                } else
+                    for (i = 0; i < 16; i++)
+                        if ((h->mb.i_cbp_luma >> (i >> 2) & 1) && nz[i]) memcpy(ly + 16 * i, h->dct.luma4x4[i], 32);
+                if (h->mb.i_cbp_chroma)
+                    for (i = 0; i < 2; i++) if (nz[25 + i]) memcpy(cdc + 4 * i, h->dct.chroma_dc[i], 8);
+                if (h->mb.i_cbp_chroma == 2)
+                    for (i = 0; i < 8; i++) if (nz[16 + i]) memcpy(cac + 16 * i, h->dct.luma4x4[16 + i], 32);
+            }
+        }
+        filter_row(h, mb_h);
+        o->stat[4 * F] = h->stat.frame.i_intra_cost; o->stat[4 * F + 1] = h->stat.frame.i_inter_cost;
+        o->stat[4 * F + 2] = h->stat.frame.i_mbs_analysed; o->stat[4 * F + 3] = 0;
+        for (y = 0; y < 16 * mb_h; y++)
+            memcpy(o->fin_y + (F * 16 * mb_h + y) * 16 * mb_w, h->fdec->plane[0] + y * h->fdec->i_stride[0], 16 * mb_w);
+        for (y = 0; y < 8 * mb_h; y++) {
+            memcpy(o->fin_u + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[1] + y * h->fdec->i_stride[1], 8 * mb_w);
+            memcpy(o->fin_v + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[2] + y * h->fdec->i_stride[2], 8 * mb_w);
+        }
+        /* x264_reference_update: newest first */
+        if (n_avail == 16) x264_frame_delete(refs[--n_avail]);
+        for (i = n_avail; i > 0; i--) refs[i] = refs[i - 1];
+        refs[0] = h->fdec; n_avail++;
+        if (n_avail > p->n_refs) x264_frame_delete(refs[--n_avail]);
+        h->fdec = x264_frame_new(h);
+    }
+    for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
+    x264_frame_delete(h->fdec); x264_frame_delete(h->fenc);
+    x264_ratecontrol_delete(h);
+    x264_macroblock_cache_end(h);
+    x264_cqm_delete(h);
+    free(h);
+    return 0;
+}

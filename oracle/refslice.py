@@ -1,0 +1,96 @@
+"""TEST INFRASTRUCTURE -- ctypes driver for oracle/ref_slice.c (the reference's own
+cache_load / analyse / encode / cache_save loop over a chain of frames) and for the
+twin of the same sweep in liboracle.so.  Both fill the same dictionary of arrays."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# R/x264.h:190-199
+ANALYSE_I4x4, ANALYSE_I8x8, ANALYSE_PSUB16x16, ANALYSE_PSUB8x8 = 0x0001, 0x0002, 0x0010, 0x0020
+ME_DIA, ME_HEX = 0, 1
+# R/common/macroblock.h:78-102 (mb types), :55-76 (partitions)
+I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = 0, 1, 2, 3, 4, 5, 6
+SLICE_P, SLICE_B, SLICE_I = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [(k, C.c_int) for k in (
+        "width", "height", "n_frames", "qp", "me_method", "me_range", "subme", "n_refs", "inter", "intra",
+        "transform8x8", "fast_pskip", "dct_decimate", "chroma_me", "cabac", "mixed_refs",
+        "deblock", "alpha_c0", "beta", "chroma_qp_offset", "keyint")]
+
+
+def make_params(width, height, n_frames, qp=26, me_method=ME_DIA, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
+                transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, mixed_refs=0, deblock=0,
+                alpha_c0=0, beta=0, chroma_qp_offset=0, keyint=0):
+    if not transform8x8:                      # x264_validate_parameters, R/encoder/encoder.c:487-491
+        inter &= ~ANALYSE_I8x8
+        intra &= ~ANALYSE_I8x8
+    return Params(width, height, n_frames, qp, me_method, me_range, subme, n_refs, inter, intra, transform8x8,
+                  fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs, deblock, alpha_c0, beta, chroma_qp_offset, keyint)
+
+
+OUT_FIELDS = [("mb_type", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("partition", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("sub_partition", np.int8, lambda F, n, R, w, h: (F, n, 4)),
+              ("mv", np.int16, lambda F, n, R, w, h: (F, n, 16, 2)),
+              ("ref", np.int8, lambda F, n, R, w, h: (F, n, 4)),
+              ("mvr", np.int16, lambda F, n, R, w, h: (F, R, n, 2)),
+              ("nnz", np.uint8, lambda F, n, R, w, h: (F, n, 27)),
+              ("i4mode", np.int8, lambda F, n, R, w, h: (F, n, 16)),
+              ("i16mode", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("chroma_mode", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("qp", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("cbp", np.int16, lambda F, n, R, w, h: (F, n)),
+              ("t8", np.int8, lambda F, n, R, w, h: (F, n)),
+              ("luma", np.int16, lambda F, n, R, w, h: (F, n, 256)),
+              ("luma_dc", np.int16, lambda F, n, R, w, h: (F, n, 16)),
+              ("chroma_dc", np.int16, lambda F, n, R, w, h: (F, n, 8)),
+              ("chroma_ac", np.int16, lambda F, n, R, w, h: (F, n, 128)),
+              ("rec_y", np.uint8, lambda F, n, R, w, h: (F, h, w)),
+              ("rec_u", np.uint8, lambda F, n, R, w, h: (F, h // 2, w // 2)),
+              ("rec_v", np.uint8, lambda F, n, R, w, h: (F, h // 2, w // 2)),
+              ("fin_y", np.uint8, lambda F, n, R, w, h: (F, h, w)),
+              ("fin_u", np.uint8, lambda F, n, R, w, h: (F, h // 2, w // 2)),
+              ("fin_v", np.uint8, lambda F, n, R, w, h: (F, h // 2, w // 2)),
+              ("frame_info", np.int32, lambda F, n, R, w, h: (F, 4)),
+              ("stat", np.int64, lambda F, n, R, w, h: (F, 4))]
+
+
+class Out(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in OUT_FIELDS]
+
+
+def alloc_out(p):
+    mb_w, mb_h = (p.width + 15) // 16, (p.height + 15) // 16
+    arrs = {name: np.zeros(shape(p.n_frames, mb_w * mb_h, p.n_refs, 16 * mb_w, 16 * mb_h), dt) for name, dt, shape in OUT_FIELDS}
+    o = Out(**{k: v.ctypes.data for k, v in arrs.items()})
+    return arrs, o
+
+
+def clip(width, height, n_frames, t0=0):
+    from x264_vs2008_amd import synth
+    fr = [synth.frame(width, height, t0 + t) for t in range(n_frames)]
+    return tuple(np.ascontiguousarray(np.stack([f[i] for f in fr])) for i in range(3))
+
+
+def run(lib, fn, p, y, u, v):
+    arrs, o = alloc_out(p)
+    f = getattr(lib, fn)
+    f.restype = C.c_int
+    rc = f(C.byref(p), y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(o))
+    if rc != 0:
+        raise RuntimeError("%s failed: %d" % (fn, rc))
+    return arrs
+
+
+def reference_lib():
+    from oracle import hostpic
+    return hostpic.load_lazy(os.path.join(HERE, "_ref", "libx264ref.so"))
+
+
+def run_reference(p, y, u, v):
+    return run(reference_lib(), "refslice_encode_chain", p, y, u, v)

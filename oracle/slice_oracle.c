@@ -1,0 +1,996 @@
+/* slice_oracle.c -- TEST INFRASTRUCTURE; textually included at the end of frame_oracle.c (it shares
+ * that file's table instances and motion-search helpers).
+ *
+ * CPU restatement of the reference's per-macroblock hot loop over a chain of frames: what
+ * x264_slice_write does for every macroblock (R/encoder/encoder.c:1141-1291) --
+ *   x264_macroblock_cache_load   R/common/macroblock.c:872-1187  (neighbour state, predictors)
+ *   x264_macroblock_analyse      R/encoder/analyse.c:2156-2774   (I and P slices, no RD)
+ *   x264_macroblock_encode       R/encoder/macroblock.c:475-790
+ *   x264_macroblock_cache_save   R/common/macroblock.c:1208-1372
+ * followed per frame by the loop filter, border expansion and half-pel planes (the twins above).
+ * Supported: I_16x16 / I_4x4 / I_8x8 + chroma, P_SKIP (fast and early), P 16x16 over several
+ * references, 8x8 transform choice, CQP, DIA / HEX, subme 0..5.  Not yet: sub-16x16 partitions,
+ * B slices, RD, trellis, AQ.  Pinned against the reference's own functions by
+ * tests/test_oracle_slice.py (oracle/ref_slice.c runs them for the same inputs).               */
+#include <math.h>
+
+typedef struct {
+    int width, height, n_frames, qp;
+    int me_method, me_range, subme, n_refs;
+    int inter, intra;
+    int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
+    int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
+} slice_params;
+
+typedef struct {
+    int8_t *mb_type, *partition, *sub_partition;
+    i16 *mv;
+    int8_t *ref;
+    i16 *mvr;
+    u8 *nnz;
+    int8_t *i4mode, *i16mode, *chroma_mode, *qp;
+    i16 *cbp;
+    int8_t *t8;
+    i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
+    u8 *rec_y, *rec_u, *rec_v, *fin_y, *fin_u, *fin_v;
+    int32_t *frame_info;
+    int64_t *stat;
+} slice_out;
+
+/* mb types / partitions / slice types with the reference's numbering (R/common/macroblock.h:55-102, R/common/common.h:128-134) */
+enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6 };
+enum { S_D_16x16 = 16 };
+enum { S_SLICE_P = 0, S_SLICE_I = 2 };
+enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
+#define S_COST_MAX (1 << 28)
+#define S_IS_INTRA(t) ((t) >= 0 && (t) <= S_I_PCM)
+
+static const int s_lambda_tab[52] = {    /* R/encoder/analyse.c:140-149 */
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+    6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+static const int s_lambda2_tab[52] = {   /* :151-159 */
+    14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1161, 1462, 1843, 2322, 2925,
+    3686, 4644, 5851, 7372, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
+    148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436};
+static const u8 s_chroma_qp[52] = {      /* i_chroma_qp_table, R/common/macroblock.h */
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+static const u8 s_z2r[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};   /* block_idx_xy_1d */
+static const int8_t s_fix4[13] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 2, 2, 2};            /* x264_mb_pred_mode4x4_fix, index mode+1 */
+static const u8 s_fix16[7] = {0, 1, 2, 3, 2, 2, 2}, s_fix8c[7] = {0, 1, 2, 3, 0, 0, 0};
+static const u8 s_pred4_nb[12] = {NB_TOP, NB_LEFT, NB_LEFT | NB_TOP, NB_TOP | NB_TOPRIGHT, NB_LEFT | NB_TOPLEFT | NB_TOP,
+                                  NB_LEFT | NB_TOPLEFT | NB_TOP, NB_LEFT | NB_TOPLEFT | NB_TOP, NB_TOP | NB_TOPRIGHT, NB_LEFT,
+                                  NB_LEFT, NB_TOP, 0};
+static int s_ue_size(int v) { int n = 0; v++; while (v >> (n + 1)) n++; return 2 * n + 1; }   /* bs_size_ue */
+static int s_te_size(int x, int v) { return x == 1 ? 1 : x > 1 ? s_ue_size(v) : 0; }          /* bs_size_te */
+
+static x264hip_predict_t s_p16[7], s_p8c[7], s_p4[12];
+static x264hip_predict8x8_t s_p8[12];
+static x264hip_predict_8x8_filter_t s_p8filter;
+void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant);
+void x264o_predict_16x16_init(x264hip_predict_t pf[7]);
+void x264o_predict_4x4_init(x264hip_predict_t pf[12]);
+#ifdef X264O_USE_REF
+void x264_predict_16x16_init(int, x264hip_predict_t pf[7]);
+void x264_predict_4x4_init(int, x264hip_predict_t pf[12]);
+#endif
+static i16 *s_cost_mv[52];
+static void s_setup(void)
+{
+    static int done;
+    init();
+    if (done) return;
+#ifdef X264O_USE_REF
+    x264_predict_16x16_init(0, s_p16); x264_predict_8x8c_init(0, s_p8c); x264_predict_4x4_init(0, s_p4);
+    x264_predict_8x8_init(0, s_p8, &s_p8filter);
+#else
+    x264o_predict_16x16_init(s_p16); x264o_predict_8x8c_init(s_p8c); x264o_predict_4x4_init(s_p4);
+    x264o_predict_8x8_init(s_p8, &s_p8filter);
+#endif
+    done = 1;
+}
+/* p_cost_mv, x264_mb_analyse_load_costs (R/encoder/analyse.c:182-198); log2f is the reference's macro (:40) */
+static const i16 *s_load_cost_mv(int qp)
+{
+    if (!s_cost_mv[qp]) {
+        i16 *t = malloc((4 * 4 * 2048 + 1) * sizeof(i16));
+        t += 2 * 4 * 2048;
+        for (int i = 0; i <= 2 * 4 * 2048; i++)
+            t[-i] = t[i] = (i16)(s_lambda_tab[qp] * (((float)log((double)(i + 1))) / (log((double)2)) * 2 + 0.718f + !!i) + .5f);
+        s_cost_mv[qp] = t;
+    }
+    return s_cost_mv[qp];
+}
+
+typedef struct {
+    u8 *alloc[4];
+    u8 *plane[3], *filt[4];
+    int8_t *mb_type;          /* as stored by cache_save (x264_mb_type_fix applied: I_8x8 -> I_4x4) */
+    i16 *mv;                  /* [n][16][2], 4x4 blocks in raster order inside the macroblock */
+    int8_t *ref;              /* [n][4] */
+    int poc, n_ref0, ref_poc[16], inv_ref_poc[16];
+} sframe;
+
+typedef struct {
+    const slice_params *p;
+    int mb_w, mb_h, n, sy, sc, w16, h16;
+    sframe *fenc, *fdec, *fref[16];
+    int n_ref, slice_type, qp, qpc, lambda, lambda2;
+    const i16 *cost_mv;
+    int ref_cost[16];
+    u8 *nnz; int8_t *i4mode, *t8; i16 *mvr;
+    int intra_count;
+    int64_t stat_intra, stat_inter, stat_n;
+    u16 mf4[4][16], b4[4][16], mf8[2][64], b8[2][64];
+    int dq4[4][6][16], dq8[2][6][64];
+    slice_out *o;
+    int f;
+} ssl;
+
+typedef struct {
+    int mbx, mby, mb, nb, nb4[16], nb8[4];
+    int type_left, type_top, type_topleft, type_topright;
+    u8 fenc[24 * FENC], fdec[27 * FDEC];
+    u8 *fe[3], *fd[3];
+    int8_t i4c[48];                      /* intra4x4_pred_mode cache, x264_scan8 layout */
+    u8 nnz[27];
+    i16 luma4[16][16], luma8[4][64], dc16[16], cdc[2][4], cac[8][16];
+    int cbp_luma, cbp_chroma, type, t8, i16mode, chroma_mode, skip_mc;
+    int mvx, mvy, ref;                   /* the 16x16 vector */
+    i16 pskip_mv[2];
+    /* analysis */
+    int satd_i16, satd_i8, satd_i4, satd_chroma, fast_intra, pred16, pred8[4], pred4[16], predc;
+    u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
+    int i4_cbp, i8_cbp;
+} smb;
+
+static int s_scan8(int i)
+{   /* x264_scan8, R/common/common.h:196-238 */
+    if (i < 16) return 4 + 1 * 8 + (blk_x[i] >> 2) + 8 * (blk_y[i] >> 2);
+    if (i < 20) return 1 + 1 * 8 + ((i - 16) & 1) + 8 * ((i - 16) >> 1);
+    if (i < 24) return 1 + 4 * 8 + ((i - 20) & 1) + 8 * ((i - 20) >> 1);
+    return 4 + 5 * 8 + (i - 24);
+}
+
+static sframe *sframe_new(const ssl *S)
+{
+    sframe *f = calloc(1, sizeof(*f));
+    size_t ly = (size_t)S->sy * (S->h16 + 2 * 32 + 2), lc = (size_t)S->sc * (S->h16 / 2 + 2 * 32 + 2);
+    f->alloc[0] = calloc(4, ly); f->alloc[1] = calloc(1, lc); f->alloc[2] = calloc(1, lc);
+    for (int i = 0; i < 4; i++) f->filt[i] = f->alloc[0] + i * ly + 32 * S->sy + 32;
+    f->plane[0] = f->filt[0];
+    f->plane[1] = f->alloc[1] + 16 * S->sc + 16; f->plane[2] = f->alloc[2] + 16 * S->sc + 16;
+    f->mb_type = calloc(S->n, 1); f->mv = calloc(S->n * 32, sizeof(i16)); f->ref = calloc(S->n * 4, 1);
+    return f;
+}
+static void sframe_free(sframe *f)
+{
+    if (!f) return;
+    for (int i = 0; i < 3; i++) free(f->alloc[i]);
+    free(f->mb_type); free(f->mv); free(f->ref); free(f);
+}
+
+/* ------------------------------------------------------------------ neighbour motion state
+ * what x264_macroblock_cache_load puts in h->mb.cache.ref / mv around the macroblock
+ * (R/common/macroblock.c:1040-1128): -2 = not available, -1 = intra.                       */
+static int nb_ref_mv(const ssl *S, const smb *m, int which, i16 mv[2])
+{
+    int mbx = m->mbx, mby = m->mby, blk;
+    mv[0] = mv[1] = 0;
+    switch (which) {
+    case 0: if (!(m->nb & NB_LEFT)) return -2; mbx--; blk = 3; break;                 /* A: left of block 0 */
+    case 1: if (!(m->nb & NB_TOP)) return -2; mby--; blk = 12; break;                 /* B: above block 0 */
+    case 2: if (!(m->nb & NB_TOPRIGHT)) return -2; mbx++; mby--; blk = 12; break;     /* C: above-right of the macroblock */
+    default: if (!(m->nb & NB_TOPLEFT)) return -2; mbx--; mby--; blk = 15; break;     /* D: above-left */
+    }
+    int o = mby * S->mb_w + mbx;
+    mv[0] = S->fdec->mv[(o * 16 + blk) * 2]; mv[1] = S->fdec->mv[(o * 16 + blk) * 2 + 1];
+    return S->fdec->ref[o * 4 + (blk >> 3) * 2 + ((blk & 3) >> 1)];
+}
+static int s_median(int a, int b, int c) { int mx = a > b ? a : b, mn = a < b ? a : b; return c > mx ? mx : c < mn ? mn : c; }
+
+/* x264_mb_predict_mv_16x16, R/common/macroblock.c:90-128 */
+static void predict_mv_16x16(const ssl *S, const smb *m, int i_ref, i16 mvp[2])
+{
+    i16 a[2], b[2], c[2];
+    int ra = nb_ref_mv(S, m, 0, a), rb = nb_ref_mv(S, m, 1, b), rc = nb_ref_mv(S, m, 2, c), cnt;
+    if (rc == -2) rc = nb_ref_mv(S, m, 3, c);
+    cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
+    if (cnt > 1) { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
+    else if (cnt == 1) { const i16 *s = ra == i_ref ? a : rb == i_ref ? b : c; mvp[0] = s[0]; mvp[1] = s[1]; }
+    else if (rb == -2 && rc == -2 && ra != -2) { mvp[0] = a[0]; mvp[1] = a[1]; }
+    else { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
+}
+/* x264_mb_predict_mv_pskip, :131-149 */
+static void predict_mv_pskip(const ssl *S, const smb *m, i16 mv[2])
+{
+    i16 a[2], b[2];
+    int ra = nb_ref_mv(S, m, 0, a), rb = nb_ref_mv(S, m, 1, b);
+    if (ra == -2 || rb == -2 || !(ra | a[0] | a[1]) || !(rb | b[0] | b[1])) mv[0] = mv[1] = 0;
+    else predict_mv_16x16(S, m, 0, mv);
+}
+/* x264_mb_predict_mv_ref16x16, :376-437 (P slice; no lookahead vectors in this configuration) */
+static int predict_mv_ref16x16(const ssl *S, const smb *m, int i_ref, i16 mvc[8][2])
+{
+    const i16 *mvr = S->mvr + (size_t)i_ref * S->n * 2;
+    const int8_t *type = S->fdec->mb_type;
+    int i = 0, top = m->mb - S->mb_w;
+#define SET(o) do { mvc[i][0] = mvr[2 * (o)]; mvc[i][1] = mvr[2 * (o) + 1]; i++; } while (0)
+    if ((m->nb & NB_LEFT) && type[m->mb - 1] != S_P_SKIP) SET(m->mb - 1);
+    if (m->nb & NB_TOP) {
+        if (type[top] != S_P_SKIP) SET(top);
+        if ((m->nb & NB_TOPLEFT) && type[top - 1] != S_P_SKIP) SET(top - 1);
+        if (m->mbx < S->mb_w - 1 && type[top + 1] != S_P_SKIP) SET(top + 1);
+    }
+#undef SET
+    if (S->fref[0]->n_ref0 > 0) {
+        const sframe *l0 = S->fref[0];
+        for (int k = 0; k < 3; k++) {
+            int dx = k == 1, dy = k == 2;
+            if ((dx && m->mbx >= S->mb_w - 1) || (dy && m->mby >= S->mb_h - 1)) continue;
+            int o = m->mb + dx + dy * S->mb_w, ref_col = l0->ref[o * 4];
+            if (ref_col >= 0) {
+                int scale = (S->fdec->poc - S->fdec->ref_poc[i_ref]) * l0->inv_ref_poc[ref_col];
+                mvc[i][0] = (i16)((l0->mv[o * 32] * scale + 128) >> 8);
+                mvc[i][1] = (i16)((l0->mv[o * 32 + 1] * scale + 128) >> 8);
+                i++;
+            }
+        }
+    }
+    return i;
+}
+
+/* ------------------------------------------------------------------ encode pieces
+ * x264_mb_encode_i4x4 / _i8x8 / _i16x16 / _8x8_chroma, R/encoder/macroblock.c:116-363 (no trellis, not lossless) */
+static void enc_i4x4(ssl *S, smb *m, int idx)
+{
+    i16 d[4][4];
+    u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
+    dctf.sub4x4_dct(d, src, dst);
+    int nz = quantf.quant_4x4(d, S->mf4[0], S->b4[0]);
+    m->nnz[idx] = nz;
+    if (nz) {
+        m->cbp_luma |= 1 << (idx >> 2);
+        zigf[0].scan_4x4(m->luma4[idx], d);
+        quantf.dequant_4x4(d, (int (*)[4][4])S->dq4[0], S->qp);
+        dctf.add4x4_idct(dst, d);
+    }
+}
+static void enc_i8x8(ssl *S, smb *m, int idx)
+{
+    i16 d[8][8];
+    int x = 8 * (idx & 1), y = 8 * (idx >> 1);
+    u8 *src = m->fe[0] + x + y * FENC, *dst = m->fd[0] + x + y * FDEC;
+    dctf.sub8x8_dct8(d, src, dst);
+    int nz = quantf.quant_8x8(d, S->mf8[0], S->b8[0]);
+    if (nz) {
+        m->cbp_luma |= 1 << idx;
+        zigf[0].scan_8x8(m->luma8[idx], d);
+        quantf.dequant_8x8(d, (int (*)[8][8])S->dq8[0], S->qp);
+        dctf.add8x8_idct8(dst, d);
+    }
+    for (int k = 0; k < 4; k++) m->nnz[4 * idx + k] = !!nz;
+}
+static void enc_i16x16(ssl *S, smb *m)
+{
+    i16 d[16][4][4], dc[4][4];
+    int b_decimate = S->p->dct_decimate && S->slice_type == S_SLICE_P, score = b_decimate ? 0 : 9, nz;
+    dctf.sub16x16_dct(d, m->fe[0], m->fd[0]);
+    for (int i = 0; i < 16; i++) {
+        dc[0][s_z2r[i]] = d[i][0][0];
+        d[i][0][0] = 0;
+        nz = quantf.quant_4x4(d[i], S->mf4[0], S->b4[0]);
+        m->nnz[i] = nz;
+        if (nz) {
+            zigf[0].scan_4x4(m->luma4[i], d[i]);
+            quantf.dequant_4x4(d[i], (int (*)[4][4])S->dq4[0], S->qp);
+            if (score < 6) score += quantf.decimate_score15(m->luma4[i]);
+            m->cbp_luma = 0xf;
+        }
+    }
+    if (score < 6) { m->cbp_luma = 0; memset(m->nnz, 0, 16); }
+    dctf.dct4x4dc(dc);
+    nz = quantf.quant_4x4_dc(dc, S->mf4[0][0] >> 1, S->b4[0][0] << 1);
+    m->nnz[24] = nz;
+    if (nz) {
+        zigf[0].scan_4x4(m->dc16, dc);
+        dctf.idct4x4dc(dc);
+        quantf.dequant_4x4_dc(dc, (int (*)[4][4])S->dq4[0], S->qp);
+        if (m->cbp_luma)
+            for (int i = 0; i < 16; i++) d[i][0][0] = dc[0][s_z2r[i]];
+    }
+    if (m->cbp_luma) dctf.add16x16_idct(m->fd[0], d);
+    else if (nz) dctf.add16x16_idct_dc(m->fd[0], dc);
+}
+static void enc_chroma(ssl *S, smb *m, int b_inter)
+{
+    int cat = 2 + b_inter, qpc = S->qpc, b_decimate = b_inter && S->p->dct_decimate;
+    int (*dq)[4][4] = (int (*)[4][4])S->dq4[cat];
+    m->cbp_chroma = 0;
+    for (int ch = 0; ch < 2; ch++) {
+        u8 *ps = m->fe[1 + ch], *pd = m->fd[1 + ch];
+        i16 d4[4][4][4], d2[2][2];
+        int score = 0, nz_ac = 0;
+        dctf.sub8x8_dct(d4, ps, pd);
+        {   /* dct2x2dc, :73-85 */
+            int a = d4[0][0][0] + d4[1][0][0], b = d4[2][0][0] + d4[3][0][0];
+            int c = d4[0][0][0] - d4[1][0][0], d = d4[2][0][0] - d4[3][0][0];
+            d2[0][0] = a + b; d2[1][0] = c + d; d2[0][1] = a - b; d2[1][1] = c - d;
+            d4[0][0][0] = d4[1][0][0] = d4[2][0][0] = d4[3][0][0] = 0;
+        }
+        for (int i = 0; i < 4; i++) {
+            int nz = quantf.quant_4x4(d4[i], S->mf4[cat], S->b4[cat]);
+            m->nnz[16 + 4 * ch + i] = nz;
+            if (nz) {
+                nz_ac = 1;
+                zigf[0].scan_4x4(m->cac[4 * ch + i], d4[i]);
+                quantf.dequant_4x4(d4[i], dq, qpc);
+                if (b_decimate) score += quantf.decimate_score15(m->cac[4 * ch + i]);
+            }
+        }
+        int nz_dc = quantf.quant_2x2_dc(d2, S->mf4[cat][0] >> 1, S->b4[cat][0] << 1);
+        m->nnz[25 + ch] = nz_dc;
+        /* IDCT_DEQUANT_START, :40-51 */
+        int e0 = d2[0][0] + d2[0][1], e1 = d2[1][0] + d2[1][1], e2 = d2[0][0] - d2[0][1], e3 = d2[1][0] - d2[1][1];
+        int dmf = dq[qpc % 6][0][0], qbits = qpc / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        if ((b_decimate && score < 7) || !nz_ac) {
+            memset(m->nnz + 16 + 4 * ch, 0, 4);
+            if (!nz_dc) continue;
+            m->cdc[ch][0] = d2[0][0]; m->cdc[ch][1] = d2[1][0]; m->cdc[ch][2] = d2[0][1]; m->cdc[ch][3] = d2[1][1];
+            i16 dd[2][2];
+            dd[0][0] = (e0 + e1) * dmf >> -qbits; dd[0][1] = (e0 - e1) * dmf >> -qbits;
+            dd[1][0] = (e2 + e3) * dmf >> -qbits; dd[1][1] = (e2 - e3) * dmf >> -qbits;
+            dctf.add8x8_idct_dc(pd, dd);
+        } else {
+            m->cbp_chroma = 1;
+            if (nz_dc) {
+                m->cdc[ch][0] = d2[0][0]; m->cdc[ch][1] = d2[1][0]; m->cdc[ch][2] = d2[0][1]; m->cdc[ch][3] = d2[1][1];
+                d4[0][0][0] = (e0 + e1) * dmf >> -qbits; d4[1][0][0] = (e0 - e1) * dmf >> -qbits;
+                d4[2][0][0] = (e2 + e3) * dmf >> -qbits; d4[3][0][0] = (e2 - e3) * dmf >> -qbits;
+            }
+            dctf.add8x8_idct(pd, d4);
+        }
+    }
+    if (m->cbp_chroma) m->cbp_chroma = 2;
+    else if (m->nnz[25] | m->nnz[26]) m->cbp_chroma = 1;
+}
+/* inter luma, R/encoder/macroblock.c:596-768 */
+static void enc_inter_luma(ssl *S, smb *m)
+{
+    int b_decimate = S->p->dct_decimate, decimate_mb = 0;
+    if (m->t8) {
+        i16 d8[4][8][8];
+        dctf.sub16x16_dct8(d8, m->fe[0], m->fd[0]);
+        for (int idx = 0; idx < 4; idx++) {
+            int nz = quantf.quant_8x8(d8[idx], S->mf8[1], S->b8[1]);
+            if (nz) {
+                zigf[0].scan_8x8(m->luma8[idx], d8[idx]);
+                if (b_decimate) {
+                    int s = quantf.decimate_score64(m->luma8[idx]);
+                    decimate_mb += s;
+                    if (s >= 4) m->cbp_luma |= 1 << idx;
+                } else
+                    m->cbp_luma |= 1 << idx;
+            }
+        }
+        if (decimate_mb < 6 && b_decimate) { m->cbp_luma = 0; memset(m->nnz, 0, 16); }
+        else
+            for (int idx = 0; idx < 4; idx++) {
+                int on = m->cbp_luma >> idx & 1;
+                if (on) {
+                    quantf.dequant_8x8(d8[idx], (int (*)[8][8])S->dq8[1], S->qp);
+                    dctf.add8x8_idct8(m->fd[0] + (idx & 1) * 8 + (idx >> 1) * 8 * FDEC, d8[idx]);
+                }
+                for (int k = 0; k < 4; k++) m->nnz[4 * idx + k] = on;
+            }
+    } else {
+        i16 d4[16][4][4];
+        dctf.sub16x16_dct(d4, m->fe[0], m->fd[0]);
+        for (int i8 = 0; i8 < 4; i8++) {
+            int dec8 = 0, cbp = 0;
+            for (int i4 = 0; i4 < 4; i4++) {
+                int idx = 4 * i8 + i4, nz = quantf.quant_4x4(d4[idx], S->mf4[1], S->b4[1]);
+                m->nnz[idx] = nz;
+                if (nz) {
+                    zigf[0].scan_4x4(m->luma4[idx], d4[idx]);
+                    quantf.dequant_4x4(d4[idx], (int (*)[4][4])S->dq4[1], S->qp);
+                    if (b_decimate && dec8 < 6) dec8 += quantf.decimate_score16(m->luma4[idx]);
+                    cbp = 1;
+                }
+            }
+            decimate_mb += dec8;
+            if (b_decimate) {
+                if (dec8 < 4) memset(m->nnz + 4 * i8, 0, 4);
+                else m->cbp_luma |= 1 << i8;
+            } else if (cbp) {
+                dctf.add8x8_idct(m->fd[0] + (i8 & 1) * 8 + (i8 >> 1) * 8 * FDEC, &d4[4 * i8]);
+                m->cbp_luma |= 1 << i8;
+            }
+        }
+        if (b_decimate) {
+            if (decimate_mb < 6) { m->cbp_luma = 0; memset(m->nnz, 0, 16); }
+            else
+                for (int i8 = 0; i8 < 4; i8++)
+                    if (m->cbp_luma >> i8 & 1) dctf.add8x8_idct(m->fd[0] + (i8 & 1) * 8 + (i8 >> 1) * 8 * FDEC, &d4[4 * i8]);
+        }
+    }
+}
+/* x264_mb_mc for one 16x16 vector (R/common/macroblock.c:462-476), into fdec */
+static void mc_16x16(const ssl *S, smb *m, int ref, int mvx, int mvy)
+{
+    const sframe *r = S->fref[ref];
+    int oy = 16 * m->mby * S->sy + 16 * m->mbx, oc = 8 * m->mby * S->sc + 8 * m->mbx;
+    u8 *src4[4] = {r->filt[0] + oy, r->filt[1] + oy, r->filt[2] + oy, r->filt[3] + oy};
+    mcf.mc_luma(m->fd[0], FDEC, src4, S->sy, mvx, mvy, 16, 16);
+    mcf.mc_chroma(m->fd[1], FDEC, r->plane[1] + oc, S->sc, mvx, mvy, 8, 8);
+    mcf.mc_chroma(m->fd[2], FDEC, r->plane[2] + oc, S->sc, mvx, mvy, 8, 8);
+}
+static void mv_clip_frame(const ssl *S, const smb *m, int *mvx, int *mvy)
+{   /* h->mb.mv_min / mv_max, R/encoder/analyse.c:258-259,290-291 */
+    *mvx = clip3i(*mvx, 4 * (-16 * m->mbx - 24), 4 * (16 * (S->mb_w - m->mbx - 1) + 24));
+    *mvy = clip3i(*mvy, 4 * (-16 * m->mby - 24), 4 * (16 * (S->mb_h - m->mby - 1) + 24));
+}
+/* x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883) */
+static int probe_pskip(ssl *S, smb *m)
+{
+    int mvx = m->pskip_mv[0], mvy = m->pskip_mv[1], dec = 0;
+    const sframe *r = S->fref[0];
+    int oy = 16 * m->mby * S->sy + 16 * m->mbx, oc = 8 * m->mby * S->sc + 8 * m->mbx;
+    i16 d4[4][4][4], d2[2][2], scan[16];
+    mv_clip_frame(S, m, &mvx, &mvy);
+    u8 *src4[4] = {r->filt[0] + oy, r->filt[1] + oy, r->filt[2] + oy, r->filt[3] + oy};
+    mcf.mc_luma(m->fd[0], FDEC, src4, S->sy, mvx, mvy, 16, 16);
+    for (int i8 = 0; i8 < 4; i8++) {
+        dctf.sub8x8_dct(d4, m->fe[0] + (i8 & 1) * 8 + (i8 >> 1) * 8 * FENC, m->fd[0] + (i8 & 1) * 8 + (i8 >> 1) * 8 * FDEC);
+        for (int i4 = 0; i4 < 4; i4++) {
+            if (!quantf.quant_4x4(d4[i4], S->mf4[1], S->b4[1])) continue;
+            zigf[0].scan_4x4(scan, d4[i4]);
+            dec += quantf.decimate_score16(scan);
+            if (dec >= 6) return 0;
+        }
+    }
+    int thresh = (s_lambda2_tab[S->qpc] + 32) >> 6;
+    for (int ch = 0; ch < 2; ch++) {
+        mcf.mc_chroma(m->fd[1 + ch], FDEC, r->plane[1 + ch] + oc, S->sc, mvx, mvy, 8, 8);
+        if (pixf.ssd[X264HIP_PIXEL_8x8](m->fd[1 + ch], FDEC, m->fe[1 + ch], FENC) < thresh) continue;
+        dctf.sub8x8_dct(d4, m->fe[1 + ch], m->fd[1 + ch]);
+        int a = d4[0][0][0] + d4[1][0][0], b = d4[2][0][0] + d4[3][0][0];
+        int c = d4[0][0][0] - d4[1][0][0], d = d4[2][0][0] - d4[3][0][0];
+        d2[0][0] = a + b; d2[1][0] = c + d; d2[0][1] = a - b; d2[1][1] = c - d;
+        d4[0][0][0] = d4[1][0][0] = d4[2][0][0] = d4[3][0][0] = 0;
+        if (quantf.quant_2x2_dc(d2, S->mf4[3][0] >> 1, S->b4[3][0] << 1)) return 0;
+        dec = 0;
+        for (int i4 = 0; i4 < 4; i4++) {
+            if (!quantf.quant_4x4(d4[i4], S->mf4[3], S->b4[3])) continue;
+            zigf[0].scan_4x4(scan, d4[i4]);
+            dec += quantf.decimate_score15(scan);
+            if (dec >= 7) return 0;
+        }
+    }
+    m->skip_mc = 1;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ intra analysis
+ * predict_*_mode_available, R/encoder/analyse.c:374-471 */
+static int modes_16x16(int nb, int *mode)
+{
+    if (nb & NB_TOPLEFT) { mode[0] = 0; mode[1] = 1; mode[2] = 2; mode[3] = 3; return 4; }
+    if (nb & NB_LEFT) { mode[0] = 4; mode[1] = 1; return 2; }
+    if (nb & NB_TOP) { mode[0] = 5; mode[1] = 0; return 2; }
+    mode[0] = 6; return 1;
+}
+static int modes_chroma(int nb, int *mode)
+{
+    if (nb & NB_TOPLEFT) { mode[0] = 2; mode[1] = 1; mode[2] = 0; mode[3] = 3; return 4; }
+    if (nb & NB_LEFT) { mode[0] = 4; mode[1] = 1; return 2; }
+    if (nb & NB_TOP) { mode[0] = 5; mode[1] = 2; return 2; }
+    mode[0] = 6; return 1;
+}
+static int modes_4x4(int nb, int *mode)
+{
+    int n = 0;
+    if ((nb & NB_LEFT) && (nb & NB_TOP)) {
+        mode[n++] = 2; mode[n++] = 1; mode[n++] = 0; mode[n++] = 3;
+        if (nb & NB_TOPLEFT) { mode[n++] = 4; mode[n++] = 5; mode[n++] = 6; }
+        mode[n++] = 7; mode[n++] = 8;
+    } else if (nb & NB_LEFT) { mode[n++] = 9; mode[n++] = 1; mode[n++] = 8; }
+    else if (nb & NB_TOP) { mode[n++] = 10; mode[n++] = 0; mode[n++] = 3; mode[n++] = 7; }
+    else mode[n++] = 11;
+    return n;
+}
+static int pred_intra4x4_mode(const smb *m, int idx)
+{   /* x264_mb_predict_intra4x4_mode, R/common/macroblock.h:423-434 */
+    int ma = s_fix4[m->i4c[s_scan8(idx) - 1] + 1], mb = s_fix4[m->i4c[s_scan8(idx) - 8] + 1], v = ma < mb ? ma : mb;
+    return v < 0 ? 2 : v;
+}
+/* x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610 */
+static void analyse_intra_chroma(ssl *S, smb *m)
+{
+    int mode[4], n, satd = S->p->subme > 1;
+    if (m->satd_chroma < S_COST_MAX) return;
+    n = modes_chroma(m->nb, mode);
+    for (int i = 0; i < n; i++) {
+        s_p8c[mode[i]](m->fd[1]); s_p8c[mode[i]](m->fd[2]);
+        int c = (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[1], FDEC, m->fe[1], FENC)
+              + (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[2], FDEC, m->fe[2], FENC)
+              + S->lambda * s_ue_size(s_fix8c[mode[i]]);
+        if (c < m->satd_chroma) { m->satd_chroma = c; m->predc = mode[i]; }
+    }
+    m->chroma_mode = m->predc;
+}
+/* x264_mb_analyse_intra, :612-843 */
+static void analyse_intra(ssl *S, smb *m, int satd_inter)
+{
+    const int flags = S->slice_type == S_SLICE_I ? S->p->intra : S->p->inter, satd = S->p->subme > 1;
+    x264hip_pixel_cmp_t *cmp = satd ? pixf.satd : pixf.sad;
+    int mode[9], n;
+    n = modes_16x16(m->nb, mode);
+    for (int i = 0; i < n; i++) {
+        s_p16[mode[i]](m->fd[0]);
+        int c = cmp[X264HIP_PIXEL_16x16](m->fd[0], FDEC, m->fe[0], FENC) + S->lambda * s_ue_size(s_fix16[mode[i]]);
+        if (c < m->satd_i16) { m->satd_i16 = c; m->pred16 = mode[i]; }
+    }
+    if (m->fast_intra && m->satd_i16 > 2 * satd_inter) return;
+
+    if (flags & 2) {                                           /* X264_ANALYSE_I8x8 */
+        u8 edge[40];
+        x264hip_pixel_cmp_t sa8d = satd ? pixf.sa8d[X264HIP_PIXEL_8x8] : pixf.sad[X264HIP_PIXEL_8x8];
+        int thresh = satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = 0, idx;
+        m->cbp_luma = 0;
+        for (idx = 0;; idx++) {
+            int x = idx & 1, y = idx >> 1, best = S_COST_MAX, pm = pred_intra4x4_mode(m, 4 * idx);
+            u8 *src = m->fe[0] + 8 * x + 8 * y * FENC, *dst = m->fd[0] + 8 * x + 8 * y * FDEC;
+            n = modes_4x4(m->nb8[idx], mode);
+            s_p8filter(dst, edge, m->nb8[idx], 0xf);
+            for (int i = 0; i < n; i++) {
+                s_p8[mode[i]](dst, edge);
+                int c = sa8d(dst, FDEC, src, FENC) + S->lambda * (pm == s_fix4[mode[i] + 1] ? 1 : 4);
+                if (c < best) { best = c; m->pred8[idx] = mode[i]; }
+            }
+            cost += best;
+            if (idx == 3 || cost > thresh) break;
+            s_p8[m->pred8[idx]](dst, edge);
+            enc_i8x8(S, m, idx);
+            for (int k = 0; k < 4; k++) m->i4c[s_scan8(4 * idx) + (k & 1) + 8 * (k >> 1)] = m->pred8[idx];
+        }
+        if (idx == 3) {
+            m->satd_i8 = cost;
+            for (int r = 0; r < 16; r++) memcpy(m->i8_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
+            memcpy(m->i8_nnz, m->nnz, 16); m->i8_cbp = m->cbp_luma;
+        } else {
+            static const u16 div8[3] = {1024, 512, 341};
+            m->satd_i8 = S_COST_MAX;
+            cost = (cost * div8[idx]) >> 8;
+        }
+        if ((cost < m->satd_i16 ? cost : m->satd_i16) > satd_inter * 5 / 4) return;
+    }
+    if (flags & 1) {                                           /* X264_ANALYSE_I4x4 */
+        int thresh = satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = S->lambda * 24, idx;
+        if (m->satd_i8 < thresh) thresh = m->satd_i8;
+        m->cbp_luma = 0;
+        for (idx = 0;; idx++) {
+            u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
+            int best = S_COST_MAX, pm = pred_intra4x4_mode(m, idx);
+            n = modes_4x4(m->nb4[idx], mode);
+            if ((m->nb4[idx] & (NB_TOPRIGHT | NB_TOP)) == NB_TOP) memset(dst + 4 - FDEC, dst[3 - FDEC], 4);
+            for (int i = 0; i < n; i++) {
+                s_p4[mode[i]](dst);
+                int c = cmp[X264HIP_PIXEL_4x4](dst, FDEC, src, FENC) + S->lambda * (pm == s_fix4[mode[i] + 1] ? 1 : 4);
+                if (c < best) { best = c; m->pred4[idx] = mode[i]; }
+            }
+            cost += best;
+            if (cost > thresh || idx == 15) break;
+            s_p4[m->pred4[idx]](dst);
+            enc_i4x4(S, m, idx);
+            m->i4c[s_scan8(idx)] = m->pred4[idx];
+        }
+        if (idx == 15) {
+            m->satd_i4 = cost;
+            for (int r = 0; r < 16; r++) memcpy(m->i4_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
+            memcpy(m->i4_nnz, m->nnz, 16); m->i4_cbp = m->cbp_luma;
+        } else
+            m->satd_i4 = S_COST_MAX;
+    }
+}
+
+/* ------------------------------------------------------------------ one macroblock */
+static void load_mb(ssl *S, smb *m, int mbx, int mby)
+{
+    const u8 *src[3] = {S->fenc->plane[0], S->fenc->plane[1], S->fenc->plane[2]};
+    memset(m, 0, sizeof(*m));
+    m->mbx = mbx; m->mby = mby; m->mb = mby * S->mb_w + mbx;
+    m->fe[0] = m->fenc; m->fe[1] = m->fenc + 16 * FENC; m->fe[2] = m->fenc + 16 * FENC + 8;
+    m->fd[0] = m->fdec + 2 * FDEC; m->fd[1] = m->fdec + 19 * FDEC; m->fd[2] = m->fdec + 19 * FDEC + 16;
+    m->type_left = m->type_top = m->type_topleft = m->type_topright = -1;
+    if (mby > 0) { m->nb |= NB_TOP; m->type_top = S->fdec->mb_type[m->mb - S->mb_w]; }
+    if (mbx > 0) { m->nb |= NB_LEFT; m->type_left = S->fdec->mb_type[m->mb - 1]; }
+    if (mbx < S->mb_w - 1 && mby > 0) { m->nb |= NB_TOPRIGHT; m->type_topright = S->fdec->mb_type[m->mb - S->mb_w + 1]; }
+    if (mbx > 0 && mby > 0) { m->nb |= NB_TOPLEFT; m->type_topleft = S->fdec->mb_type[m->mb - S->mb_w - 1]; }
+    for (int pl = 0; pl < 3; pl++) {
+        int w = pl ? 8 : 16, st = pl ? S->sc : S->sy, o = w * mby * st + w * mbx;
+        const u8 *rec = S->fdec->plane[pl] + o;
+        for (int y = 0; y < w; y++) memcpy(m->fe[pl] + y * FENC, src[pl] + o + y * st, w);
+        /* reconstructed neighbours, still unfiltered: the row above (x = -1 .. w*3/2-1) and the column to the left */
+        if (mby > 0) memcpy(m->fd[pl] - FDEC - 1, rec - st - 1, w * 3 / 2 + 1);
+        if (mbx > 0) for (int y = 0; y < w; y++) m->fd[pl][y * FDEC - 1] = rec[y * st - 1];
+    }
+    /* intra4x4_pred_mode cache: -1 where there is no neighbour, DC for anything that is not I_4x4 / I_8x8 */
+    memset(m->i4c, -1, sizeof(m->i4c));
+    if (m->nb & NB_TOP) {
+        const int8_t *t = S->i4mode + (m->mb - S->mb_w) * 16;
+        m->i4c[s_scan8(0) - 8] = t[10]; m->i4c[s_scan8(1) - 8] = t[11]; m->i4c[s_scan8(4) - 8] = t[14]; m->i4c[s_scan8(5) - 8] = t[15];
+    }
+    if (m->nb & NB_LEFT) {
+        const int8_t *l = S->i4mode + (m->mb - 1) * 16;
+        m->i4c[s_scan8(0) - 1] = l[5]; m->i4c[s_scan8(2) - 1] = l[7]; m->i4c[s_scan8(8) - 1] = l[13]; m->i4c[s_scan8(10) - 1] = l[15];
+    }
+    /* i_neighbour4 / i_neighbour8, R/common/macroblock.c:733-743,1172-1186 */
+    int nb = m->nb, all = NB_LEFT | NB_TOP | NB_TOPLEFT | NB_TOPRIGHT;
+    m->nb4[0] = m->nb8[0] = (nb & (NB_TOP | NB_LEFT | NB_TOPLEFT)) | ((nb & NB_TOP) ? NB_TOPRIGHT : 0);
+    m->nb4[4] = m->nb4[1] = NB_LEFT | ((nb & NB_TOP) ? (NB_TOP | NB_TOPLEFT | NB_TOPRIGHT) : 0);
+    m->nb4[2] = m->nb4[8] = m->nb4[10] = m->nb8[2] = NB_TOP | NB_TOPRIGHT | ((nb & NB_LEFT) ? (NB_LEFT | NB_TOPLEFT) : 0);
+    m->nb4[5] = m->nb8[1] = NB_LEFT | (nb & NB_TOPRIGHT) | ((nb & NB_TOP) ? NB_TOP | NB_TOPLEFT : 0);
+    m->nb4[6] = m->nb4[9] = m->nb4[12] = m->nb4[14] = all;
+    m->nb4[3] = m->nb4[7] = m->nb4[11] = m->nb4[13] = m->nb4[15] = m->nb8[3] = NB_LEFT | NB_TOP | NB_TOPLEFT;
+    m->satd_i16 = m->satd_i8 = m->satd_i4 = m->satd_chroma = S_COST_MAX;
+    if (S->slice_type == S_SLICE_P) predict_mv_pskip(S, m, m->pskip_mv);
+}
+
+static void set_me_ctx(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c)
+{
+    int oy = 16 * m->mby * S->sy + 16 * m->mbx, oc = 8 * m->mby * S->sc + 8 * m->mbx, sp[4], fp[4];
+    const sframe *r = S->fref[ref];
+    mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, 512, sp, fp);
+    c->fenc = S->fenc->plane[0] + oy; c->fenc_u = S->fenc->plane[1] + oc; c->fenc_v = S->fenc->plane[2] + oc;
+    c->sy = S->sy; c->sc = S->sc;
+    for (int k = 0; k < 4; k++) c->fref[k] = r->filt[k] + oy;
+    c->fref[4] = r->plane[1] + oc; c->fref[5] = r->plane[2] + oc;
+    c->cmx = S->cost_mv - mvp[0]; c->cmy = S->cost_mv - mvp[1];
+    c->fmin[0] = fp[0]; c->fmax[0] = fp[1]; c->fmin[1] = fp[2]; c->fmax[1] = fp[3];
+    c->smin[0] = sp[0]; c->smax[0] = sp[1]; c->smin[1] = sp[2]; c->smax[1] = sp[3];
+}
+/* x264_me_refine_qpel -> refine_subpel(.., b_refine_qpel = 1), R/encoder/me.c:634-778, 16x16 */
+static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
+{
+    int subme = S->p->subme, hpel = me_subpel_iters[subme][0], qpel = me_subpel_iters[subme][1];
+    int satd = subme > 1, chroma_me = S->p->chroma_me && subme >= 5;
+    int bx = *pmx, by = *pmy, bc = cost, i, cst;
+    if (hpel && subme < 3) {
+        int mx = clip3i(mvp[0], c->smin[0], c->smax[0]), my = clip3i(mvp[1], c->smin[1], c->smax[1]);
+        if ((mx - bx) | (my - by)) { cst = me_qpel_cmp(c, mx, my, 0); if (cst < bc) { bc = cst; bx = mx; by = my; } }
+    }
+    for (i = hpel; i > 0; i--) {
+        int ox = bx, oy = by, c0 = me_qpel_cmp(c, ox, oy - 2, 0), c1 = me_qpel_cmp(c, ox, oy + 2, 0);
+        int c2 = me_qpel_cmp(c, ox - 2, oy, 0), c3 = me_qpel_cmp(c, ox + 2, oy, 0);
+        if (c0 < bc) { bc = c0; by = oy - 2; }
+        if (c1 < bc) { bc = c1; by = oy + 2; }
+        if (c2 < bc) { bc = c2; bx = ox - 2; by = oy; }
+        if (c3 < bc) { bc = c3; bx = ox + 2; by = oy; }
+        if (bx == ox && by == oy) break;
+    }
+    for (i = qpel; i > 0; i--) {
+        static const int dq[4][2] = {{0, -1}, {0, 1}, {-1, 0}, {1, 0}};
+        int ox = bx, oy = by;
+        for (int d = 0; d < 4; d++) {
+            cst = me_satd_chroma(c, ox + dq[d][0], oy + dq[d][1], bc, chroma_me, satd);
+            if (cst < bc) { bc = cst; bx = ox + dq[d][0]; by = oy + dq[d][1]; }
+        }
+        if (bx == ox && by == oy) break;
+    }
+    if (by > c->smax[1]) {
+        by = c->smax[1]; bc = S_COST_MAX;
+        cst = me_satd_chroma(c, bx, by, bc, chroma_me, satd);
+        if (cst < bc) bc = cst;
+    }
+    *pmx = bx; *pmy = by;
+    return bc;
+}
+
+static void analyse_mb(ssl *S, smb *m)
+{
+    const slice_params *p = S->p;
+    int i_cost = S_COST_MAX;
+    m->skip_mc = 0; m->t8 = 0;
+    /* x264_mb_analyse_init's fast-intra decision, R/encoder/analyse.c:345-362 */
+    if (S->slice_type == S_SLICE_P && m->mb > 4) {
+        int likely = S_IS_INTRA(m->type_left) || S_IS_INTRA(m->type_top) || S_IS_INTRA(m->type_topleft) || S_IS_INTRA(m->type_topright)
+                  || S_IS_INTRA(S->fref[0]->mb_type[m->mb]) || m->mb < 3 * S->intra_count;
+        m->fast_intra = !likely;
+    }
+    if (S->slice_type == S_SLICE_I) {
+        analyse_intra(S, m, S_COST_MAX);
+        i_cost = m->satd_i16; m->type = S_I_16x16;
+        if (m->satd_i4 < i_cost) { i_cost = m->satd_i4; m->type = S_I_4x4; }
+        if (m->satd_i8 < i_cost) { i_cost = m->satd_i8; m->type = S_I_8x8; }
+    } else {
+        int b_skip = 0, try_pskip = 0;
+        if (p->fast_pskip) {
+            if (p->subme >= 3) try_pskip = 1;
+            else if (m->type_left == S_P_SKIP || m->type_top == S_P_SKIP || m->type_topleft == S_P_SKIP || m->type_topright == S_P_SKIP)
+                b_skip = probe_pskip(S, m);
+        }
+        if (b_skip) m->type = S_P_SKIP;
+        else {
+            /* x264_mb_analyse_inter_p16x16, :1077-1143 */
+            int thresh = 0x7fffffff, best = 0x7fffffff, bmx = 0, bmy = 0, bref = 0, chroma_me = p->chroma_me && p->subme >= 5;
+            i16 bmvp[2] = {0, 0};
+            for (int r = 0; r < S->n_ref; r++) {
+                i16 mvp[2], mvc[8][2];
+                me_ctx c;
+                int mvx, mvy, cost, cost_mv = 0, n_mvc;
+                predict_mv_16x16(S, m, r, mvp);
+                n_mvc = predict_mv_ref16x16(S, m, r, mvc);
+                set_me_ctx(S, m, r, mvp, &c);
+                thresh -= S->ref_cost[r];
+                cost = me_search16(&c, mvp, (const i16 (*)[2])mvc, n_mvc, p->me_method, p->me_range, p->subme, chroma_me,
+                                   S->n_ref > 1 ? &thresh : 0, &mvx, &mvy, &cost_mv);
+                if (r == 0 && try_pskip && cost - cost_mv < 300 * S->lambda
+                    && abs(mvx - m->pskip_mv[0]) + abs(mvy - m->pskip_mv[1]) <= 1 && probe_pskip(S, m)) {
+                    m->type = S_P_SKIP;
+                    return;
+                }
+                cost += S->ref_cost[r];
+                thresh += S->ref_cost[r];
+                if (cost < best) { best = cost; bmx = mvx; bmy = mvy; bref = r; bmvp[0] = mvp[0]; bmvp[1] = mvp[1]; }
+                S->mvr[((size_t)r * S->n + m->mb) * 2] = mvx; S->mvr[((size_t)r * S->n + m->mb) * 2 + 1] = mvy;
+            }
+            m->type = S_P_L0;
+            /* x264_me_refine_qpel on the winner (:2289-2294; the reference cost leaves the sum, me.c:639-640) */
+            {
+                me_ctx c;
+                set_me_ctx(S, m, bref, bmvp, &c);
+                best -= S->ref_cost[bref];
+                best = refine_qpel16(S, &c, best, &bmx, &bmy, bmvp);
+            }
+            m->mvx = bmx; m->mvy = bmy; m->ref = bref;
+            i_cost = best;
+            if (chroma_me) {
+                analyse_intra_chroma(S, m);
+                analyse_intra(S, m, i_cost - m->satd_chroma);
+                m->satd_i16 += m->satd_chroma; m->satd_i8 += m->satd_chroma; m->satd_i4 += m->satd_chroma;
+            } else
+                analyse_intra(S, m, i_cost);
+            int satd_inter = i_cost, satd_intra = m->satd_i16 < m->satd_i8 ? m->satd_i16 : m->satd_i8;
+            if (m->satd_i4 < satd_intra) satd_intra = m->satd_i4;
+            int itype = S_I_16x16, icost = m->satd_i16;
+            if (m->satd_i8 < icost) { icost = m->satd_i8; itype = S_I_8x8; }
+            if (m->satd_i4 < icost) { icost = m->satd_i4; itype = S_I_4x4; }
+            if (icost < i_cost) { i_cost = icost; m->type = itype; }
+            if (icost == S_COST_MAX) icost = i_cost * satd_intra / satd_inter + 1;
+            S->stat_intra += icost; S->stat_inter += i_cost; S->stat_n++;
+        }
+    }
+}
+
+/* x264_analyse_update_cache + x264_mb_analyse_transform (non-RD), R/encoder/analyse.c:2109-2126,2777-2826 */
+static void update_mb(ssl *S, smb *m)
+{
+    switch (m->type) {
+    case S_I_4x4:
+        for (int i = 0; i < 16; i++) m->i4c[s_scan8(i)] = m->pred4[i];
+        analyse_intra_chroma(S, m);
+        break;
+    case S_I_8x8:
+        for (int i = 0; i < 16; i++) m->i4c[s_scan8(i)] = m->pred8[i >> 2];
+        analyse_intra_chroma(S, m);
+        break;
+    case S_I_16x16:
+        m->i16mode = m->pred16;
+        analyse_intra_chroma(S, m);
+        break;
+    case S_P_SKIP:
+        m->mvx = m->pskip_mv[0]; m->mvy = m->pskip_mv[1]; m->ref = 0;
+        break;
+    default:
+        break;
+    }
+    if (m->type == S_P_L0 && S->p->transform8x8) {
+        mc_16x16(S, m, m->ref, m->mvx, m->mvy);
+        int c8 = pixf.sa8d[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
+        int c4 = pixf.satd[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
+        m->t8 = c8 < c4;
+        m->skip_mc = 1;
+    }
+}
+
+/* x264_macroblock_encode, R/encoder/macroblock.c:475-790 */
+static void encode_mb(ssl *S, smb *m)
+{
+    m->cbp_luma = 0; m->nnz[24] = 0;
+    if (m->type == S_P_SKIP) {
+        if (!m->skip_mc) {
+            int mvx = m->mvx, mvy = m->mvy;
+            mv_clip_frame(S, m, &mvx, &mvy);
+            mc_16x16(S, m, 0, mvx, mvy);
+        }
+        m->cbp_luma = m->cbp_chroma = 0;
+        memset(m->nnz, 0, sizeof(m->nnz));
+        return;
+    }
+    if (m->type == S_I_16x16) {
+        m->t8 = 0;
+        s_p16[m->i16mode](m->fd[0]);
+        enc_i16x16(S, m);
+    } else if (m->type == S_I_8x8) {
+        u8 edge[40];
+        m->t8 = 1;
+        for (int r = 0; r < 16; r++) memcpy(m->fd[0] + r * FDEC, m->i8_fdec + 16 * r, 16);
+        memcpy(m->nnz, m->i8_nnz, 16); m->cbp_luma = m->i8_cbp;
+        {
+            u8 *dst = m->fd[0] + 8 + 8 * FDEC;
+            int mode = m->i4c[s_scan8(12)];
+            s_p8filter(dst, edge, m->nb8[3], s_pred4_nb[mode]);
+            s_p8[mode](dst, edge);
+            enc_i8x8(S, m, 3);
+        }
+    } else if (m->type == S_I_4x4) {
+        m->t8 = 0;
+        for (int r = 0; r < 16; r++) memcpy(m->fd[0] + r * FDEC, m->i4_fdec + 16 * r, 16);
+        memcpy(m->nnz, m->i4_nnz, 16); m->cbp_luma = m->i4_cbp;
+        {
+            u8 *dst = m->fd[0] + 12 + 12 * FDEC;
+            if ((m->nb4[15] & (NB_TOPRIGHT | NB_TOP)) == NB_TOP) memset(dst + 4 - FDEC, dst[3 - FDEC], 4);
+            s_p4[m->i4c[s_scan8(15)]](dst);
+            enc_i4x4(S, m, 15);
+        }
+    } else {
+        if (!m->skip_mc) mc_16x16(S, m, m->ref, m->mvx, m->mvy);
+        enc_inter_luma(S, m);
+    }
+    if (S_IS_INTRA(m->type)) { s_p8c[m->chroma_mode](m->fd[1]); s_p8c[m->chroma_mode](m->fd[2]); }
+    enc_chroma(S, m, !S_IS_INTRA(m->type));
+    if (m->type == S_P_L0 && !(m->cbp_luma | m->cbp_chroma) && m->mvx == m->pskip_mv[0] && m->mvy == m->pskip_mv[1] && m->ref == 0)
+        m->type = S_P_SKIP;
+}
+
+/* x264_macroblock_cache_save (+ the copy-out the golden harness compares) */
+static void save_mb(ssl *S, smb *m)
+{
+    slice_out *o = S->o;
+    size_t M = (size_t)S->f * S->n + m->mb;
+    int intra = S_IS_INTRA(m->type), cbp_dc = S->p->cabac ? (m->nnz[24] | m->nnz[25] << 1 | m->nnz[26] << 2) : 0;
+    for (int pl = 0; pl < 3; pl++) {
+        int w = pl ? 8 : 16, st = pl ? S->sc : S->sy;
+        u8 *rec = S->fdec->plane[pl] + w * m->mby * st + w * m->mbx;
+        u8 *out = (pl == 0 ? o->rec_y : pl == 1 ? o->rec_u : o->rec_v) + ((size_t)S->f * w * S->mb_h + w * m->mby) * w * S->mb_w + w * m->mbx;
+        for (int y = 0; y < w; y++) { memcpy(rec + y * st, m->fd[pl] + y * FDEC, w); memcpy(out + (size_t)y * w * S->mb_w, m->fd[pl] + y * FDEC, w); }
+    }
+    S->fdec->mb_type[m->mb] = m->type == S_I_8x8 ? S_I_4x4 : m->type;
+    if (m->type == S_I_4x4 || m->type == S_I_8x8) for (int i = 0; i < 16; i++) S->i4mode[m->mb * 16 + i] = m->i4c[s_scan8(i)];
+    else memset(S->i4mode + m->mb * 16, 2, 16);
+    if (m->cbp_luma == 0 && m->type != S_I_8x8) m->t8 = 0;
+    S->t8[m->mb] = m->t8;
+    memcpy(S->nnz + m->mb * 27, m->nnz, 27);
+    for (int i = 0; i < 16; i++) {
+        S->fdec->mv[(m->mb * 16 + i) * 2] = intra ? 0 : m->mvx;
+        S->fdec->mv[(m->mb * 16 + i) * 2 + 1] = intra ? 0 : m->mvy;
+    }
+    for (int i = 0; i < 4; i++) S->fdec->ref[m->mb * 4 + i] = intra ? -1 : m->ref;
+    if (intra) S->intra_count++;
+
+    o->mb_type[M] = m->type; o->partition[M] = S_D_16x16;
+    memset(o->sub_partition + M * 4, 0, 4);
+    memcpy(o->nnz + M * 27, m->nnz, 27);
+    o->qp[M] = S->qp;
+    o->cbp[M] = m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
+    o->t8[M] = m->t8;
+    o->i16mode[M] = m->type == S_I_16x16 ? m->i16mode : 0;
+    o->chroma_mode[M] = intra ? m->chroma_mode : 0;
+    memcpy(o->i4mode + M * 16, S->i4mode + m->mb * 16, 16);
+    if (S->slice_type == S_SLICE_P) {
+        memcpy(o->mv + M * 32, S->fdec->mv + m->mb * 32, 64);
+        memcpy(o->ref + M * 4, S->fdec->ref + m->mb * 4, 4);
+        for (int r = 0; r < S->n_ref; r++) {
+            o->mvr[(((size_t)S->f * S->p->n_refs + r) * S->n + m->mb) * 2] = S->mvr[((size_t)r * S->n + m->mb) * 2];
+            o->mvr[(((size_t)S->f * S->p->n_refs + r) * S->n + m->mb) * 2 + 1] = S->mvr[((size_t)r * S->n + m->mb) * 2 + 1];
+        }
+    } else
+        memset(o->ref + M * 4, -1, 4);
+    i16 *ly = o->luma + M * 256, *ldc = o->luma_dc + M * 16, *cdc = o->chroma_dc + M * 8, *cac = o->chroma_ac + M * 128;
+    memset(ly, 0, 512); memset(ldc, 0, 32); memset(cdc, 0, 16); memset(cac, 0, 256);
+    if (m->type != S_P_SKIP) {
+        if (m->type == S_I_16x16 && m->nnz[24]) memcpy(ldc, m->dc16, 32);
+        if (m->t8) {
+            for (int i = 0; i < 4; i++) if ((m->cbp_luma >> i & 1) && m->nnz[4 * i]) memcpy(ly + 64 * i, m->luma8[i], 128);
+        } else
+            for (int i = 0; i < 16; i++) if ((m->cbp_luma >> (i >> 2) & 1) && m->nnz[i]) memcpy(ly + 16 * i, m->luma4[i], 32);
+        if (m->cbp_chroma) for (int i = 0; i < 2; i++) if (m->nnz[25 + i]) memcpy(cdc + 4 * i, m->cdc[i], 8);
+        if (m->cbp_chroma == 2) for (int i = 0; i < 8; i++) if (m->nnz[16 + i]) memcpy(cac + 16 * i, m->cac[i], 32);
+    }
+}
+
+/* ------------------------------------------------------------------ the chain */
+int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, const u8 *src_v, slice_out *o)
+{
+    ssl S;
+    sframe *refs[16] = {0};
+    int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
+    s_setup();
+    if ((p->inter & 0x30) || p->subme > 5 || p->me_method > 1 || p->mixed_refs) return -3;
+    memset(&S, 0, sizeof(S));
+    S.p = p; S.o = o;
+    S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;
+    S.w16 = 16 * S.mb_w; S.h16 = 16 * S.mb_h;
+    S.sy = (S.w16 + 64 + 15) & ~15; S.sc = ((S.sy >> 1) + 15) & ~15;
+    S.nnz = calloc(S.n, 27); S.i4mode = calloc(S.n, 16); S.t8 = calloc(S.n, 1);
+    S.mvr = calloc((size_t)p->n_refs * S.n * 2, sizeof(i16));
+    S.fenc = sframe_new(&S);
+    for (int f = 0; f < p->n_frames; f++) {
+        int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
+        size_t F = f;
+        if (idr) { for (int i = 0; i < n_avail; i++) sframe_free(refs[i]); n_avail = 0; last_idr = f; }
+        for (int y = 0; y < p->height; y++) memcpy(S.fenc->plane[0] + y * S.sy, src_y + (F * p->height + y) * p->width, p->width);
+        for (int y = 0; y < chh; y++) {
+            memcpy(S.fenc->plane[1] + y * S.sc, src_u + (F * chh + y) * cw, cw);
+            memcpy(S.fenc->plane[2] + y * S.sc, src_v + (F * chh + y) * cw, cw);
+        }
+        x264o_plane_pad_mod16(S.fenc->plane[0], S.sy, p->width, p->height, S.w16, S.h16);
+        x264o_plane_pad_mod16(S.fenc->plane[1], S.sc, cw, chh, S.w16 / 2, S.h16 / 2);
+        x264o_plane_pad_mod16(S.fenc->plane[2], S.sc, cw, chh, S.w16 / 2, S.h16 / 2);
+        S.f = f;
+        S.fdec = sframe_new(&S);
+        S.fdec->poc = 2 * (f - last_idr);
+        S.n_ref = n_avail < p->n_refs ? n_avail : p->n_refs;
+        for (int i = 0; i < S.n_ref; i++) S.fref[i] = refs[i];
+        S.slice_type = idr ? S_SLICE_I : S_SLICE_P;
+        /* CQP: x264_ratecontrol_new / _start, R/encoder/ratecontrol.c:370-373,845-853 (ip_factor 1.4) */
+        S.qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51) : p->qp;
+        S.qpc = s_chroma_qp[clip3i(S.qp + p->chroma_qp_offset, 0, 51)];
+        S.lambda = s_lambda_tab[S.qp]; S.lambda2 = s_lambda2_tab[S.qp];
+        S.cost_mv = s_load_cost_mv(S.qp);
+        for (int i = 0; i < 16; i++) S.ref_cost[i] = S.lambda * s_te_size(clip3i((S.n_ref <= 0 ? 1 : S.n_ref) - 1, 0, 2), i);
+        for (int cat = 0; cat < 4; cat++) x264o_cqm_flat(cat, cat < 2 ? S.qp : S.qpc, 0, S.mf4[cat], S.b4[cat], &S.dq4[cat][0][0]);
+        for (int cat = 0; cat < 2; cat++) x264o_cqm_flat(cat, S.qp, 1, S.mf8[cat], S.b8[cat], &S.dq8[cat][0][0]);
+        /* x264_macroblock_slice_init, R/common/macroblock.c:771-808 */
+        S.fdec->n_ref0 = S.n_ref;
+        for (int i = 0; i < S.n_ref; i++) {
+            int delta = S.fdec->poc - S.fref[i]->poc;
+            S.fdec->ref_poc[i] = S.fref[i]->poc;
+            S.fdec->inv_ref_poc[i] = (256 + delta / 2) / delta;
+        }
+        S.intra_count = 0; S.stat_intra = S.stat_inter = S.stat_n = 0;
+        o->frame_info[4 * F] = S.slice_type; o->frame_info[4 * F + 1] = S.qp; o->frame_info[4 * F + 2] = S.n_ref;
+        o->frame_info[4 * F + 3] = S.fdec->poc;
+        for (int mb = 0; mb < S.n; mb++) {
+            smb m;
+            load_mb(&S, &m, mb % S.mb_w, mb / S.mb_w);
+            analyse_mb(&S, &m);
+            update_mb(&S, &m);
+            encode_mb(&S, &m);
+            save_mb(&S, &m);
+        }
+        o->stat[4 * F] = S.stat_intra; o->stat[4 * F + 1] = S.stat_inter; o->stat[4 * F + 2] = S.stat_n; o->stat[4 * F + 3] = 0;
+        /* x264_fdec_filter_row over the finished frame: loop filter, borders, half-pel planes */
+        if (p->deblock) {
+            u8 *t = malloc(S.n), *q = malloc(S.n), *t8 = malloc(S.n), *nz = malloc(S.n * 26);
+            for (int mb = 0; mb < S.n; mb++) {
+                int ty = o->mb_type[F * S.n + mb];
+                t[mb] = S_IS_INTRA(ty) ? 1 : ty == S_P_SKIP ? 2 : 0;
+                q[mb] = (u8)o->qp[F * S.n + mb]; t8[mb] = (u8)S.t8[mb];
+                memcpy(nz + mb * 26, S.nnz + mb * 27, 24); nz[mb * 26 + 24] = S.nnz[mb * 27 + 25]; nz[mb * 26 + 25] = S.nnz[mb * 27 + 26];
+            }
+            x264o_frame_deblock(S.fdec->plane[0], S.fdec->plane[1], S.fdec->plane[2], S.mb_w, S.mb_h, S.sy, S.sc, t, q, nz, t8,
+                                S.fdec->mv, S.fdec->ref, p->alpha_c0, p->beta, p->chroma_qp_offset);
+            free(t); free(q); free(t8); free(nz);
+        }
+        x264o_plane_expand_border(S.fdec->plane[0], S.sy, S.w16, S.h16, 32, 32);
+        x264o_plane_expand_border(S.fdec->plane[1], S.sc, S.w16 / 2, S.h16 / 2, 16, 16);
+        x264o_plane_expand_border(S.fdec->plane[2], S.sc, S.w16 / 2, S.h16 / 2, 16, 16);
+        if (p->subme) x264o_frame_hpel(S.fdec->filt[0], S.fdec->filt[1], S.fdec->filt[2], S.fdec->filt[3], S.sy, S.w16, S.h16, S.mb_h);
+        else for (int k = 1; k < 4; k++) S.fdec->filt[k] = S.fdec->filt[0];
+        for (int y = 0; y < S.h16; y++) memcpy(o->fin_y + (F * S.h16 + y) * S.w16, S.fdec->plane[0] + y * S.sy, S.w16);
+        for (int y = 0; y < S.h16 / 2; y++) {
+            memcpy(o->fin_u + (F * S.h16 / 2 + y) * (S.w16 / 2), S.fdec->plane[1] + y * S.sc, S.w16 / 2);
+            memcpy(o->fin_v + (F * S.h16 / 2 + y) * (S.w16 / 2), S.fdec->plane[2] + y * S.sc, S.w16 / 2);
+        }
+        for (int i = n_avail; i > 0; i--) refs[i] = refs[i - 1];
+        refs[0] = S.fdec; n_avail++;
+        if (n_avail > p->n_refs) sframe_free(refs[--n_avail]);
+    }
+    for (int i = 0; i < n_avail; i++) sframe_free(refs[i]);
+    sframe_free(S.fenc);
+    free(S.nnz); free(S.i4mode); free(S.t8); free(S.mvr);
+    return 0;
+}

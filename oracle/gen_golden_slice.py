@@ -1,0 +1,69 @@
+"""TEST INFRASTRUCTURE -- golden vectors for the per-macroblock sweep, produced by the REFERENCE's
+own x264_macroblock_cache_load / _analyse / _encode / _cache_save loop (oracle/ref_slice.c inside
+oracle/_ref/libx264ref.so, built from the sources where they lie).  Runs only where
+/root/reference exists; the .npz files under tests/golden/ are what travels.
+
+    python -m oracle.gen_golden_slice
+"""
+import os
+
+import numpy as np
+
+from oracle import refslice as rs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# (name, size, frames, clip kind, parameters)
+CASES = [
+    ("uf", (208, 144), 4, "moving", dict(qp=30, subme=0)),
+    ("uf_static", (200, 120), 4, "static", dict(qp=38, subme=1)),
+    ("hex2", (200, 120), 4, "static", dict(qp=30, subme=2, me_method=rs.ME_HEX)),
+    ("refs3", (208, 144), 5, "static", dict(qp=30, subme=5, me_method=rs.ME_HEX, n_refs=3, cabac=1, deblock=1)),
+    ("intra_all", (208, 144), 4, "static", dict(qp=26, subme=4, me_method=rs.ME_HEX, n_refs=2, inter=0x3, intra=0x3,
+                                                 transform8x8=1, cabac=1, deblock=1)),
+    ("nodecimate", (200, 120), 4, "moving", dict(qp=34, subme=3, intra=0x1, inter=0x1, n_refs=2, deblock=1, dct_decimate=0,
+                                                  fast_pskip=0)),
+]
+
+
+def static_clip(w, h, n):
+    """Synthetic clip whose background is frozen at frame 0 outside a moving window (P_SKIP territory)."""
+    y, u, v = rs.clip(w, h, n)
+    for t in range(1, n):
+        x0, y0 = ((16 + 24 * t) % max(w - 96, 1)) & ~1, ((8 + 16 * t) % max(h - 64, 1)) & ~1
+        by, bu, bv = y[0].copy(), u[0].copy(), v[0].copy()
+        by[y0:y0 + 64, x0:x0 + 96] = y[t][y0:y0 + 64, x0:x0 + 96]
+        bu[y0 // 2:y0 // 2 + 32, x0 // 2:x0 // 2 + 48] = u[t][y0 // 2:y0 // 2 + 32, x0 // 2:x0 // 2 + 48]
+        bv[y0 // 2:y0 // 2 + 32, x0 // 2:x0 // 2 + 48] = v[t][y0 // 2:y0 // 2 + 32, x0 // 2:x0 // 2 + 48]
+        y[t], u[t], v[t] = by, bu, bv
+    return y, u, v
+
+
+def case_inputs(size, frames, kind):
+    return (static_clip if kind == "static" else rs.clip)(size[0], size[1], frames)
+
+
+def masked(a):
+    """mvr of skipped macroblocks / unused references is never read by the reference (undefined): zero it."""
+    a = dict(a)
+    skip = a["mb_type"] == rs.P_SKIP
+    m = np.broadcast_to(skip[:, None, :, None], a["mvr"].shape) | \
+        (np.arange(a["mvr"].shape[1])[None, :, None, None] >= a["frame_info"][:, 2][:, None, None, None])
+    a["mvr"] = np.where(m, 0, a["mvr"]).astype(np.int16)
+    return a
+
+
+def main():
+    for name, size, frames, kind, kw in CASES:
+        p = rs.make_params(size[0], size[1], frames, **kw)
+        y, u, v = case_inputs(size, frames, kind)
+        a = masked(rs.run_reference(p, y, u, v))
+        path = os.path.join(GOLDEN, "slice_%s.npz" % name)
+        np.savez_compressed(path, **a)
+        types = [np.bincount(a["mb_type"][f], minlength=7)[[0, 1, 2, 4, 6]].tolist() for f in range(frames)]
+        print("%s: %d bytes, types per frame (I4 I8 I16 P skip) %s" % (path, os.path.getsize(path), types))
+
+
+if __name__ == "__main__":
+    main()

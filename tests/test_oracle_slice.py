@@ -1,0 +1,43 @@
+"""CPU: the twin of the reference's per-macroblock loop (oracle/slice_oracle.c: cache_load ->
+x264_macroblock_analyse -> x264_macroblock_encode -> cache_save over chains of I and P frames)
+against golden arrays produced by the reference's own functions (oracle/ref_slice.c, vectors by
+oracle/gen_golden_slice.py).  Every decision (types, modes, vectors, references, cbp, nnz), every
+coefficient level and every reconstructed pixel, before and after the loop filter."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import refslice as rs
+from oracle.gen_golden_slice import CASES, case_inputs, masked
+
+
+def load_case(name):
+    with np.load(os.path.join(GOLDEN, "slice_%s.npz" % name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def assert_same(got, want):
+    for k in want:
+        assert np.array_equal(got[k], want[k]), "%s differs first at %s" % (k, np.argwhere(got[k] != want[k])[:3].tolist())
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw", CASES, ids=[c[0] for c in CASES])
+def test_sweep_twin_matches_reference_loop(oracle_lib, name, size, frames, kind, kw):
+    want = load_case(name)
+    p = rs.make_params(size[0], size[1], frames, **kw)
+    y, u, v = case_inputs(size, frames, kind)
+    got = masked(rs.run(oracle_lib, "x264o_encode_chain", p, y, u, v))
+    assert_same(got, want)
+    # the vectors exercise what they claim to
+    t = want["mb_type"][1:]
+    assert (t == rs.P_L0).any() and (want["cbp"] != 0).any()
+    if kind == "static":
+        assert (t == rs.P_SKIP).sum() > 20
+    if kw.get("intra", 0) & 1:
+        assert (want["mb_type"] == rs.I_4x4).any()
+    if kw.get("transform8x8"):
+        assert (want["mb_type"] == rs.I_8x8).any() and want["t8"][1:].any()
+    if kw.get("n_refs", 1) > 1:
+        assert (want["ref"] > 0).any()

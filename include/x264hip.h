@@ -199,6 +199,59 @@ int x264hip_me_search16_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc,
                               int n_refs, const x264hip_me16_params *p, int16_t *out_mv_dev, int32_t *out_cost_dev,
                               int32_t *best_dev);
 
+/* ---- the per-macroblock hot loop itself ------------------------------------------------------
+ * One launch per frame runs, for every macroblock of every chain of the batch, what
+ * x264_slice_write does (R/encoder/encoder.c:1171-1222): x264_macroblock_cache_load
+ * (R/common/macroblock.c:872), x264_macroblock_analyse (R/encoder/analyse.c:2156),
+ * x264_macroblock_encode (R/encoder/macroblock.c:475), x264_macroblock_cache_save
+ * (R/common/macroblock.c:1208), in the wavefront order their neighbour dependences allow.  The
+ * entropy coder is not part of it: it consumes x264hip_mb_state on the host.
+ *
+ * x264hip_mb_state = what the reference keeps per frame in x264_frame_t / h->mb (mb_type, mv, ref,
+ * non_zero_count, intra modes, qp, cbp ...) plus h->dct for every macroblock; every array is
+ * [batch][n_mb][...] in HBM.  Numbering follows the reference: mb types R/common/macroblock.h:78-102
+ * (I_4x4 0, I_8x8 1, I_16x16 2, I_PCM 3, P_L0 4, P_8x8 5, P_SKIP 6), partitions :55-76, intra modes
+ * R/common/predict.h:31-107, nnz index = block index of x264_scan8 (0-15 luma, 16-23 chroma AC,
+ * 24 luma DC, 25/26 chroma DC).  Levels are in scan order and zero wherever cbp / nnz say "not coded". */
+typedef struct {
+    int8_t  *mb_type, *partition;
+    int8_t  *ref;          /* [n][4] per 8x8; -1 intra */
+    int8_t  *i4mode;       /* [n][16] intra 4x4 / 8x8 modes by block index; I_PRED_4x4_DC elsewhere */
+    int8_t  *i16mode, *chroma_mode, *qp, *t8;
+    int16_t *mv;           /* [n][16][2] quarter-pel, 4x4 blocks in raster order inside the macroblock */
+    int16_t *mvr;          /* [8][n][2] 16x16 search result per reference (h->mb.mvr) */
+    int16_t *cbp;          /* h->mb.cbp: dc << 8 | chroma << 4 | luma */
+    uint8_t *nnz;          /* [n][27] */
+    int16_t *luma, *luma_dc, *chroma_dc, *chroma_ac;   /* [n][256] [n][16] [n][2][4] [n][8][16] */
+    int32_t *cost_intra, *cost_inter;                  /* per macroblock terms of h->stat.frame.i_intra_cost / i_inter_cost */
+    int32_t *progress;     /* [batch][mb_h] + abort flag: the sweep's row counters */
+    int poc, n_ref0, inv_ref_poc[8];                   /* x264_frame_t.i_poc / i_ref[0] / inv_ref_poc, filled by the sweep */
+} x264hip_mb_state;
+
+typedef struct {
+    int slice_type;                    /* 0 = SLICE_TYPE_P, 2 = SLICE_TYPE_I (R/common/common.h:128-134) */
+    int qp, chroma_qp_offset;
+    int me_method, me_range, subme, chroma_me, mv_range;       /* param.analyse.* */
+    int fast_pskip, dct_decimate, cabac, transform8x8;
+    int analyse_inter, analyse_intra;  /* X264_ANALYSE_* masks (R/x264.h:190-199) */
+    const uint16_t *quant4_mf, *quant4_bias, *quant8_mf, *quant8_bias;   /* device, as x264hip_residual_params */
+    const int32_t *dequant4_mf, *dequant8_mf;
+    const int16_t *cost_mv;            /* device: p_cost_mv for this qp's lambda, centred at cost_mv_range */
+    int cost_mv_range;
+    int poc, ref_poc[8];               /* fdec->i_poc and fdec->ref_poc[0][] */
+} x264hip_slice_params;
+
+int  x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st);
+void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st);
+/* refs: list0, most recent first (reconstructed, borders expanded, half-pel planes built);
+ * l0 = the state refs[0] was coded with (temporal predictors, fast-intra test) or NULL;
+ * recon: receives the unfiltered reconstruction (deblock / expand / hpel are separate calls). */
+int  x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs,
+                               int n_refs, x264hip_picture *recon, const x264hip_slice_params *p,
+                               const x264hip_mb_state *l0, x264hip_mb_state *out);
+/* synchronises; -1 if a wavefront gave up waiting for its neighbours (the frame is then invalid) */
+int  x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st);
+
 /* Inter residual pipeline for every macroblock (x264_macroblock_encode's
  * inter branch, R/encoder/macroblock.c:596-768, without trellis/denoise):
  * x264_mb_mc 16x16 (mc_luma + mc_chroma) -> sub16x16_dct(8) -> quant ->
@@ -269,6 +322,7 @@ typedef struct {
     const int16_t *mv;
     const int8_t  *ref;
     int alpha_c0_offset, beta_offset, chroma_qp_offset;
+    int state_layout;      /* 0: compact codes above, nnz [mb][26]; 1: the arrays of an x264hip_mb_state (reference type numbers, nnz [mb][27]) */
 } x264hip_deblock_params;
 int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x264hip_deblock_params *p);
 

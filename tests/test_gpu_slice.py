@@ -1,0 +1,84 @@
+"""GPU: the macroblock sweep (x264hip_slice_sweep_frame: cache_load -> x264_macroblock_analyse ->
+x264_macroblock_encode -> cache_save for every macroblock, one wavefront per macroblock row) against
+golden arrays produced by the REFERENCE's own functions for the same chains (oracle/ref_slice.c,
+oracle/gen_golden_slice.py): every decision, every level, every reconstructed pixel before and after
+the loop filter, frame after frame (each frame is predicted from the GPU's own previous output)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle.gen_golden_slice import CASES, case_inputs
+from x264_vs2008_amd import slice as sl
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED = [c for c in CASES if not c[4].get("inter") and not c[4].get("intra") and not c[4].get("transform8x8")]
+STATE = ["mb_type", "partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc",
+         "chroma_dc", "chroma_ac"]
+
+
+def run_chain(hip_lib, cqm, size, frames, y, u, v, kw, batch=1, shift=0):
+    """Encode the clip; returns per frame a dict of downloaded arrays (batch element 0 unless stated)."""
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=batch, **kw)
+    out = []
+    try:
+        for f in range(frames):
+            for b in range(batch):
+                t = (f + b * shift) % frames if shift else f
+                enc.upload(y[t], u[t], v[t], b=b)
+            stype, qp, state = enc.encode_frame()
+            enc.status()
+            recon = enc.last[0]
+            d = {k: state.get(k) for k in STATE + ["mvr", "cost_intra", "cost_inter"]}
+            d["info"] = (stype, qp)
+            for nm in ("y", "u", "v"):
+                d["rec_" + nm] = np.stack([enc.ctx.download(recon, nm, padded=False, b=b) for b in range(batch)])
+            enc.finish_frame()
+            enc.ctx.sync()
+            for nm in ("y", "u", "v"):
+                d["fin_" + nm] = np.stack([enc.ctx.download(recon, nm, padded=False, b=b) for b in range(batch)])
+            out.append(d)
+    finally:
+        enc.close()
+    return out
+
+
+def check_frame(d, gold, f, n_refs, b=0):
+    for k in STATE:
+        got, want = d[k][b], gold[k][f]
+        assert np.array_equal(got.reshape(want.shape), want), "frame %d: %s differs first at %s" % (f, k, np.argwhere(got.reshape(want.shape) != want)[:3].tolist())
+    for nm in ("y", "u", "v"):
+        for kind in ("rec_", "fin_"):
+            got, want = d[kind + nm][b], gold[kind + nm][f]
+            assert np.array_equal(got, want), "frame %d: %s%s differs at %s" % (f, kind, nm, np.argwhere(got != want)[:3].tolist())
+    skip = gold["mb_type"][f] == sl.P_SKIP
+    nr = int(gold["frame_info"][f][2])
+    for r in range(nr):
+        got, want = d["mvr"][b][r], gold["mvr"][f][r]
+        assert np.array_equal(got[~skip], want[~skip]), "frame %d: mvr[%d]" % (f, r)
+    assert d["info"] == (int(gold["frame_info"][f][0]), int(gold["frame_info"][f][1]))
+    assert int(d["cost_intra"][b].sum()) == int(gold["stat"][f][0]) and int(d["cost_inter"][b].sum()) == int(gold["stat"][f][1])
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw", SUPPORTED, ids=[c[0] for c in SUPPORTED])
+def test_sweep_matches_reference_loop(hip_lib, cqm, name, size, frames, kind, kw):
+    with np.load(os.path.join(GOLDEN, "slice_%s.npz" % name)) as z:
+        gold = {k: z[k] for k in z.files}
+    y, u, v = case_inputs(size, frames, kind)
+    out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw)
+    for f in range(frames):
+        check_frame(out[f], gold, f, kw.get("n_refs", 1))
+
+
+def test_sweep_batched_chains_are_independent(hip_lib, cqm):
+    """Three chains in one launch; every element gets the same clip and must equal the golden chain."""
+    name, size, frames, kind, kw = next(c for c in SUPPORTED if c[0] == "refs3")
+    with np.load(os.path.join(GOLDEN, "slice_%s.npz" % name)) as z:
+        gold = {k: z[k] for k in z.files}
+    y, u, v = case_inputs(size, frames, kind)
+    out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw, batch=3)
+    for f in range(frames):
+        for b in range(3):
+            check_frame(out[f], gold, f, kw.get("n_refs", 1), b=b)

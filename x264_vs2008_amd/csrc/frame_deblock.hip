@@ -43,6 +43,7 @@ static __constant__ u8 c_chroma_qp[76] = {
 struct DbGeom {
     int mb_w, mb_h, sy, sc, a_off, b_off, cqp_off, diag, y_min, count;
     size_t bs_y, bs_c;  // bytes between batch elements
+    int layout;         // 0: compact type codes (0 inter 1 intra 2 skip), nnz[26]; 1: x264hip_mb_state (reference numbering, nnz[27])
 };
 
 __device__ __forceinline__ int z_of(int x, int y) { return (y >> 1) * 8 + (x >> 1) * 4 + (y & 1) * 2 + (x & 1); }
@@ -112,13 +113,15 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
     {   // batch element
         const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
         py += g.bs_y * bz; pu += g.bs_c * bz; pv += g.bs_c * bz;
-        mb_type += nmb * bz; qp += nmb * bz; nnz += 26 * nmb * bz; t8x8 += nmb * bz; mv += 32 * nmb * bz; ref += 4 * nmb * bz;
+        mb_type += nmb * bz; qp += nmb * bz; nnz += (size_t)(g.layout ? 27 : 26) * nmb * bz; t8x8 += nmb * bz; mv += 32 * nmb * bz; ref += 4 * nmb * bz;
     }
     DbLds &s = s_all[wave];
     const int mby = g.y_min + k, mbx = g.diag - 2 * mby, mb = mby * g.mb_w + mbx;
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
                          __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-    const int q = qp[mb], t8 = t8x8[mb], type = mb_type[mb];
+    const int ns = g.layout ? 27 : 26;
+#define DB_TYPE(t_) (g.layout ? ((t_) <= 3 ? 1 : (t_) == 6 ? 2 : 0) : (int)(t_))
+    const int q = qp[mb], t8 = t8x8[mb], type = DB_TYPE(mb_type[mb]);
     const int qp_thresh = 15 - (g.a_off < g.b_off ? g.a_off : g.b_off) - (g.cqp_off > 0 ? g.cqp_off : 0);
     const int edge_end = (type == 2 || q <= qp_thresh) ? 1 : 4;
 
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
         int bs = 255;
         if (active) {
             int mbn = edge ? mb : (dir ? mb - g.mb_w : mb - 1);
-            bool intra = type == 1 || mb_type[mbn] == 1;
+            bool intra = type == 1 || DB_TYPE(mb_type[mbn]) == 1;
             if (intra) bs = edge == 0 ? 4 : 3;
             else {
                 // segments 0..i are needed for the "copy the previous segment" rule: recompute them serially
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
                     int x = dir == 0 ? edge : j, y = dir == 0 ? j : edge;
                     int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
                     int b = 0;
-                    if (nnz[mb * 26 + z_of(x, y)] || nnz[mbn * 26 + z_of(xn, yn)]) b = 2;
+                    if (nnz[mb * ns + z_of(x, y)] || nnz[mbn * ns + z_of(xn, yn)]) b = 2;
                     else if (!(edge & 1)) {
                         if ((j & 1) && prev != 2) b = prev;
                         else {
@@ -229,7 +232,7 @@ extern "C" int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *reco
     DbGeom g;
     g.mb_w = c->d.mb_w; g.mb_h = c->d.mb_h; g.sy = c->d.stride_y; g.sc = c->d.stride_c;
     g.bs_y = c->bs_y; g.bs_c = c->bs_c;
-    g.a_off = p->alpha_c0_offset; g.b_off = p->beta_offset; g.cqp_off = p->chroma_qp_offset;
+    g.a_off = p->alpha_c0_offset; g.b_off = p->beta_offset; g.cqp_off = p->chroma_qp_offset; g.layout = p->state_layout ? 1 : 0;
     if (g.a_off < -12 || g.a_off > 12 || g.b_off < -12 || g.b_off > 12 || g.cqp_off < -12 || g.cqp_off > 12) {
         set_error("deblock: offsets out of range");
         return -1;

@@ -1,0 +1,878 @@
+// frame_slice.hip -- FRAME LEVEL, part 7: the reference's per-macroblock hot loop itself.
+//
+// What x264_slice_write does for every macroblock of a slice (R/encoder/encoder.c:1141-1291):
+//   x264_macroblock_cache_load   R/common/macroblock.c:872-1187   neighbour state, predictors
+//   x264_macroblock_analyse      R/encoder/analyse.c:2156-2774    I and P slices, no RD (subme <= 5)
+//   x264_macroblock_encode       R/encoder/macroblock.c:475-790
+//   x264_macroblock_cache_save   R/common/macroblock.c:1208-1372
+// in ONE launch per frame for a whole batch of independent GOP chains.
+//
+// Schedule.  A macroblock needs its left, top-left, top and top-right neighbours finished
+// (reconstructed pixels for intra prediction, vectors / references / types for the predictors), so
+// a frame is a 2:1 wavefront.  One wavefront (= one workgroup) owns one macroblock ROW of one
+// chain and walks it left to right; row r may start macroblock x once row r-1 has published x+2
+// finished macroblocks (release store / acquire load on a per-row progress word in HBM).  The left
+// neighbour is the wave's own previous iteration: its state stays in LDS / registers.  Workgroup
+// ids are laid out so that all rows of a chain land on the same XCD (id % 8 == chain % 8): the
+// cross-row traffic stays inside one L2.  Every wait is bounded: a wave that spins too long raises
+// the abort flag and every wave leaves, so the grid always drains.
+//
+// Inside a macroblock all 64 lanes work on the same block: 4 luma pixels per lane for prediction and
+// SAD, 32 lanes x 8 pixels for SATD, 16 lanes x one 4x4 block for the transforms; every decision is
+// wave-uniform scalar state.  Built so far: I_16x16 + chroma modes, P_SKIP (fast and early), P 16x16
+// over several references (DIA / HEX, subme 0..5, chroma ME), CQP.
+#include <cstring>
+#include "me_exact.h"
+#include "intra_pred.h"
+#include "frame_internal.h"
+
+using namespace x264hip;
+
+#define SW_MAX_REFS 8
+#define SW_SPIN_LIMIT (1 << 21)
+#define FD 32                      // FDEC_STRIDE
+#define FDY (2 * FD)               // fdec_buf layout, R/common/macroblock.c:721-737
+#define FDU (19 * FD)
+#define FDV (19 * FD + 16)
+
+enum { T_I_4x4 = 0, T_I_8x8 = 1, T_I_16x16 = 2, T_I_PCM = 3, T_P_L0 = 4, T_P_8x8 = 5, T_P_SKIP = 6 };
+enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
+#define IS_INTRA_T(t) ((t) >= 0 && (t) <= T_I_PCM)
+
+struct SwRefs {
+    const u8 *y[SW_MAX_REFS][4];
+    const u8 *u[SW_MAX_REFS], *v[SW_MAX_REFS];
+};
+struct SwArgs {
+    int mb_w, mb_h, sy, sc, batch, batch_pad;
+    size_t bs_y, bs_c;
+    int slice_type, qp, qpc, lambda, chroma_skip_thresh, n_refs;
+    int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS];
+    int l0_n_ref0, l0_inv_ref_poc[SW_MAX_REFS];
+    int me_method, me_range, subme, chroma_me, fast_pskip, dct_decimate, cabac, mv_range;
+    const u16 *q4mf, *q4bias;
+    const int *dq4;
+    const i16 *cost_mv;
+    int cost_center;
+    const u8 *fy, *fu, *fv;
+    u8 *dy, *du, *dv;
+    const signed char *l0_type, *l0_ref;
+    const i16 *l0_mv;
+    signed char *mb_type, *partition, *ref, *i4mode, *i16mode, *chroma_mode, *qp_out, *t8;
+    i16 *mv, *mvr, *cbp;
+    u8 *nnz;
+    i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
+    int *cost_intra, *cost_inter;
+    int *progress, *abort_flag;
+};
+
+struct SwLds {
+    u8 fe[384];                 // source: Y 16x16 | U 8x8 | V 8x8
+    u8 fd[27 * FD];             // prediction / reconstruction with its borders, fdec_buf layout
+    i16 coef[16][16];           // dequantised luma coefficients
+    i16 ccoef[8][16];           // dequantised chroma AC
+    int score[16], cscore[8];
+    i16 cdc[8], cdcout[8], dc16[16];
+    int keep8, cmode[2], nzdc16;
+    i16 lv_y[256], lv_dc[16], lv_cdc[8], lv_cac[128];
+    u8 nnz[32];
+    i16 mvc[8][2];
+    i16 left_mvr[SW_MAX_REFS][2];
+};
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
+                         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+__device__ __forceinline__ void sw_blk_xy(int k, int &x, int &y)
+{
+    x = ((k >> 2) & 1) * 8 + (k & 1) * 4;
+    y = (k >> 3) * 8 + ((k >> 1) & 1) * 4;
+}
+__device__ __forceinline__ int sw_decimate(const i16 *lv, int n)
+{   // R/common/quant.c:213-239 on scanned levels lv[0..n)
+    int i = n - 1, score = 0;
+    while (i >= 0 && lv[i] == 0) i--;
+    while (i >= 0) {
+        if ((unsigned)(lv[i--] + 1) > 2u) return 9;
+        int run = 0;
+        while (i >= 0 && lv[i] == 0) { i--; run++; }
+        score += c_decimate4[run];
+    }
+    return score;
+}
+__device__ __forceinline__ int sw_ue_size(int v) { return v == 0 ? 1 : v < 3 ? 3 : 5; }   // bs_size_ue for 0..6
+__device__ __forceinline__ int sw_median(int a, int b, int c) { int mx = max(a, b), mn = min(a, b); return c > mx ? mx : c < mn ? mn : c; }
+
+// ---- motion compensation of one 16x16 vector into s.fd (x264_mb_mc_0xywh, R/common/macroblock.c:462-476)
+__device__ __forceinline__ void sw_mc16(SwLds &s, const SwRefs &refs, const SwArgs &a, int ri, int mvx, int mvy, ptrdiff_t oy, ptrdiff_t oc,
+                                        size_t by, size_t bc, int lane, bool do_chroma)
+{
+    {
+        const int r = lane >> 2, x = (lane & 3) * 4;
+        const int qx = mvx & 3, qy = mvy & 3, idx = qy * 4 + qx;
+        const ptrdiff_t base = oy + (ptrdiff_t)((mvy >> 2) + r) * a.sy + (mvx >> 2) + x + (ptrdiff_t)by;
+        const u8 *pa = refs.y[ri][c_qpel_a[idx]] + base + (qy == 3) * a.sy;
+        const u8 *pb = refs.y[ri][c_qpel_b[idx]] + base + (qx == 3);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            s.fd[FDY + r * FD + x + i] = (idx & 5) ? (u8)(((int)pa[i] + (int)pb[i] + 1) >> 1) : pa[i];
+    }
+    if (do_chroma) {
+        const int cx = lane & 7, cy = lane >> 3;
+        const int dx = mvx & 7, dyy = mvy & 7;
+        const int ca = (8 - dx) * (8 - dyy), cb = dx * (8 - dyy), cc = (8 - dx) * dyy, cd = dx * dyy;
+        const ptrdiff_t cbase = oc + (ptrdiff_t)((mvy >> 3) + cy) * a.sc + (mvx >> 3) + cx + (ptrdiff_t)bc;
+        const u8 *pu = refs.u[ri] + cbase, *pv = refs.v[ri] + cbase;
+        s.fd[FDU + cy * FD + cx] = (u8)((ca * pu[0] + cb * pu[1] + cc * pu[a.sc] + cd * pu[a.sc + 1] + 32) >> 6);
+        s.fd[FDV + cy * FD + cx] = (u8)((ca * pv[0] + cb * pv[1] + cc * pv[a.sc] + cd * pv[a.sc + 1] + 32) >> 6);
+    }
+}
+
+// ---- block costs between s.fe and s.fd ---------------------------------------------------------
+// one row of an 8x4 block per lane (lanes of one block are l, l^1, l^2, l^3); returns the block SATD
+__device__ __forceinline__ int sw_satd_row8(const u8 *f, const u8 *p, int lane)
+{
+    int d[8];
+#pragma unroll
+    for (int x = 0; x < 8; x++) d[x] = (int)f[x] - (int)p[x];
+    u32 p0 = (u32)d[0] + ((u32)d[4] << 16), p1 = (u32)d[1] + ((u32)d[5] << 16);
+    u32 p2 = (u32)d[2] + ((u32)d[6] << 16), p3 = (u32)d[3] + ((u32)d[7] << 16);
+    u32 t0, t1, t2, t3;
+    wht4(t0, t1, t2, t3, p0, p1, p2, p3);
+    return satd_rows4(t0, t1, t2, t3, lane);
+}
+// mbcmp[PIXEL_16x16](fdec luma, fenc luma): SATD above subme 1, else SAD (R/encoder/encoder.c:608-618)
+__device__ __forceinline__ int sw_cmp_luma16(const SwLds &s, int satd, int lane)
+{
+    int v = 0;
+    if (satd) {
+        if (lane < 32) {
+            const int blk = lane >> 2, r = lane & 3, bx = (blk & 1) * 8, y = (blk >> 1) * 4 + r;
+            v = sw_satd_row8(s.fe + y * 16 + bx, s.fd + FDY + y * FD + bx, lane);
+            if (r) v = 0;
+        }
+    } else {
+        const int r = lane >> 2, x = (lane & 3) * 4;
+        v = (int)sad4(*(const u32 *)(s.fe + r * 16 + x), *(const u32 *)(s.fd + FDY + r * FD + x), 0);
+    }
+    return wave_sum(v);
+}
+// mbcmp[PIXEL_8x8] of both chroma planes, summed
+__device__ __forceinline__ int sw_cmp_chroma(const SwLds &s, int satd, int lane)
+{
+    int v = 0;
+    if (satd) {
+        if (lane < 16) {
+            const int pl = lane >> 3, blk = (lane >> 2) & 1, r = lane & 3, y = blk * 4 + r;
+            v = sw_satd_row8(s.fe + 256 + 64 * pl + y * 8, s.fd + (pl ? FDV : FDU) + y * FD, lane);
+            if (r) v = 0;
+        }
+    } else {
+        const int x = lane & 7, y = lane >> 3;
+        v = iabs((int)s.fe[256 + y * 8 + x] - (int)s.fd[FDU + y * FD + x]) + iabs((int)s.fe[320 + y * 8 + x] - (int)s.fd[FDV + y * FD + x]);
+    }
+    return wave_sum(v);
+}
+
+// ---- intra prediction into s.fd ----------------------------------------------------------------
+__device__ __forceinline__ void sw_pred16(SwLds &s, int mode, int lane)
+{
+    const int r = lane >> 2, x = (lane & 3) * 4;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = pred_px(0, mode, s.fd + FDY, FD, x + i, r);
+    WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 4; i++) s.fd[FDY + r * FD + x + i] = (u8)v[i];
+    WAVE_SYNC();
+}
+__device__ __forceinline__ void sw_pred8c(SwLds &s, int mode, int lane)
+{
+    const int x = lane & 7, y = lane >> 3;
+    int pu = pred_px(1, mode, s.fd + FDU, FD, x, y), pv = pred_px(1, mode, s.fd + FDV, FD, x, y);
+    WAVE_SYNC();
+    s.fd[FDU + y * FD + x] = (u8)pu; s.fd[FDV + y * FD + x] = (u8)pv;
+    WAVE_SYNC();
+}
+// predict_16x16_mode_available / predict_8x8chroma_mode_available, R/encoder/analyse.c:374-433
+__device__ __forceinline__ int sw_modes16(int nb, int *m)
+{
+    if (nb & NB_TOPLEFT) { m[0] = 0; m[1] = 1; m[2] = 2; m[3] = 3; return 4; }
+    if (nb & NB_LEFT) { m[0] = 4; m[1] = 1; return 2; }
+    if (nb & NB_TOP) { m[0] = 5; m[1] = 0; return 2; }
+    m[0] = 6; return 1;
+}
+__device__ __forceinline__ int sw_modes8c(int nb, int *m)
+{
+    if (nb & NB_TOPLEFT) { m[0] = 2; m[1] = 1; m[2] = 0; m[3] = 3; return 4; }
+    if (nb & NB_LEFT) { m[0] = 4; m[1] = 1; return 2; }
+    if (nb & NB_TOP) { m[0] = 5; m[1] = 2; return 2; }
+    m[0] = 6; return 1;
+}
+__device__ __forceinline__ int sw_fix16(int m) { return m < 4 ? m : 2; }      // x264_mb_pred_mode16x16_fix
+__device__ __forceinline__ int sw_fix8c(int m) { return m < 4 ? m : 0; }      // x264_mb_pred_mode8x8c_fix
+
+// ---- encode pieces (R/encoder/macroblock.c:116-363, 596-768; no trellis, not lossless) ------------
+// luma 4x4 transform + quant + scan + dequant of the 16 blocks, lanes 0-15.  cat: 0 intra, 1 inter.
+// i16 mode takes the DC out first (s.dc16 in raster order) and scores with decimate_score15.
+__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane)
+{
+    if (lane < 16) {
+        int bx, by, r[16];
+        sw_blk_xy(lane, bx, by);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
+        i16 c[16], lv[16];
+        fwd4x4(c, r);
+        if (dc_out) { s.dc16[(by >> 2) * 4 + (bx >> 2)] = c[0]; c[0] = 0; }
+        const u16 *mf = a.q4mf + (cat * 52 + a.qp) * 16, *bs = a.q4bias + (cat * 52 + a.qp) * 16;
+        const int *dq = a.dq4 + cat * 96 + (a.qp % 6) * 16;
+        int nz = 0, bits = a.qp / 6 - 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[0][i]] : (i16)0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s.lv_y[16 * lane + i] = lv[i]; s.coef[lane][i] = (i16)dequant_one(c[i], dq[i], bits); }
+        s.score[lane] = (nz ? (dc_out ? sw_decimate(lv + 1, 15) : sw_decimate(lv, 16)) : 0) | ((nz != 0) << 8);
+    }
+    WAVE_SYNC();
+}
+__device__ __forceinline__ void sw_luma4x4_add(SwLds &s, int lane, int keep8)
+{
+    if (lane < 16 && ((keep8 >> (lane >> 2)) & 1)) {
+        int bx, by, res[16];
+        sw_blk_xy(lane, bx, by);
+        inv4x4(res, s.coef[lane]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u8 *p = s.fd + FDY + (by + j) * FD + bx + i;
+                *p = (u8)clip_u8((int)*p + res[4 * j + i]);
+            }
+    }
+    WAVE_SYNC();
+}
+// x264_macroblock_encode's inter 4x4-transform branch; returns cbp_luma, fills s.nnz[0..15]
+__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane)
+{
+    sw_luma4x4_fwd(s, a, 1, false, lane);
+    if (lane == 0) {
+        int cbp = 0, dec_mb = 0;
+        for (int i8 = 0; i8 < 4; i8++) {
+            int dec8 = 0, any = 0;
+            for (int i4 = 0; i4 < 4; i4++) {
+                int v = s.score[4 * i8 + i4];
+                s.nnz[4 * i8 + i4] = (u8)(v >> 8);
+                if (v >> 8) { any = 1; if (a.dct_decimate && dec8 < 6) dec8 += v & 255; }
+            }
+            dec_mb += dec8;
+            if (a.dct_decimate) {
+                if (dec8 < 4) s.nnz[4 * i8] = s.nnz[4 * i8 + 1] = s.nnz[4 * i8 + 2] = s.nnz[4 * i8 + 3] = 0;
+                else cbp |= 1 << i8;
+            } else if (any) cbp |= 1 << i8;
+        }
+        if (a.dct_decimate && dec_mb < 6) { cbp = 0; for (int i = 0; i < 16; i++) s.nnz[i] = 0; }
+        s.keep8 = cbp;
+    }
+    WAVE_SYNC();
+    const int keep = s.keep8;
+    sw_luma4x4_add(s, lane, keep);
+    return keep;
+}
+// x264_mb_encode_i16x16 (prediction already in s.fd); returns cbp_luma, fills s.nnz[0..15], s.nnz[24]
+__device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int lane)
+{
+    sw_luma4x4_fwd(s, a, 0, true, lane);
+    if (lane == 0) {
+        const int b_decimate = a.dct_decimate && a.slice_type == 0;
+        int score = b_decimate ? 0 : 9, cbp = 0;
+        for (int i = 0; i < 16; i++) {
+            int v = s.score[i];
+            s.nnz[i] = (u8)(v >> 8);
+            if (v >> 8) { if (score < 6) score += v & 255; cbp = 0xf; }
+        }
+        if (score < 6) { cbp = 0; for (int i = 0; i < 16; i++) s.nnz[i] = 0; }
+        // dct4x4dc (R/common/dct.c:39-71), quant_4x4_dc, scan, idct4x4dc, dequant_4x4_dc (quant.c:151-178)
+        i16 d[16], t[16];
+        for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
+        for (int r = 0; r < 4; r++) {
+            int p = d[4 * r] + d[4 * r + 1], q = d[4 * r] - d[4 * r + 1], u = d[4 * r + 2] + d[4 * r + 3], w = d[4 * r + 2] - d[4 * r + 3];
+            t[r] = (i16)(p + u); t[4 + r] = (i16)(p - u); t[8 + r] = (i16)(q - w); t[12 + r] = (i16)(q + w);
+        }
+        for (int r = 0; r < 4; r++) {
+            int p = t[4 * r] + t[4 * r + 1], q = t[4 * r] - t[4 * r + 1], u = t[4 * r + 2] + t[4 * r + 3], w = t[4 * r + 2] - t[4 * r + 3];
+            d[4 * r] = (i16)((p + u + 1) >> 1); d[4 * r + 1] = (i16)((p - u + 1) >> 1);
+            d[4 * r + 2] = (i16)((q - w + 1) >> 1); d[4 * r + 3] = (i16)((q + w + 1) >> 1);
+        }
+        const int mf = (int)a.q4mf[(0 * 52 + a.qp) * 16] >> 1, bias = (int)a.q4bias[(0 * 52 + a.qp) * 16] << 1;
+        int nz = 0;
+        for (int i = 0; i < 16; i++) { int q = quant_one(d[i], mf, bias); d[i] = (i16)q; nz |= q; }
+        s.nnz[24] = (u8)(nz != 0);
+        if (nz) {
+            for (int i = 0; i < 16; i++) s.lv_dc[i] = d[c_scan4[0][i]];
+            for (int r = 0; r < 4; r++) {
+                int p = d[4 * r] + d[4 * r + 1], q = d[4 * r] - d[4 * r + 1], u = d[4 * r + 2] + d[4 * r + 3], w = d[4 * r + 2] - d[4 * r + 3];
+                t[r] = (i16)(p + u); t[4 + r] = (i16)(p - u); t[8 + r] = (i16)(q - w); t[12 + r] = (i16)(q + w);
+            }
+            for (int r = 0; r < 4; r++) {
+                int p = t[4 * r] + t[4 * r + 1], q = t[4 * r] - t[4 * r + 1], u = t[4 * r + 2] + t[4 * r + 3], w = t[4 * r + 2] - t[4 * r + 3];
+                d[4 * r] = (i16)(p + u); d[4 * r + 1] = (i16)(p - u); d[4 * r + 2] = (i16)(q - w); d[4 * r + 3] = (i16)(q + w);
+            }
+            const int m = a.dq4[0 * 96 + (a.qp % 6) * 16], bits = a.qp / 6 - 6;
+            for (int i = 0; i < 16; i++) s.dc16[i] = (i16)dequant_one(d[i], m, bits);
+        }
+        s.keep8 = cbp; s.nzdc16 = nz != 0;
+    }
+    WAVE_SYNC();
+    const int keep = s.keep8, nzdc = s.nzdc16;
+    if (keep) {
+        if (lane < 16) {
+            int bx, by;
+            sw_blk_xy(lane, bx, by);
+            if (nzdc) s.coef[lane][0] = s.dc16[(by >> 2) * 4 + (bx >> 2)];
+        }
+        WAVE_SYNC();
+        sw_luma4x4_add(s, lane, 0xf);
+    } else if (nzdc) {
+        // add16x16_idct_dc, R/common/dct.c:369-382
+        const int r = lane >> 2, x = (lane & 3) * 4;
+        const int dc = (int)(i16)((s.dc16[(r >> 2) * 4 + (x >> 2)] + 32) >> 6);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { u8 *p = s.fd + FDY + r * FD + x + i; *p = (u8)clip_u8((int)*p + dc); }
+        WAVE_SYNC();
+    }
+    return keep;
+}
+// x264_mb_encode_8x8_chroma; returns cbp_chroma, fills s.nnz[16..23], s.nnz[25..26]
+__device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b_inter, int lane)
+{
+    const int cat = 2 + b_inter, b_decimate = b_inter && a.dct_decimate;
+    const u16 *mf = a.q4mf + (cat * 52 + a.qpc) * 16, *bs = a.q4bias + (cat * 52 + a.qpc) * 16;
+    if (lane < 8) {
+        int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, r[16];
+        const u8 *fe = s.fe + 256 + 64 * ch, *pr = s.fd + (ch ? FDV : FDU);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                r[4 * j + i] = (int)fe[(by + j) * 8 + bx + i] - (int)pr[(by + j) * FD + bx + i];
+        i16 c[16], lv[16];
+        fwd4x4(c, r);
+        s.cdc[lane] = c[0];
+        c[0] = 0;                                     // dct2x2dc takes the DCs out (macroblock.c:73-85)
+        const int *dq = a.dq4 + cat * 96 + (a.qpc % 6) * 16;
+        int nz = 0, bits = a.qpc / 6 - 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[0][i]] : (i16)0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s.lv_cac[16 * lane + i] = lv[i]; s.ccoef[lane][i] = nz ? (i16)dequant_one(c[i], dq[i], bits) : (i16)0; }
+        s.cscore[lane] = (nz ? sw_decimate(lv + 1, 15) : 0) | ((nz != 0) << 8);
+    }
+    WAVE_SYNC();
+    if (lane < 2) {
+        const int ch = lane;
+        int b0 = s.cdc[4 * ch], b1 = s.cdc[4 * ch + 1], b2 = s.cdc[4 * ch + 2], b3 = s.cdc[4 * ch + 3];
+        int a0 = b0 + b1, a1 = b2 + b3, a2 = b0 - b1, a3 = b2 - b3;
+        i16 d2[4] = {(i16)(a0 + a1), (i16)(a0 - a1), (i16)(a2 + a3), (i16)(a2 - a3)};   // [0][0] [0][1] [1][0] [1][1]
+        int nz_dc = 0;
+        for (int i = 0; i < 4; i++) { int q = quant_one(d2[i], (int)mf[0] >> 1, (int)bs[0] << 1); d2[i] = (i16)q; nz_dc |= q; }
+        int score = 0, nz_ac = 0;
+        u8 nzf[4];
+        for (int i = 0; i < 4; i++) { int v = s.cscore[4 * ch + i]; nzf[i] = (u8)(v >> 8); if (v >> 8) { nz_ac = 1; if (b_decimate) score += v & 255; } }
+        int e0 = d2[0] + d2[1], e1 = d2[2] + d2[3], e2 = d2[0] - d2[1], e3 = d2[2] - d2[3];
+        int dmf = a.dq4[cat * 96 + (a.qpc % 6) * 16], qbits = a.qpc / 6 - 5;
+        if (qbits > 0) { dmf <<= qbits; qbits = 0; }
+        int mode;
+        if ((b_decimate && score < 7) || !nz_ac) { nzf[0] = nzf[1] = nzf[2] = nzf[3] = 0; mode = nz_dc ? 1 : 0; }
+        else mode = 2;
+        const bool put = nz_dc != 0;
+        s.lv_cdc[4 * ch] = put ? d2[0] : (i16)0; s.lv_cdc[4 * ch + 1] = put ? d2[2] : (i16)0;
+        s.lv_cdc[4 * ch + 2] = put ? d2[1] : (i16)0; s.lv_cdc[4 * ch + 3] = put ? d2[3] : (i16)0;
+        s.cdcout[4 * ch + 0] = (i16)((e0 + e1) * dmf >> -qbits); s.cdcout[4 * ch + 1] = (i16)((e0 - e1) * dmf >> -qbits);
+        s.cdcout[4 * ch + 2] = (i16)((e2 + e3) * dmf >> -qbits); s.cdcout[4 * ch + 3] = (i16)((e2 - e3) * dmf >> -qbits);
+        if (!nz_dc) s.cdcout[4 * ch] = s.cdcout[4 * ch + 1] = s.cdcout[4 * ch + 2] = s.cdcout[4 * ch + 3] = 0;
+        s.cmode[ch] = mode | (nz_dc ? 16 : 0);
+        for (int i = 0; i < 4; i++) s.nnz[16 + 4 * ch + i] = nzf[i];
+        s.nnz[25 + ch] = (u8)(nz_dc != 0);
+    }
+    WAVE_SYNC();
+    if (lane < 8) {
+        int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, mode = s.cmode[ch] & 15;
+        u8 *pr = s.fd + (ch ? FDV : FDU);
+        if (mode == 2) {
+            int res[16];
+            s.ccoef[lane][0] = s.cdcout[lane];
+            inv4x4(res, s.ccoef[lane]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) { u8 *p = pr + (by + j) * FD + bx + i; *p = (u8)clip_u8((int)*p + res[4 * j + i]); }
+        } else if (mode == 1) {
+            int dc = (int)(i16)((s.cdcout[lane] + 32) >> 6);
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++) { u8 *p = pr + (by + j) * FD + bx + i; *p = (u8)clip_u8((int)*p + dc); }
+        }
+    }
+    WAVE_SYNC();
+    const int m0 = s.cmode[0], m1 = s.cmode[1];
+    return ((m0 & 15) == 2 || (m1 & 15) == 2) ? 2 : (((m0 | m1) & 16) ? 1 : 0);
+}
+// x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883); leaves the P-skip prediction in s.fd
+__device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, const SwArgs &a, int pmx, int pmy, int mbx, int mby,
+                                              ptrdiff_t oy, ptrdiff_t oc, size_t by_, size_t bc_, int lane)
+{
+    const int vx = clip3(pmx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
+    const int vy = clip3(pmy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
+    sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
+    WAVE_SYNC();
+    int score = 0, dc = 0, ssd = 0;
+    if (lane < 24) {
+        const bool luma = lane < 16;
+        int bx, by, r[16];
+        const u8 *fe, *pr; int st;
+        if (luma) { sw_blk_xy(lane, bx, by); fe = s.fe; pr = s.fd + FDY; st = 16; }
+        else { int l = lane - 16, i4 = l & 3; bx = (i4 & 1) * 4; by = (i4 >> 1) * 4; fe = s.fe + 256 + 64 * (l >> 2); pr = s.fd + ((l >> 2) ? FDV : FDU); st = 8; }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                r[4 * j + i] = (int)fe[(by + j) * st + bx + i] - (int)pr[(by + j) * FD + bx + i];
+                ssd += r[4 * j + i] * r[4 * j + i];
+            }
+        i16 c[16], lv[16];
+        fwd4x4(c, r);
+        const int cat = luma ? 1 : 3, q = luma ? a.qp : a.qpc;
+        const u16 *mf = a.q4mf + (cat * 52 + q) * 16, *bs = a.q4bias + (cat * 52 + q) * 16;
+        if (!luma) { dc = c[0]; c[0] = 0; }
+        int nz = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { int qq = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)qq; nz |= qq; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) lv[i] = c[c_scan4[0][i]];
+        if (nz) score = luma ? sw_decimate(lv, 16) : sw_decimate(lv + 1, 15);
+    }
+    int luma_sum = 0, c_sum[2] = {0, 0}, c_ssd[2] = {0, 0}, c_dc[2][4];
+#pragma unroll
+    for (int k = 0; k < 16; k++) luma_sum += __shfl(score, k, 64);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        c_sum[k >> 2] += __shfl(score, 16 + k, 64);
+        c_ssd[k >> 2] += __shfl(ssd, 16 + k, 64);
+        c_dc[k >> 2][k & 3] = __shfl(dc, 16 + k, 64);
+    }
+    int ok = luma_sum < 6;
+    const u16 *mf = a.q4mf + (3 * 52 + a.qpc) * 16, *bs = a.q4bias + (3 * 52 + a.qpc) * 16;
+    for (int ch = 0; ch < 2 && ok; ch++) {
+        if (c_ssd[ch] < a.chroma_skip_thresh) continue;
+        int b0 = c_dc[ch][0], b1 = c_dc[ch][1], b2 = c_dc[ch][2], b3 = c_dc[ch][3];
+        int a0 = b0 + b1, a1 = b2 + b3, a2 = b0 - b1, a3 = b2 - b3;
+        int d2[4] = {(i16)(a0 + a1), (i16)(a0 - a1), (i16)(a2 + a3), (i16)(a2 - a3)};
+        int nzdc = 0;
+        for (int i = 0; i < 4; i++) nzdc |= quant_one(d2[i], (int)mf[0] >> 1, (int)bs[0] << 1);
+        if (nzdc || c_sum[ch] >= 7) ok = 0;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
+{
+    __shared__ SwLds s;
+    const int lane = threadIdx.x;
+    const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
+    if (bz >= a.batch) return;
+    const size_t nmb = (size_t)a.mb_w * a.mb_h, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
+    // batch element
+    a.fy += by_; a.fu += bc_; a.fv += bc_; a.dy += by_; a.du += bc_; a.dv += bc_;
+    a.mb_type += nmb * bz; a.partition += nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz; a.i16mode += nmb * bz;
+    a.chroma_mode += nmb * bz; a.qp_out += nmb * bz; a.t8 += nmb * bz; a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
+    a.cbp += nmb * bz; a.nnz += 27 * nmb * bz; a.luma += 256 * nmb * bz; a.luma_dc += 16 * nmb * bz; a.chroma_dc += 8 * nmb * bz;
+    a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz;
+    if (a.l0_type) { a.l0_type += nmb * bz; a.l0_ref += 4 * nmb * bz; a.l0_mv += 32 * nmb * bz; }
+    int *prog = a.progress + (size_t)bz * a.mb_h;
+    const int satd = a.subme > 1, is_p = a.slice_type == 0;
+    const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me};
+
+    // the left neighbour = this wave's previous macroblock
+    int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0;
+
+    for (int mbx = 0; mbx < a.mb_w; mbx++) {
+        const int mb = mby * a.mb_w + mbx;
+        // ---- wait for the row above: left-top, top and top-right neighbours finished ----
+        if (mby > 0) {
+            const int need = min(mbx + 2, a.mb_w);
+            int spins = 0;
+            for (;;) {
+                int v = __builtin_amdgcn_readfirstlane(sw_load_acq(prog + mby - 1));
+                if ((v & 0xffff) >= need) break;
+                __builtin_amdgcn_s_sleep(8);
+                int ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (ab || ++spins > SW_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+        }
+        const ptrdiff_t oy = (ptrdiff_t)16 * mby * a.sy + 16 * mbx, oc = (ptrdiff_t)8 * mby * a.sc + 8 * mbx;
+        // ---- x264_macroblock_cache_load: pixels ----
+        if (mbx > 0) {      // copy_column8: the column to the left is the previous reconstruction's last column
+            if (lane < 16) s.fd[FDY + lane * FD - 1] = s.fd[FDY + lane * FD + 15];
+            else if (lane < 24) s.fd[FDU + (lane - 16) * FD - 1] = s.fd[FDU + (lane - 16) * FD + 7];
+            else if (lane < 32) s.fd[FDV + (lane - 24) * FD - 1] = s.fd[FDV + (lane - 24) * FD + 7];
+        }
+        {
+            const int r = lane >> 2, x = (lane & 3) * 4, cx = lane & 7, cy = lane >> 3;
+            *(u32 *)(s.fe + r * 16 + x) = *(const u32 *)(a.fy + oy + (ptrdiff_t)r * a.sy + x);
+            s.fe[256 + lane] = a.fu[oc + (ptrdiff_t)cy * a.sc + cx];
+            s.fe[320 + lane] = a.fv[oc + (ptrdiff_t)cy * a.sc + cx];
+        }
+        WAVE_SYNC();
+        if (mby > 0) {      // the row above, still unfiltered: x = -1 .. w*3/2-1
+            if (lane < 25) s.fd[FDY - FD - 1 + lane] = a.dy[oy - a.sy - 1 + lane];
+            else if (lane >= 32 && lane < 45) s.fd[FDU - FD - 1 + (lane - 32)] = a.du[oc - a.sc - 1 + (lane - 32)];
+            else if (lane >= 48 && lane < 61) s.fd[FDV - FD - 1 + (lane - 48)] = a.dv[oc - a.sc - 1 + (lane - 48)];
+        }
+        WAVE_SYNC();
+        // ---- neighbour availability and types ----
+        int nb = 0, type_top = -1, type_topleft = -1, type_topright = -1;
+        if (mby > 0) { nb |= NB_TOP; type_top = a.mb_type[mb - a.mb_w]; }
+        if (mbx > 0) nb |= NB_LEFT;
+        if (mbx < a.mb_w - 1 && mby > 0) { nb |= NB_TOPRIGHT; type_topright = a.mb_type[mb - a.mb_w + 1]; }
+        if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = a.mb_type[mb - a.mb_w - 1]; }
+
+        int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0;
+        int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
+        int stat_intra = 0, stat_inter = 0, analysed = 0;
+
+        // x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610
+        auto analyse_chroma = [&]() {
+            if (satd_chroma < MX_COST_MAX) return;
+            int m[4], n = sw_modes8c(nb, m);
+            for (int i = 0; i < n; i++) {
+                sw_pred8c(s, m[i], lane);
+                int c = sw_cmp_chroma(s, satd, lane) + a.lambda * sw_ue_size(sw_fix8c(m[i]));
+                if (c < satd_chroma) { satd_chroma = c; predc = m[i]; }
+            }
+        };
+        // x264_mb_analyse_intra, :612-658 (16x16 part)
+        auto analyse_intra16 = [&]() {
+            int m[4], n = sw_modes16(nb, m);
+            for (int i = 0; i < n; i++) {
+                sw_pred16(s, m[i], lane);
+                int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m[i]));
+                if (c < satd_i16) { satd_i16 = c; pred16 = m[i]; }
+            }
+        };
+
+        if (!is_p) {
+            analyse_intra16();
+            type = T_I_16x16;
+        } else {
+            // ---- motion neighbours: what cache_load puts around the block (R/common/macroblock.c:1040-1128) ----
+            int ra = left_ref, ax = left_mvx, ay = left_mvy;                 // A
+            int rb = -2, bx = 0, byv = 0, rc = -2, cx = 0, cy = 0;            // B, C (or D)
+            if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = a.ref[o * 4 + 2]; bx = a.mv[(o * 16 + 12) * 2]; byv = a.mv[(o * 16 + 12) * 2 + 1]; }
+            if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = a.ref[o * 4 + 2]; cx = a.mv[(o * 16 + 12) * 2]; cy = a.mv[(o * 16 + 12) * 2 + 1]; }
+            else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = a.ref[o * 4 + 3]; cx = a.mv[(o * 16 + 15) * 2]; cy = a.mv[(o * 16 + 15) * 2 + 1]; }
+            // x264_mb_predict_mv_16x16, :90-128
+            auto predict16 = [&](int i_ref, int &px, int &py) {
+                const int cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
+                if (cnt > 1) { px = sw_median(ax, bx, cx); py = sw_median(ay, byv, cy); }
+                else if (cnt == 1) { if (ra == i_ref) { px = ax; py = ay; } else if (rb == i_ref) { px = bx; py = byv; } else { px = cx; py = cy; } }
+                else if (rb == -2 && rc == -2 && ra != -2) { px = ax; py = ay; }
+                else { px = sw_median(ax, bx, cx); py = sw_median(ay, byv, cy); }
+            };
+            // x264_mb_predict_mv_pskip, :131-149
+            if (ra == -2 || rb == -2 || !(ra | ax | ay) || !(rb | bx | byv)) { pskx = 0; psky = 0; }
+            else predict16(0, pskx, psky);
+
+            int b_skip = 0, try_pskip = 0;
+            if (a.fast_pskip) {
+                if (a.subme >= 3) try_pskip = 1;
+                else if (left_type == T_P_SKIP || type_top == T_P_SKIP || type_topleft == T_P_SKIP || type_topright == T_P_SKIP) {
+                    b_skip = sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane);
+                    skip_mc = b_skip;
+                }
+            }
+            if (b_skip) type = T_P_SKIP;
+            else {
+                // ---- x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1077-1143 ----
+                const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
+                MxCtx c;
+                c.fe = (const u32 *)s.fe; c.fe_u = s.fe + 256; c.fe_v = s.fe + 320; c.sy = a.sy; c.sc = a.sc; c.lane = lane;
+                int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
+                bool early_skip = false;
+                for (int r = 0; r < a.n_refs; r++) {
+                    int mvpx, mvpy;
+                    predict16(r, mvpx, mvpy);
+                    // x264_mb_predict_mv_ref16x16, R/common/macroblock.c:376-437
+                    int n_mvc = 0;
+                    {
+                        const i16 *mvr = a.mvr + (size_t)r * nmb * 2;
+                        const int top = mb - a.mb_w;
+                        WAVE_SYNC();                                   // the previous reference's candidates have been read
+                        // every lane stores the same values: the list is wave-uniform
+#define SETC(vx_, vy_) do { s.mvc[n_mvc][0] = (i16)(vx_); s.mvc[n_mvc][1] = (i16)(vy_); n_mvc++; } while (0)
+                        if ((nb & NB_LEFT) && left_type != T_P_SKIP) SETC(s.left_mvr[r][0], s.left_mvr[r][1]);
+                        if (nb & NB_TOP) {
+                            if (type_top != T_P_SKIP) SETC(mvr[2 * top], mvr[2 * top + 1]);
+                            if ((nb & NB_TOPLEFT) && type_topleft != T_P_SKIP) SETC(mvr[2 * (top - 1)], mvr[2 * (top - 1) + 1]);
+                            if (mbx < a.mb_w - 1 && type_topright != T_P_SKIP) SETC(mvr[2 * (top + 1)], mvr[2 * (top + 1) + 1]);
+                        }
+                        if (a.l0_n_ref0 > 0)
+                            for (int k = 0; k < 3; k++) {
+                                const int dx = k == 1, dy = k == 2;
+                                if ((dx && mbx >= a.mb_w - 1) || (dy && mby >= a.mb_h - 1)) continue;
+                                const int o = mb + dx + dy * a.mb_w, ref_col = a.l0_ref[o * 4];
+                                if (ref_col >= 0) {
+                                    const int scale = a.poc_delta[r] * a.l0_inv_ref_poc[ref_col];
+                                    SETC((a.l0_mv[o * 32] * scale + 128) >> 8, (a.l0_mv[o * 32 + 1] * scale + 128) >> 8);
+                                }
+                            }
+#undef SETC
+                        WAVE_SYNC();
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + by_ + oy;
+                    c.cu = refs.u[r] + bc_ + oc; c.cv = refs.v[r] + bc_ + oc;
+                    c.cmx = a.cost_mv + a.cost_center - mvpx; c.cmy = a.cost_mv + a.cost_center - mvpy;
+                    thresh -= a.ref_cost[r];
+                    int smx, smy, cost_mv;
+                    int cost = me_search_ref16(c, L, mo, mvpx, mvpy, &s.mvc[0][0], n_mvc, a.n_refs > 1 ? &thresh : nullptr, smx, smy, cost_mv);
+                    if (r == 0 && try_pskip && cost - cost_mv < 300 * a.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
+                        if (sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
+                    }
+                    cost += a.ref_cost[r];
+                    thresh += a.ref_cost[r];
+                    if (cost < best) { best = cost; mvx = smx; mvy = smy; ref = r; bmvpx = mvpx; bmvpy = mvpy; }
+                    if (lane == 0) {
+                        a.mvr[((size_t)r * nmb + mb) * 2] = (i16)smx; a.mvr[((size_t)r * nmb + mb) * 2 + 1] = (i16)smy;
+                        s.left_mvr[r][0] = (i16)smx; s.left_mvr[r][1] = (i16)smy;
+                    }
+                }
+                if (early_skip) { type = T_P_SKIP; skip_mc = 1; }
+                else {
+                    type = T_P_L0;
+                    // x264_me_refine_qpel on the winner (analyse.c:2289-2294); the reference cost leaves the sum (me.c:639-640)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c.pl[k] = refs.y[ref][k] + by_ + oy;
+                    c.cu = refs.u[ref] + bc_ + oc; c.cv = refs.v[ref] + bc_ + oc;
+                    c.cmx = a.cost_mv + a.cost_center - bmvpx; c.cmy = a.cost_mv + a.cost_center - bmvpy;
+                    best -= a.ref_cost[ref];
+                    best = me_refine_qpel16(c, L, mo, bmvpx, bmvpy, best, mvx, mvy);
+                    int i_cost = best;
+                    if (a.chroma_me) {
+                        analyse_chroma();
+                        analyse_intra16();
+                        satd_i16 += satd_chroma;
+                    } else
+                        analyse_intra16();
+                    int icost = satd_i16;
+                    stat_inter = i_cost;
+                    if (icost < i_cost) { i_cost = icost; type = T_I_16x16; }
+                    stat_intra = icost; analysed = 1;
+                    stat_inter = type == T_P_L0 ? i_cost : icost;
+                }
+            }
+        }
+        // stat.frame.i_inter_cost takes the chosen cost (analyse.c:2399-2400)
+        (void)analysed;
+
+        // ---- x264_analyse_update_cache + x264_macroblock_encode ----
+        int cbp_luma = 0, cbp_chroma = 0;
+        if (lane < 32) s.nnz[lane] = 0;
+        WAVE_SYNC();
+        if (type == T_P_SKIP) {
+            mvx = pskx; mvy = psky; ref = 0;
+            if (!skip_mc) {
+                const int vx = clip3(mvx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
+                const int vy = clip3(mvy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
+                sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
+                WAVE_SYNC();
+            }
+        } else {
+            if (type == T_I_16x16) {
+                analyse_chroma();
+                sw_pred16(s, pred16, lane);
+                cbp_luma = sw_encode_i16x16(s, a, lane);
+                sw_pred8c(s, predc, lane);
+                cbp_chroma = sw_encode_chroma(s, a, 0, lane);
+            } else {
+                sw_mc16(s, refs, a, ref, mvx, mvy, oy, oc, by_, bc_, lane, true);
+                WAVE_SYNC();
+                cbp_luma = sw_encode_inter_luma(s, a, lane);
+                cbp_chroma = sw_encode_chroma(s, a, 1, lane);
+                if (!(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
+            }
+        }
+        const int intra = IS_INTRA_T(type);
+
+        // ---- x264_macroblock_cache_save: reconstruction, per-macroblock state, levels ----
+        {
+            const int r = lane >> 2, x = (lane & 3) * 4;
+            *(u32 *)(a.dy + oy + (ptrdiff_t)r * a.sy + x) = *(const u32 *)(s.fd + FDY + r * FD + x);
+            if (lane < 32) {
+                const int chn = lane >> 4, l = lane & 15, cr = l >> 1, cx4 = (l & 1) * 4;
+                *(u32 *)((chn ? a.dv : a.du) + oc + (ptrdiff_t)cr * a.sc + cx4) = *(const u32 *)(s.fd + (chn ? FDV : FDU) + cr * FD + cx4);
+            }
+        }
+        if (lane < 16) {
+            a.mv[((size_t)mb * 16 + lane) * 2] = (i16)(intra ? 0 : mvx);
+            a.mv[((size_t)mb * 16 + lane) * 2 + 1] = (i16)(intra ? 0 : mvy);
+            a.i4mode[(size_t)mb * 16 + lane] = 2;
+        }
+        if (lane < 4) a.ref[(size_t)mb * 4 + lane] = (signed char)(is_p ? (intra ? -1 : ref) : -1);
+        if (lane < 27) a.nnz[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
+        if (lane == 0) {
+            const int cbp_dc = a.cabac ? (s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2) : 0;
+            a.mb_type[mb] = (signed char)type;
+            a.partition[mb] = 16;
+            a.i16mode[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
+            a.chroma_mode[mb] = (signed char)(intra ? predc : 0);
+            a.qp_out[mb] = (signed char)a.qp;
+            a.t8[mb] = 0;
+            a.cbp[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
+            a.cost_intra[mb] = stat_intra; a.cost_inter[mb] = stat_inter;
+        }
+        {   // coefficient levels, masked by what the entropy coder reads (cbp, then nnz)
+            const bool coded = type != T_P_SKIP;
+            i16 *ly = a.luma + (size_t)mb * 256, *cac = a.chroma_ac + (size_t)mb * 128;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = lane + 64 * k, blk = i >> 4;
+                ly[i] = (coded && ((cbp_luma >> (blk >> 2)) & 1) && s.nnz[blk]) ? s.lv_y[i] : (i16)0;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = lane + 64 * k, blk = i >> 4;
+                cac[i] = (coded && cbp_chroma == 2 && s.nnz[16 + blk]) ? s.lv_cac[i] : (i16)0;
+            }
+            if (lane < 16) a.luma_dc[(size_t)mb * 16 + lane] = (coded && type == T_I_16x16 && s.nnz[24]) ? s.lv_dc[lane] : (i16)0;
+            if (lane < 8) a.chroma_dc[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
+        }
+        left_type = type; left_ref = is_p ? (intra ? -1 : ref) : -1; left_mvx = intra ? 0 : mvx; left_mvy = intra ? 0 : mvy;
+        // ---- publish: everything this macroblock wrote is visible before the count moves ----
+        __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(prog + mby, mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------ host
+static const int k_lambda_tab[52] = {    // x264_lambda_tab, R/encoder/analyse.c:140-149
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+    6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+static const int k_lambda2_tab[52] = {   // x264_lambda2_tab, :151-159
+    14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1161, 1462, 1843, 2322, 2925,
+    3686, 4644, 5851, 7372, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
+    148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436};
+static const uint8_t k_chroma_qp[52] = {  // i_chroma_qp_table, R/common/macroblock.h
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st)
+{
+    const size_t n = (size_t)c->d.mb_w * c->d.mb_h * c->batch;
+    memset(st, 0, sizeof(*st));
+    struct { void **p; size_t bytes; } items[] = {
+        {(void **)&st->mb_type, n}, {(void **)&st->partition, n}, {(void **)&st->ref, 4 * n}, {(void **)&st->i4mode, 16 * n},
+        {(void **)&st->i16mode, n}, {(void **)&st->chroma_mode, n}, {(void **)&st->qp, n}, {(void **)&st->t8, n},
+        {(void **)&st->mv, 64 * n}, {(void **)&st->mvr, 4 * SW_MAX_REFS * n}, {(void **)&st->cbp, 2 * n}, {(void **)&st->nnz, 27 * n},
+        {(void **)&st->luma, 512 * n}, {(void **)&st->luma_dc, 32 * n}, {(void **)&st->chroma_dc, 16 * n}, {(void **)&st->chroma_ac, 256 * n},
+        {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n},
+        {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}};
+    for (auto &it : items) {
+        HIPCHK(hipMalloc(it.p, it.bytes));
+        HIPCHK(hipMemsetAsync(*it.p, 0, it.bytes, c->stream));
+    }
+    return 0;
+}
+extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st)
+{
+    (void)c;
+    void *ps[] = {st->mb_type, st->partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
+                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->progress};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    memset(st, 0, sizeof(*st));
+}
+
+extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs, int n_refs,
+                                         x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
+                                         x264hip_mb_state *out)
+{
+    const bool is_p = p->slice_type == 0;
+    if (p->slice_type != 0 && p->slice_type != 2) { set_error("slice_sweep: slice type %d not built (0 P, 2 I)", p->slice_type); return -1; }
+    if (is_p && (n_refs < 1 || n_refs > SW_MAX_REFS)) { set_error("slice_sweep: %d references (1..%d)", n_refs, SW_MAX_REFS); return -1; }
+    if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
+    if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
+    if (p->me_method < 0 || p->me_method > 1) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX)", p->me_method); return -1; }
+    if ((p->analyse_inter | p->analyse_intra) != 0 || p->transform8x8) { set_error("slice_sweep: sub-partitions / i4x4 / i8x8 / 8x8dct not built yet"); return -1; }
+    if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
+    if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
+    SwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mb_w = c->d.mb_w; a.mb_h = c->d.mb_h; a.sy = c->d.stride_y; a.sc = c->d.stride_c; a.batch = c->batch; a.batch_pad = (c->batch + 7) & ~7;
+    a.bs_y = c->bs_y; a.bs_c = c->bs_c;
+    a.slice_type = p->slice_type; a.qp = p->qp;
+    int qc = p->qp + p->chroma_qp_offset; qc = qc < 0 ? 0 : qc > 51 ? 51 : qc;
+    a.qpc = k_chroma_qp[qc];
+    a.lambda = k_lambda_tab[p->qp];
+    a.chroma_skip_thresh = (k_lambda2_tab[a.qpc] + 32) >> 6;
+    a.n_refs = is_p ? n_refs : 0;
+    for (int i = 0; i < SW_MAX_REFS; i++) {
+        int x = (n_refs <= 0 ? 1 : n_refs) - 1; x = x > 2 ? 2 : x;
+        // REF_COST: lambda * bs_size_te(x, i), R/encoder/analyse.c:195-197
+        int bits = x == 1 ? 1 : x > 1 ? (i == 0 ? 1 : i < 3 ? 3 : i < 7 ? 5 : 7) : 0;
+        a.ref_cost[i] = a.lambda * bits;
+        a.poc_delta[i] = i < n_refs ? p->poc - p->ref_poc[i] : 0;
+        a.l0_inv_ref_poc[i] = l0 ? l0->inv_ref_poc[i] : 0;
+    }
+    a.l0_n_ref0 = l0 ? l0->n_ref0 : 0;
+    a.me_method = p->me_method; a.me_range = p->me_range; a.subme = p->subme;
+    a.chroma_me = p->chroma_me && is_p && p->subme >= 5;            // h->mb.b_chroma_me, analyse.c:234-235
+    a.fast_pskip = p->fast_pskip; a.dct_decimate = p->dct_decimate; a.cabac = p->cabac; a.mv_range = p->mv_range > 0 ? p->mv_range : 512;
+    a.q4mf = p->quant4_mf; a.q4bias = p->quant4_bias; a.dq4 = p->dequant4_mf;
+    a.cost_mv = p->cost_mv; a.cost_center = p->cost_mv_range;
+    a.fy = fenc->plane[0]; a.fu = fenc->plane[1]; a.fv = fenc->plane[2];
+    a.dy = recon->plane[0]; a.du = recon->plane[1]; a.dv = recon->plane[2];
+    if (l0) { a.l0_type = (const signed char *)l0->mb_type; a.l0_ref = (const signed char *)l0->ref; a.l0_mv = l0->mv; }
+    a.mb_type = (signed char *)out->mb_type; a.partition = (signed char *)out->partition; a.ref = (signed char *)out->ref;
+    a.i4mode = (signed char *)out->i4mode; a.i16mode = (signed char *)out->i16mode; a.chroma_mode = (signed char *)out->chroma_mode;
+    a.qp_out = (signed char *)out->qp; a.t8 = (signed char *)out->t8; a.mv = out->mv; a.mvr = out->mvr; a.cbp = out->cbp; a.nnz = out->nnz;
+    a.luma = out->luma; a.luma_dc = out->luma_dc; a.chroma_dc = out->chroma_dc; a.chroma_ac = out->chroma_ac;
+    a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter;
+    a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
+    SwRefs t;
+    for (int i = 0; i < SW_MAX_REFS; i++) {
+        const x264hip_picture *r = (is_p && n_refs > 0) ? refs[i < n_refs ? i : 0] : fenc;
+        for (int k = 0; k < 4; k++) t.y[i][k] = r->filtered[k];
+        t.u[i] = r->plane[1]; t.v[i] = r->plane[2];
+    }
+    HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
+    hipLaunchKernelGGL(k_slice_sweep, dim3((unsigned)(a.batch_pad * a.mb_h)), dim3(64), 0, c->stream, a, t);
+    HIPCHK(hipGetLastError());
+    // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
+    out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;
+    for (int i = 0; i < SW_MAX_REFS; i++) {
+        int delta = i < n_refs && is_p ? p->poc - p->ref_poc[i] : 0;
+        out->inv_ref_poc[i] = delta ? (256 + delta / 2) / delta : 0;
+    }
+    return 0;
+}
+
+extern "C" int x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st)
+{
+    int flag = 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(&flag, st->progress + (size_t)c->d.mb_h * c->batch, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) { set_error("slice_sweep: a wavefront gave up waiting for its neighbours (aborted frame)"); return -1; }
+    return 0;
+}

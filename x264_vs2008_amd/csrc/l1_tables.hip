@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "device_prims.h"
+#include "intra_pred.h"
 #include "internal.h"
 
 using namespace x264hip;
@@ -47,109 +48,6 @@ __device__ __forceinline__ void blk4_xy(int k, int &x, int &y)
 {
     x = ((k >> 2) & 1) * 8 + (k & 1) * 4;
     y = (k >> 3) * 8 + ((k >> 1) & 1) * 4;
-}
-
-// Directional intra prediction of pixel (x,y) of an NxN block from an edge
-// array e[] with e[n-1-k] = left k, e[n] = top-left, e[n+1+k] = top k
-// (H.264 8.3.1.2 / 8.3.2.2; R/common/predict.c:398-497, :618-751).
-__device__ int dir_pred_px(int n, int mode, const int *e, int x, int y)
-{
-#define EL(k) e[n - 1 - (k)]
-#define ET(k) e[n + 1 + (k)]
-#define EZ(k) e[n + (k)]
-#define F1(a, b) (((a) + (b) + 1) >> 1)
-#define F2(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
-    switch (mode) {
-    case 3:
-        if (x == n - 1 && y == n - 1) return F2(ET(2 * n - 2), ET(2 * n - 1), ET(2 * n - 1));
-        return F2(ET(x + y), ET(x + y + 1), ET(x + y + 2));
-    case 4:
-        return F2(EZ(x - y - 1), EZ(x - y), EZ(x - y + 1));
-    case 5: {
-        int z = 2 * x - y, i = x - (y >> 1);
-        if (z >= 0) return (z & 1) ? F2(EZ(i - 1), EZ(i), EZ(i + 1)) : F1(EZ(i), EZ(i + 1));
-        if (z == -1) return F2(EL(0), EZ(0), ET(0));
-        return F2(EL(y - 2 * x - 1), EL(y - 2 * x - 2), EL(y - 2 * x - 3));
-    }
-    case 6: {
-        int z = 2 * y - x, i = y - (x >> 1);
-        if (z >= 0) return (z & 1) ? F2(EZ(-i + 1), EZ(-i), EZ(-i - 1)) : F1(EZ(-i), EZ(-i - 1));
-        if (z == -1) return F2(EL(0), EZ(0), ET(0));
-        return F2(ET(x - 2 * y - 1), ET(x - 2 * y - 2), ET(x - 2 * y - 3));
-    }
-    case 7: {
-        int i = x + (y >> 1);
-        return (y & 1) ? F2(ET(i), ET(i + 1), ET(i + 2)) : F1(ET(i), ET(i + 1));
-    }
-    default: {
-        int z = x + 2 * y, last = 2 * n - 3, i = y + (x >> 1);
-        if (z > last) return EL(n - 1);
-        if (z == last) return F2(EL(n - 2), EL(n - 1), EL(n - 1));
-        return (z & 1) ? F2(EL(i), EL(i + 1), EL(i + 2)) : F1(EL(i), EL(i + 1));
-    }
-    }
-#undef EL
-#undef ET
-#undef EZ
-}
-
-// prediction of pixel (x,y) for the table families 16x16 (fam 0), 8x8 chroma
-// (fam 1), 4x4 (fam 2).  s points at the block inside a local buffer of
-// stride ls that holds row -1 and column -1.  Mode numbers are the table
-// slots (R/common/predict.h:31-93).
-__device__ int pred_px(int fam, int mode, const u8 *s, int ls, int x, int y)
-{
-#define PX(xx, yy) ((int)s[(xx) + (yy) * ls])
-    const int n = fam == 0 ? 16 : fam == 1 ? 8 : 4;
-    if (fam == 0 || fam == 1) {
-        // slot order differs: 16x16 = V,H,DC,P,DCL,DCT,DC128; 8x8c = DC,H,V,P,DCL,DCT,DC128
-        int kind = mode;   // canonical: 0 V 1 H 2 DC 3 P 4 DCL 5 DCT 6 128
-        if (fam == 1) kind = mode == 0 ? 2 : mode == 2 ? 0 : mode;
-        if (kind == 0) return PX(x, -1);
-        if (kind == 1) return PX(-1, y);
-        if (kind == 6) return 128;
-        if (kind == 3) {
-            int half = n / 2, H = 0, V = 0;
-            for (int i = 1; i <= half; i++) {
-                H += i * (PX(half - 1 + i, -1) - PX(half - 1 - i, -1));
-                V += i * (PX(-1, half - 1 + i) - PX(-1, half - 1 - i));
-            }
-            int coef = fam == 0 ? 5 : 17, sh = fam == 0 ? 6 : 5;
-            int a = 16 * (PX(-1, n - 1) + PX(n - 1, -1));
-            int b = (coef * H + (1 << (sh - 1))) >> sh, c = (coef * V + (1 << (sh - 1))) >> sh;
-            return clip_u8((a - (half - 1) * (b + c) + 16 + b * x + c * y) >> 5);
-        }
-        if (fam == 0) {
-            int t = 0, l = 0;
-            for (int i = 0; i < 16; i++) { t += PX(i, -1); l += PX(-1, i); }
-            if (kind == 2) return (t + l + 16) >> 5;
-            if (kind == 4) return (l + 8) >> 4;
-            return (t + 8) >> 4;
-        }
-        // chroma: per-quadrant DC rules (R/common/predict.c:176-262)
-        int qx = x >> 2, qy = y >> 2, t = 0, l = 0;
-        for (int i = 0; i < 4; i++) { t += PX(4 * qx + i, -1); l += PX(-1, 4 * qy + i); }
-        if (kind == 4) return (l + 2) >> 2;
-        if (kind == 5) return (t + 2) >> 2;
-        if (qx == qy) return (t + l + 4) >> 3;
-        return qx ? (t + 2) >> 2 : (l + 2) >> 2;
-    }
-    // 4x4: V,H,DC,DDL,DDR,VR,HD,VL,HU,DCL,DCT,DC128
-    if (mode == 0) return PX(x, -1);
-    if (mode == 1) return PX(-1, y);
-    if (mode == 11) return 128;
-    if (mode == 2 || mode == 9 || mode == 10) {
-        int t = 0, l = 0;
-        for (int i = 0; i < 4; i++) { t += PX(i, -1); l += PX(-1, i); }
-        if (mode == 2) return (t + l + 4) >> 3;
-        return mode == 9 ? (l + 2) >> 2 : (t + 2) >> 2;
-    }
-    int e[13];
-    for (int k = 0; k < 4; k++) e[3 - k] = PX(-1, k);
-    e[4] = PX(-1, -1);
-    for (int k = 0; k < 8; k++) e[5 + k] = PX(k, -1);
-    return dir_pred_px(4, mode, e, x, y);
-#undef PX
 }
 
 // one line of a deblocking edge; v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3

@@ -1,0 +1,154 @@
+"""Host-side mirror of the macroblock sweep (include/x264hip.h: x264hip_slice_sweep_frame) and a
+chain encoder around it: I frame, then P frames, every frame kept as reference -- the sequencing
+x264_encoder_encode / x264_slice_write / x264_fdec_filter_row do on the host
+(R/encoder/encoder.c:1316-1560, 1141-1291, 983-1056), restricted to CQP without B-frames.
+
+The arithmetic lives in the HIP library; this file only orders launches and owns device buffers.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from .frame import CqmDevice, DeblockParams, DeviceArray, FrameCtx, cost_mv_table
+
+SLICE_P, SLICE_I = 0, 2
+I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = range(7)
+LAMBDA_TAB = (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+              6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91)   # R/encoder/analyse.c:140-149
+COST_SPAN = 2 * 4 * 2048      # p_cost_mv reaches +-2*4*2048 quarter-pels (R/encoder/analyse.c:191-198)
+
+STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("ref", np.int8, (4,)), ("i4mode", np.int8, (16,)),
+                ("i16mode", np.int8, ()), ("chroma_mode", np.int8, ()), ("qp", np.int8, ()), ("t8", np.int8, ()),
+                ("mv", np.int16, (16, 2)), ("mvr", np.int16, None), ("cbp", np.int16, ()), ("nnz", np.uint8, (27,)),
+                ("luma", np.int16, (256,)), ("luma_dc", np.int16, (16,)), ("chroma_dc", np.int16, (8,)), ("chroma_ac", np.int16, (128,)),
+                ("cost_intra", np.int32, ()), ("cost_inter", np.int32, ())]
+
+
+class MbState(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in STATE_FIELDS] + \
+               [("progress", C.c_void_p), ("poc", C.c_int), ("n_ref0", C.c_int), ("inv_ref_poc", C.c_int * 8)]
+
+
+class SliceParams(C.Structure):
+    _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("chroma_qp_offset", C.c_int),
+                ("me_method", C.c_int), ("me_range", C.c_int), ("subme", C.c_int), ("chroma_me", C.c_int), ("mv_range", C.c_int),
+                ("fast_pskip", C.c_int), ("dct_decimate", C.c_int), ("cabac", C.c_int), ("transform8x8", C.c_int),
+                ("analyse_inter", C.c_int), ("analyse_intra", C.c_int),
+                ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p), ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
+                ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
+                ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8)]
+
+
+def iframe_qp(qp, ip_factor=1.4):
+    """rc->qp_constant[SLICE_TYPE_I] (R/encoder/ratecontrol.c:370-372): the float ip_factor's log, truncated."""
+    return min(max(int(qp - 6.0 * math.log(float(np.float32(ip_factor))) / math.log(2.0) + 0.5), 0), 51)
+
+
+class DeviceState:
+    """One x264hip_mb_state: allocated by the library, read back as numpy arrays [batch][n][...]."""
+
+    def __init__(self, ctx):
+        self.ctx, self.st = ctx, MbState()
+        ctx.check(ctx.lib.x264hip_mb_state_alloc(ctx.h, C.byref(self.st)), "mb_state_alloc")
+
+    def get(self, name):
+        d, B = self.ctx.dims, self.ctx.batch
+        n = d.mb_w * d.mb_h
+        _, dt, tail = next(f for f in STATE_FIELDS if f[0] == name)
+        shape = (B, 8, n, 2) if name == "mvr" else (B, n) + tail
+        out = np.zeros(shape, dt)
+        rc = self.ctx.lib.x264hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(getattr(self.st, name)), C.c_size_t(out.nbytes))
+        assert rc == 0
+        return out
+
+    def free(self):
+        self.ctx.lib.x264hip_mb_state_free(self.ctx.h, C.byref(self.st))
+
+
+class ChainEncoder:
+    """Encodes `batch` independent chains in lock step, frame t of every chain per sweep launch."""
+
+    def __init__(self, lib, width, height, cqm, batch=1, qp=26, me_method=0, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
+                 transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
+                 chroma_qp_offset=0, keyint=0):
+        self.lib = lib
+        self.ctx = FrameCtx(lib, width, height, batch=batch)
+        self.opt = dict(qp=qp, me_method=me_method, me_range=me_range, subme=subme, n_refs=n_refs, inter=inter, intra=intra,
+                        transform8x8=transform8x8, fast_pskip=fast_pskip, dct_decimate=dct_decimate, chroma_me=chroma_me, cabac=cabac,
+                        deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint)
+        self.cqm = CqmDevice(lib, cqm)
+        self.cost = {}
+        self.fenc = self.ctx.new_picture()
+        self.pool = [self.ctx.new_picture() for _ in range(n_refs + 1)]
+        self.states = [DeviceState(self.ctx) for _ in range(n_refs + 1)]
+        self.refs = []                 # [(picture, state, poc)], newest first
+        self.t = 0
+        self.last_idr = 0
+
+    def cost_table(self, qp):
+        if qp not in self.cost:
+            tab = cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)
+            self.cost[qp] = DeviceArray(self.lib, tab.shape, np.uint16, tab)
+        return self.cost[qp]
+
+    def upload(self, y, u, v, b=0):
+        self.ctx.upload(self.fenc, y, u, v, b=b)
+
+    def encode_frame(self):
+        """Sweep + loop filter + reference preparation for the frame uploaded to every batch element.
+        Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync()."""
+        L, c, o = self.lib, self.ctx, self.opt
+        idr = (self.t % o["keyint"] == 0) if o["keyint"] > 0 else self.t == 0
+        if idr:
+            self.refs, self.last_idr = [], self.t
+        used = [r[0] for r in self.refs]
+        pic_i = next(i for i, p in enumerate(self.pool) if not any(p is q for q in used))
+        recon, state = self.pool[pic_i], self.states[pic_i]
+        refs = self.refs[:o["n_refs"]]
+        stype = SLICE_I if idr else SLICE_P
+        qp = iframe_qp(o["qp"]) if idr else o["qp"]
+        poc = 2 * (self.t - self.last_idr)
+        b = self.cqm.bufs
+        p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
+                        subme=o["subme"], chroma_me=o["chroma_me"], mv_range=512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
+                        cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
+                        quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
+                        quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
+                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc)
+        for i, r in enumerate(refs):
+            p.ref_poc[i] = r[2]
+        arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None
+        l0 = C.byref(refs[0][1].st) if refs else None
+        c.check(L.x264hip_slice_sweep_frame(c.h, C.byref(self.fenc), arr, len(refs), C.byref(recon), C.byref(p), l0, C.byref(state.st)),
+                "slice_sweep_frame")
+        self.unfiltered = None
+        self.last = (recon, state)
+        return stype, qp, state
+
+    def finish_frame(self):
+        """x264_fdec_filter_row for the whole frame: loop filter, borders, half-pel planes; then the frame joins the reference list."""
+        L, c, o = self.lib, self.ctx, self.opt
+        recon, state = self.last
+        if o["deblock"]:
+            s = state.st
+            dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
+                               alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1)
+            c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
+        c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
+        c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
+        self.refs.insert(0, (recon, state, 2 * (self.t - self.last_idr)))
+        del self.refs[o["n_refs"]:]
+        self.t += 1
+
+    def status(self):
+        c = self.ctx
+        c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(self.last[1].st)), "slice_sweep_status")
+
+    def close(self):
+        for s in self.states:
+            s.free()
+        for d in self.cost.values():
+            d.free()
+        self.cqm.free()
+        self.ctx.close()

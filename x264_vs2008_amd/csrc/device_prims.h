@@ -285,3 +285,29 @@ static __constant__ u8 c_qpel_b[16] = {0,0,0,0, 2,2,3,2, 2,2,3,2, 2,2,3,2};
 static __constant__ u8 c_decimate4[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static __constant__ u8 c_decimate8[64] = {3,3,3,3,2,2,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,
     0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+
+// ---- register-only scan + decimate (no indexed private arrays, so nothing spills to scratch) -------
+// frame zigzag of a 4x4 block held in c[16] (reference's transposed storage), R/common/dct.c:488-500
+#define SCAN4_FRAME(lv, c) do { \
+    lv[0] = c[0]; lv[1] = c[4]; lv[2] = c[1]; lv[3] = c[2]; lv[4] = c[5]; lv[5] = c[8]; lv[6] = c[12]; lv[7] = c[9]; \
+    lv[8] = c[6]; lv[9] = c[3]; lv[10] = c[7]; lv[11] = c[10]; lv[12] = c[13]; lv[13] = c[14]; lv[14] = c[11]; lv[15] = c[15]; } while (0)
+// JVT-B118 score (R/common/quant.c:203-239) from bit masks of the scanned levels: bit i of nzm = level i
+// non-zero, of big = |level i| > 1.  Pass the masks shifted right by one for decimate_score15.
+__device__ __forceinline__ int decimate_masks(u32 nzm, u32 big)
+{
+    if (big) return 9;
+    int score = 0, prev = 32;
+    // walk the set bits from the highest: run = zeros between consecutive non-zero levels
+    while (nzm) {
+        const int idx = 31 - __clz(nzm);
+        nzm &= ~(1u << idx);
+        const int below = nzm ? 31 - __clz(nzm) : -1, run = idx - below - 1;
+        score += (run < 1) + (run < 3) + (run < 6);
+        prev = idx;
+    }
+    (void)prev;
+    return score;
+}
+#define LEVEL_MASKS(lv, nzm, big) do { nzm = 0; big = 0; _Pragma("unroll") for (int i_ = 0; i_ < 16; i_++) { \
+    nzm |= (u32)(lv[i_] != 0) << i_; big |= (u32)((unsigned)(lv[i_] + 1) > 2u) << i_; } } while (0)
+

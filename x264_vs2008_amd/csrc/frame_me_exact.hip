@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
                                                                int *__restrict__ out_cost, int *__restrict__ best_out)
 {
     __shared__ u32 s_fe[MX_WAVES][64];
-    __shared__ u8 s_fc[MX_WAVES][128];
+    __shared__ __attribute__((aligned(16))) u8 s_fc[MX_WAVES][128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int mb = xcd_band_order(blockIdx.x, gridDim.x) * MX_WAVES + wave;
     if (mb >= g.mb_w * g.mb_h) return;
@@ -73,10 +73,10 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
         c.cu = refs.u[r] + g.bs_c * bz + oc; c.cv = refs.v[r] + g.bs_c * bz + oc;
         const i16 *mvp = mvp_in + ((size_t)mb * g.n_refs + r) * 2;
         const int mvpx = mvp[0], mvpy = mvp[1];
-        c.cmx = cost_mv + g.cost_center - mvpx; c.cmy = cost_mv + g.cost_center - mvpy;
+        c.cost_g = cost_mv + g.cost_center; c.cost_l = nullptr; c.mvpx = mvpx; c.mvpy = mvpy;
         thresh -= g.ref_cost[r];
         int mvx, mvy, cost_mv_out;
-        int mcost = me_search_ref16(c, L, o, mvpx, mvpy, mvc_in + ((size_t)mb * g.n_refs + r) * 16, n_mvc_in[(size_t)mb * g.n_refs + r],
+        int mcost = me_search_ref16(c, L, o, mvc_in + ((size_t)mb * g.n_refs + r) * 16, n_mvc_in[(size_t)mb * g.n_refs + r],
                                     g.n_refs > 1 ? &thresh : nullptr, mvx, mvy, cost_mv_out);
         mcost += g.ref_cost[r];
         thresh += g.ref_cost[r];

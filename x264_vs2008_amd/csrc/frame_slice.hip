@@ -64,10 +64,11 @@ struct SwArgs {
     i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
     int *cost_intra, *cost_inter;
     int *progress, *abort_flag;
+    long long *prof;            // optional [batch][mb_h][8] accumulated wall-clock ticks per phase (developer aid)
 };
 
 struct SwLds {
-    u8 fe[384];                 // source: Y 16x16 | U 8x8 | V 8x8
+    __attribute__((aligned(16))) u8 fe[384];   // source: Y 16x16 | U 8x8 | V 8x8
     u8 fd[27 * FD];             // prediction / reconstruction with its borders, fdec_buf layout
     i16 coef[16][16];           // dequantised luma coefficients
     i16 ccoef[8][16];           // dequantised chroma AC
@@ -78,6 +79,10 @@ struct SwLds {
     u8 nnz[32];
     i16 mvc[8][2];
     i16 left_mvr[SW_MAX_REFS][2];
+    // this frame's quantiser rows (cat 0 intra Y, 1 inter Y at qp; 2 intra C, 3 inter C at the chroma qp) and the centre of p_cost_mv
+    u16 qmf[4][16], qbias[4][16];
+    int qdq[4][16];
+    i16 costl[2 * MX_COST_LDS + 2];
 };
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
@@ -175,12 +180,34 @@ __device__ __forceinline__ int sw_cmp_chroma(const SwLds &s, int satd, int lane)
 }
 
 // ---- intra prediction into s.fd ----------------------------------------------------------------
+// x264_predict_16x16_* (R/common/predict.c:52-170): the sums the DC and plane modes need are reduced
+// across the wave once per call instead of per pixel
 __device__ __forceinline__ void sw_pred16(SwLds &s, int mode, int lane)
 {
     const int r = lane >> 2, x = (lane & 3) * 4;
+    const u8 *top = s.fd + FDY - FD, *left = s.fd + FDY - 1;
     int v[4];
+    if (mode == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = pred_px(0, mode, s.fd + FDY, FD, x + i, r);
+        for (int i = 0; i < 4; i++) v[i] = top[x + i];
+    } else if (mode == 1) {
+        v[0] = v[1] = v[2] = v[3] = left[r * FD];
+    } else if (mode == 3) {
+        int h = 0, w = 0;
+        if (lane < 8) { h = (lane + 1) * ((int)top[8 + lane] - (int)top[6 - lane]); w = (lane + 1) * ((int)left[(8 + lane) * FD] - (int)left[(6 - lane) * FD]); }
+        const int H = wave_sum(h), V = wave_sum(w);
+        const int a = 16 * ((int)left[15 * FD] + (int)top[15]), b = (5 * H + 32) >> 6, c = (5 * V + 32) >> 6;
+        const int i00 = a - 7 * b - 7 * c + 16 + c * r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = clip_u8((i00 + b * (x + i)) >> 5);
+    } else {
+        int dc = 128;
+        if (mode != 6) {
+            const int t = wave_sum(lane < 16 ? (int)top[lane] : 0), l = wave_sum(lane < 16 ? (int)left[lane * FD] : 0);
+            dc = mode == 2 ? (t + l + 16) >> 5 : mode == 4 ? (l + 8) >> 4 : (t + 8) >> 4;
+        }
+        v[0] = v[1] = v[2] = v[3] = dc;
+    }
     WAVE_SYNC();
 #pragma unroll
     for (int i = 0; i < 4; i++) s.fd[FDY + r * FD + x + i] = (u8)v[i];
@@ -228,16 +255,17 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int ca
         i16 c[16], lv[16];
         fwd4x4(c, r);
         if (dc_out) { s.dc16[(by >> 2) * 4 + (bx >> 2)] = c[0]; c[0] = 0; }
-        const u16 *mf = a.q4mf + (cat * 52 + a.qp) * 16, *bs = a.q4bias + (cat * 52 + a.qp) * 16;
-        const int *dq = a.dq4 + cat * 96 + (a.qp % 6) * 16;
+        const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
+        const int *dq = s.qdq[cat];
         int nz = 0, bits = a.qp / 6 - 4;
 #pragma unroll
         for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
-#pragma unroll
-        for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[0][i]] : (i16)0;
+        SCAN4_FRAME(lv, c);
+        u32 nzm, big;
+        LEVEL_MASKS(lv, nzm, big);
 #pragma unroll
         for (int i = 0; i < 16; i++) { s.lv_y[16 * lane + i] = lv[i]; s.coef[lane][i] = (i16)dequant_one(c[i], dq[i], bits); }
-        s.score[lane] = (nz ? (dc_out ? sw_decimate(lv + 1, 15) : sw_decimate(lv, 16)) : 0) | ((nz != 0) << 8);
+        s.score[lane] = (nz ? (dc_out ? decimate_masks(nzm >> 1, big >> 1) : decimate_masks(nzm, big)) : 0) | ((nz != 0) << 8);
     }
     WAVE_SYNC();
 }
@@ -299,7 +327,9 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
         if (score < 6) { cbp = 0; for (int i = 0; i < 16; i++) s.nnz[i] = 0; }
         // dct4x4dc (R/common/dct.c:39-71), quant_4x4_dc, scan, idct4x4dc, dequant_4x4_dc (quant.c:151-178)
         i16 d[16], t[16];
+#pragma unroll
         for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
+#pragma unroll
         for (int r = 0; r < 4; r++) {
             int p = d[4 * r] + d[4 * r + 1], q = d[4 * r] - d[4 * r + 1], u = d[4 * r + 2] + d[4 * r + 3], w = d[4 * r + 2] - d[4 * r + 3];
             t[r] = (i16)(p + u); t[4 + r] = (i16)(p - u); t[8 + r] = (i16)(q - w); t[12 + r] = (i16)(q + w);
@@ -309,12 +339,14 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
             d[4 * r] = (i16)((p + u + 1) >> 1); d[4 * r + 1] = (i16)((p - u + 1) >> 1);
             d[4 * r + 2] = (i16)((q - w + 1) >> 1); d[4 * r + 3] = (i16)((q + w + 1) >> 1);
         }
-        const int mf = (int)a.q4mf[(0 * 52 + a.qp) * 16] >> 1, bias = (int)a.q4bias[(0 * 52 + a.qp) * 16] << 1;
+        const int mf = (int)s.qmf[0][0] >> 1, bias = (int)s.qbias[0][0] << 1;
         int nz = 0;
         for (int i = 0; i < 16; i++) { int q = quant_one(d[i], mf, bias); d[i] = (i16)q; nz |= q; }
         s.nnz[24] = (u8)(nz != 0);
         if (nz) {
-            for (int i = 0; i < 16; i++) s.lv_dc[i] = d[c_scan4[0][i]];
+            { i16 lvd[16]; SCAN4_FRAME(lvd, d);
+#pragma unroll
+              for (int i = 0; i < 16; i++) s.lv_dc[i] = lvd[i]; }
             for (int r = 0; r < 4; r++) {
                 int p = d[4 * r] + d[4 * r + 1], q = d[4 * r] - d[4 * r + 1], u = d[4 * r + 2] + d[4 * r + 3], w = d[4 * r + 2] - d[4 * r + 3];
                 t[r] = (i16)(p + u); t[4 + r] = (i16)(p - u); t[8 + r] = (i16)(q - w); t[12 + r] = (i16)(q + w);
@@ -323,7 +355,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
                 int p = t[4 * r] + t[4 * r + 1], q = t[4 * r] - t[4 * r + 1], u = t[4 * r + 2] + t[4 * r + 3], w = t[4 * r + 2] - t[4 * r + 3];
                 d[4 * r] = (i16)(p + u); d[4 * r + 1] = (i16)(p - u); d[4 * r + 2] = (i16)(q - w); d[4 * r + 3] = (i16)(q + w);
             }
-            const int m = a.dq4[0 * 96 + (a.qp % 6) * 16], bits = a.qp / 6 - 6;
+            const int m = s.qdq[0][0], bits = a.qp / 6 - 6;
             for (int i = 0; i < 16; i++) s.dc16[i] = (i16)dequant_one(d[i], m, bits);
         }
         s.keep8 = cbp; s.nzdc16 = nz != 0;
@@ -352,7 +384,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
 __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b_inter, int lane)
 {
     const int cat = 2 + b_inter, b_decimate = b_inter && a.dct_decimate;
-    const u16 *mf = a.q4mf + (cat * 52 + a.qpc) * 16, *bs = a.q4bias + (cat * 52 + a.qpc) * 16;
+    const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
     if (lane < 8) {
         int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, r[16];
         const u8 *fe = s.fe + 256 + 64 * ch, *pr = s.fd + (ch ? FDV : FDU);
@@ -365,15 +397,16 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
         fwd4x4(c, r);
         s.cdc[lane] = c[0];
         c[0] = 0;                                     // dct2x2dc takes the DCs out (macroblock.c:73-85)
-        const int *dq = a.dq4 + cat * 96 + (a.qpc % 6) * 16;
+        const int *dq = s.qdq[cat];
         int nz = 0, bits = a.qpc / 6 - 4;
 #pragma unroll
         for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
-#pragma unroll
-        for (int i = 0; i < 16; i++) lv[i] = nz ? c[c_scan4[0][i]] : (i16)0;
+        SCAN4_FRAME(lv, c);
+        u32 nzm, big;
+        LEVEL_MASKS(lv, nzm, big);
 #pragma unroll
         for (int i = 0; i < 16; i++) { s.lv_cac[16 * lane + i] = lv[i]; s.ccoef[lane][i] = nz ? (i16)dequant_one(c[i], dq[i], bits) : (i16)0; }
-        s.cscore[lane] = (nz ? sw_decimate(lv + 1, 15) : 0) | ((nz != 0) << 8);
+        s.cscore[lane] = (nz ? decimate_masks(nzm >> 1, big >> 1) : 0) | ((nz != 0) << 8);
     }
     WAVE_SYNC();
     if (lane < 2) {
@@ -387,7 +420,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
         u8 nzf[4];
         for (int i = 0; i < 4; i++) { int v = s.cscore[4 * ch + i]; nzf[i] = (u8)(v >> 8); if (v >> 8) { nz_ac = 1; if (b_decimate) score += v & 255; } }
         int e0 = d2[0] + d2[1], e1 = d2[2] + d2[3], e2 = d2[0] - d2[1], e3 = d2[2] - d2[3];
-        int dmf = a.dq4[cat * 96 + (a.qpc % 6) * 16], qbits = a.qpc / 6 - 5;
+        int dmf = s.qdq[cat][0], qbits = a.qpc / 6 - 5;
         if (qbits > 0) { dmf <<= qbits; qbits = 0; }
         int mode;
         if ((b_decimate && score < 7) || !nz_ac) { nzf[0] = nzf[1] = nzf[2] = nzf[3] = 0; mode = nz_dc ? 1 : 0; }
@@ -448,15 +481,16 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
             }
         i16 c[16], lv[16];
         fwd4x4(c, r);
-        const int cat = luma ? 1 : 3, q = luma ? a.qp : a.qpc;
-        const u16 *mf = a.q4mf + (cat * 52 + q) * 16, *bs = a.q4bias + (cat * 52 + q) * 16;
+        const int cat = luma ? 1 : 3;
+        const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
         if (!luma) { dc = c[0]; c[0] = 0; }
         int nz = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) { int qq = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)qq; nz |= qq; }
-#pragma unroll
-        for (int i = 0; i < 16; i++) lv[i] = c[c_scan4[0][i]];
-        if (nz) score = luma ? sw_decimate(lv, 16) : sw_decimate(lv + 1, 15);
+        SCAN4_FRAME(lv, c);
+        u32 nzm, big;
+        LEVEL_MASKS(lv, nzm, big);
+        if (nz) score = luma ? decimate_masks(nzm, big) : decimate_masks(nzm >> 1, big >> 1);
     }
     int luma_sum = 0, c_sum[2] = {0, 0}, c_ssd[2] = {0, 0}, c_dc[2][4];
 #pragma unroll
@@ -468,7 +502,7 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
         c_dc[k >> 2][k & 3] = __shfl(dc, 16 + k, 64);
     }
     int ok = luma_sum < 6;
-    const u16 *mf = a.q4mf + (3 * 52 + a.qpc) * 16, *bs = a.q4bias + (3 * 52 + a.qpc) * 16;
+    const u16 *mf = s.qmf[3], *bs = s.qbias[3];
     for (int ch = 0; ch < 2 && ok; ch++) {
         if (c_ssd[ch] < a.chroma_skip_thresh) continue;
         int b0 = c_dc[ch][0], b1 = c_dc[ch][1], b2 = c_dc[ch][2], b3 = c_dc[ch][3];
@@ -500,7 +534,17 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
     int *prog = a.progress + (size_t)bz * a.mb_h;
     const int satd = a.subme > 1, is_p = a.slice_type == 0;
     const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me};
+    {   // tables that every macroblock of the row reads: into LDS once
+        const int cat = lane >> 4, i = lane & 15, q = cat < 2 ? a.qp : a.qpc;
+        s.qmf[cat][i] = a.q4mf[(cat * 52 + q) * 16 + i]; s.qbias[cat][i] = a.q4bias[(cat * 52 + q) * 16 + i];
+        s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
+        if (is_p)
+            for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = a.cost_mv[a.cost_center - MX_COST_LDS + k];
+    }
+    WAVE_SYNC();
 
+    long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptime = a.prof ? (long long)wall_clock64() : 0;
+#define PROF(k_) do { if (a.prof) { long long now_ = (long long)wall_clock64(); pacc[k_] += now_ - ptime; ptime = now_; } } while (0)
     // the left neighbour = this wave's previous macroblock
     int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0;
 
@@ -521,6 +565,7 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
                 }
             }
         }
+        PROF(0);
         const ptrdiff_t oy = (ptrdiff_t)16 * mby * a.sy + 16 * mbx, oc = (ptrdiff_t)8 * mby * a.sc + 8 * mbx;
         // ---- x264_macroblock_cache_load: pixels ----
         if (mbx > 0) {      // copy_column8: the column to the left is the previous reconstruction's last column
@@ -541,6 +586,7 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
             else if (lane >= 48 && lane < 61) s.fd[FDV - FD - 1 + (lane - 48)] = a.dv[oc - a.sc - 1 + (lane - 48)];
         }
         WAVE_SYNC();
+        PROF(1);
         // ---- neighbour availability and types ----
         int nb = 0, type_top = -1, type_topleft = -1, type_topright = -1;
         if (mby > 0) { nb |= NB_TOP; type_top = a.mb_type[mb - a.mb_w]; }
@@ -608,6 +654,7 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
                 const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
                 MxCtx c;
                 c.fe = (const u32 *)s.fe; c.fe_u = s.fe + 256; c.fe_v = s.fe + 320; c.sy = a.sy; c.sc = a.sc; c.lane = lane;
+                c.cost_g = a.cost_mv + a.cost_center; c.cost_l = s.costl;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
                 for (int r = 0; r < a.n_refs; r++) {
@@ -643,10 +690,10 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
 #pragma unroll
                     for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + by_ + oy;
                     c.cu = refs.u[r] + bc_ + oc; c.cv = refs.v[r] + bc_ + oc;
-                    c.cmx = a.cost_mv + a.cost_center - mvpx; c.cmy = a.cost_mv + a.cost_center - mvpy;
+                    c.mvpx = mvpx; c.mvpy = mvpy;
                     thresh -= a.ref_cost[r];
                     int smx, smy, cost_mv;
-                    int cost = me_search_ref16(c, L, mo, mvpx, mvpy, &s.mvc[0][0], n_mvc, a.n_refs > 1 ? &thresh : nullptr, smx, smy, cost_mv);
+                    int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], n_mvc, a.n_refs > 1 ? &thresh : nullptr, smx, smy, cost_mv);
                     if (r == 0 && try_pskip && cost - cost_mv < 300 * a.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
                         if (sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
                     }
@@ -665,9 +712,10 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
 #pragma unroll
                     for (int k = 0; k < 4; k++) c.pl[k] = refs.y[ref][k] + by_ + oy;
                     c.cu = refs.u[ref] + bc_ + oc; c.cv = refs.v[ref] + bc_ + oc;
-                    c.cmx = a.cost_mv + a.cost_center - bmvpx; c.cmy = a.cost_mv + a.cost_center - bmvpy;
+                    c.mvpx = bmvpx; c.mvpy = bmvpy;
                     best -= a.ref_cost[ref];
-                    best = me_refine_qpel16(c, L, mo, bmvpx, bmvpy, best, mvx, mvy);
+                    best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
+                    PROF(2);
                     int i_cost = best;
                     if (a.chroma_me) {
                         analyse_chroma();
@@ -683,8 +731,8 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
                 }
             }
         }
-        // stat.frame.i_inter_cost takes the chosen cost (analyse.c:2399-2400)
         (void)analysed;
+        PROF(6);
 
         // ---- x264_analyse_update_cache + x264_macroblock_encode ----
         int cbp_luma = 0, cbp_chroma = 0;
@@ -714,6 +762,7 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
             }
         }
         const int intra = IS_INTRA_T(type);
+        PROF(3);
 
         // ---- x264_macroblock_cache_save: reconstruction, per-macroblock state, levels ----
         {
@@ -759,11 +808,18 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
             if (lane < 8) a.chroma_dc[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
         }
         left_type = type; left_ref = is_p ? (intra ? -1 : ref) : -1; left_mvx = intra ? 0 : mvx; left_mvy = intra ? 0 : mvy;
+        PROF(4);
         // ---- publish: everything this macroblock wrote is visible before the count moves ----
         __threadfence();
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store(prog + mby, mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        PROF(5);
     }
+    if (a.prof && lane < 8) {
+        long long v = lane == 0 ? pacc[0] : lane == 1 ? pacc[1] : lane == 2 ? pacc[2] : lane == 3 ? pacc[3] : lane == 4 ? pacc[4] : lane == 5 ? pacc[5] : lane == 6 ? pacc[6] : pacc[7];
+        a.prof[((size_t)bz * a.mb_h + mby) * 8 + lane] = v;
+    }
+#undef PROF
 }
 
 // ------------------------------------------------------------------ host
@@ -850,6 +906,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.luma = out->luma; a.luma_dc = out->luma_dc; a.chroma_dc = out->chroma_dc; a.chroma_ac = out->chroma_ac;
     a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter;
     a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
+    a.prof = (long long *)p->profile;
     SwRefs t;
     for (int i = 0; i < SW_MAX_REFS; i++) {
         const x264hip_picture *r = (is_p && n_refs > 0) ? refs[i < n_refs ? i : 0] : fenc;

@@ -1,25 +1,32 @@
 // me_exact.h -- the reference's motion search for one 16x16 block on one wavefront, shared by the
 // per-frame search kernel (frame_me_exact.hip) and the macroblock sweep (frame_slice.hip).
 //
-// x264_me_search_ref + refine_subpel (R/encoder/me.c:156-778) and x264_me_refine_qpel (:634-644),
-// run exactly in the reference's candidate order:
-//   * up to four candidates are scored at once (COST_MV_X4 / _X3_DIR): 16 lanes per candidate,
-//     one picture row per lane = four v_sad_u8 on dwords re-aligned with v_alignbyte, reduced
-//     with four shuffles inside the 16-lane group;
-//   * sub-pel candidates blend two of the four half-pel planes on the fly (get_ref, mc.c:181-202);
-//   * SATD uses 32 lanes = 8 (8x4 blocks) x 4 rows: horizontal butterflies in registers on the
-//     reference's two-lanes-per-dword layout, vertical butterflies with two shuffles, the
-//     per-block halving kept per block as the reference does (pixel.c:214-253);
-//   * all lanes carry the same scalar state (best vector, cost, direction), so control flow is
-//     wave-uniform.
-// Reference pixels are read straight from HBM/L2 (the walk may start anywhere inside the mv
-// limits, so no window is staged); the source block lives in LDS.
+// x264_me_search_ref + refine_subpel (R/encoder/me.c:156-778) and x264_me_refine_qpel (:634-644).
+// The walk is data dependent and every step costs one round trip to L2/HBM for reference pixels, so
+// the code is organised to make each round trip score as many candidates as the reference's own
+// control flow allows, and replays the reference's sequential comparisons on the scores afterwards:
+//   * predictor candidates are scored four at a time (16 lanes per candidate, one picture row per
+//     lane = four v_sad_u8 on dwords re-aligned with v_alignbyte), then compared in list order;
+//   * the hexagon's first ring and the square refine score 6 / 8 candidates per trip (8 lanes each);
+//   * sub-pel rounds score up to four candidates, luma AND both chroma planes, in one trip: one lane
+//     = one 8x4 block of one candidate (SATD on the reference's two-lanes-per-dword layout, the
+//     per-block halving kept per block as pixel.c:214-253 does); the reference's "add chroma only
+//     while still below the best" rule is applied to the finished sums, which gives the same result;
+//   * all lanes carry the same scalar state (best vector, cost, direction): control flow is uniform.
+// Reference pixels are read straight from HBM/L2 (the walk may start anywhere inside the mv limits);
+// the source block and, in the sweep, the centre of the mv-cost table live in LDS.
 #pragma once
 #include "device_prims.h"
 
 #define MX_COST_MAX (1 << 28)
+#define MX_COST_LDS 1024          // half-width of the LDS copy of p_cost_mv (quarter-pels)
 
-// 16 consecutive bytes at an arbitrary address as four dwords (aligned loads + v_alignbyte)
+// R/encoder/me.c:34-50: subpel_iterations, hex2 (radius-2 hexagon with repeats), mod6m1
+static __constant__ int c_subpel_iters[10][4] = {{0,0,0,0},{1,1,0,0},{0,1,1,0},{0,2,1,0},{0,2,1,1},{0,2,1,2},{0,0,2,2},{0,0,2,2},{0,0,4,10},{0,0,4,10}};
+static __constant__ int c_hex2[8][2] = {{-1,-2},{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2},{-2,0}};
+static __constant__ int c_mod6m1[8] = {5,0,1,2,3,4,5,0};
+
+// 16 / 8(+1) consecutive bytes at an arbitrary address as dwords (aligned loads + v_alignbyte)
 __device__ __forceinline__ void load16u(const u8 *p, u32 o[4])
 {
     const uintptr_t a = (uintptr_t)p;
@@ -29,24 +36,40 @@ __device__ __forceinline__ void load16u(const u8 *p, u32 o[4])
     o[0] = __builtin_amdgcn_alignbyte(w1, w0, s); o[1] = __builtin_amdgcn_alignbyte(w2, w1, s);
     o[2] = __builtin_amdgcn_alignbyte(w3, w2, s); o[3] = __builtin_amdgcn_alignbyte(w4, w3, s);
 }
+__device__ __forceinline__ void load9u(const u8 *p, u32 &o0, u32 &o1, u32 &o2)   // bytes 0..7 in o0,o1; byte 8 in the low byte of o2
+{
+    const uintptr_t a = (uintptr_t)p;
+    const u32 s = (u32)(a & 3);
+    const u32 *q = (const u32 *)(a - s);
+    u32 w0 = q[0], w1 = q[1], w2 = q[2];
+    o0 = __builtin_amdgcn_alignbyte(w1, w0, s); o1 = __builtin_amdgcn_alignbyte(w2, w1, s); o2 = __builtin_amdgcn_alignbyte(0u, w2, s);
+}
 // rounded byte-wise average of two dwords: (a + b + 1) >> 1 per byte, no carries across bytes
 __device__ __forceinline__ u32 avg4(u32 a, u32 b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+__device__ __forceinline__ int byte_of(u32 w, int k) { return (int)((w >> (8 * k)) & 255u); }
 
 struct MxCtx {
     const u32 *fe;            // LDS: 16 rows x 4 dwords
     const u8 *fe_u, *fe_v;    // LDS: 8x8 each
     const u8 *pl[4];          // four half-pel planes at the macroblock origin
     const u8 *cu, *cv;        // chroma planes at the macroblock origin
-    const i16 *cmx, *cmy;     // cost tables offset by the predictor
+    const i16 *cost_g;        // p_cost_mv, centred (global memory)
+    const i16 *cost_l;        // LDS copy of cost_g[-MX_COST_LDS .. MX_COST_LDS], or nullptr
+    int mvpx, mvpy;           // the predictor the costs are relative to
     int sy, sc, lane;
+    __device__ __forceinline__ int cost1(int d) const
+    {
+        return (cost_l && (unsigned)(d + MX_COST_LDS) <= 2u * MX_COST_LDS) ? (int)cost_l[d + MX_COST_LDS] : (int)cost_g[d];
+    }
+    __device__ __forceinline__ int cost(int mx, int my) const { return cost1(mx - mvpx) + cost1(my - mvpy); }   // p_cost_mvx[mx] + p_cost_mvy[my]
 };
 
+#define MX_PICK4(g_, v_) ((g_) == 0 ? (v_)[0] : (g_) == 1 ? (v_)[1] : (g_) == 2 ? (v_)[2] : (v_)[3])
 // SAD 16x16 of up to four full-pel candidates (fx[k], fy[k]); result for candidate k in out[k]
 __device__ __forceinline__ void sad_fpel4(const MxCtx &c, const int fx[4], const int fy[4], int out[4])
 {
     const int g = c.lane >> 4, row = c.lane & 15;
-    const int mx = g == 0 ? fx[0] : g == 1 ? fx[1] : g == 2 ? fx[2] : fx[3];
-    const int my = g == 0 ? fy[0] : g == 1 ? fy[1] : g == 2 ? fy[2] : fy[3];
+    const int mx = MX_PICK4(g, fx), my = MX_PICK4(g, fy);
     u32 r[4];
     load16u(c.pl[0] + (ptrdiff_t)(my + row) * c.sy + mx, r);
     const u32 *f = c.fe + 4 * row;
@@ -55,12 +78,29 @@ __device__ __forceinline__ void sad_fpel4(const MxCtx &c, const int fx[4], const
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     out[0] = __shfl(v, 0, 64); out[1] = __shfl(v, 16, 64); out[2] = __shfl(v, 32, 64); out[3] = __shfl(v, 48, 64);
 }
-// SAD 16x16 of up to four quarter-pel candidates through get_ref's blend
+// the same for eight candidates: 8 lanes each, two picture rows per lane
+__device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const int fy[8], int out[8])
+{
+    const int g = c.lane >> 3, r = c.lane & 7;
+    int mx = fx[0], my = fy[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) if (g == k) { mx = fx[k]; my = fy[k]; }
+    u32 a[4], b[4];
+    load16u(c.pl[0] + (ptrdiff_t)(my + r) * c.sy + mx, a);
+    load16u(c.pl[0] + (ptrdiff_t)(my + r + 8) * c.sy + mx, b);
+    const u32 *f0 = c.fe + 4 * r, *f1 = c.fe + 4 * (r + 8);
+    u32 s = sad4(a[0], f0[0], 0); s = sad4(a[1], f0[1], s); s = sad4(a[2], f0[2], s); s = sad4(a[3], f0[3], s);
+    s = sad4(b[0], f1[0], s); s = sad4(b[1], f1[1], s); s = sad4(b[2], f1[2], s); s = sad4(b[3], f1[3], s);
+    int v = (int)s;
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = __shfl(v, 8 * k, 64);
+}
+// SAD 16x16 of up to four quarter-pel candidates through get_ref's blend (mc.c:181-202)
 __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const int qy[4], int out[4])
 {
     const int g = c.lane >> 4, row = c.lane & 15;
-    const int mx = g == 0 ? qx[0] : g == 1 ? qx[1] : g == 2 ? qx[2] : qx[3];
-    const int my = g == 0 ? qy[0] : g == 1 ? qy[1] : g == 2 ? qy[2] : qy[3];
+    const int mx = MX_PICK4(g, qx), my = MX_PICK4(g, qy);
     const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
     const ptrdiff_t base = (ptrdiff_t)((my >> 2) + row) * c.sy + (mx >> 2);
     u32 a[4];
@@ -77,8 +117,7 @@ __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     out[0] = __shfl(v, 0, 64); out[1] = __shfl(v, 16, 64); out[2] = __shfl(v, 32, 64); out[3] = __shfl(v, 48, 64);
 }
-// vertical half of the 8x4 SATD: lanes l, l^1, l^2 hold rows of one block; t[] = this row's
-// horizontally transformed packed words.  Returns the block's SATD (same value in its 4 lanes).
+// vertical half of the 8x4 SATD when the four rows of a block sit in lanes l, l^1, l^2, l^3
 __device__ __forceinline__ int satd_rows4(u32 t0, u32 t1, u32 t2, u32 t3, int lane)
 {
     u32 t[4] = {t0, t1, t2, t3}, acc = 0;
@@ -94,66 +133,101 @@ __device__ __forceinline__ int satd_rows4(u32 t0, u32 t1, u32 t2, u32 t3, int la
     acc += (u32)__shfl_xor((int)acc, 2, 64);
     return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
 }
-// SATD 16x16 of one quarter-pel candidate (mbcmp_unaligned at subme > 1)
-__device__ __forceinline__ int satd_qpel(const MxCtx &c, int mx, int my)
+
+// cost of one 8x4 block whose four rows are given as source / prediction dword pairs:
+// SATD (x264_pixel_satd_8x4, pixel.c:214-233) or SAD
+__device__ __forceinline__ int blk8x4_cost(const u32 f[4][2], const u32 p[4][2], int satd)
 {
-    int blk_satd = 0;
-    if (c.lane < 32) {
-        const int blk = c.lane >> 2, r = c.lane & 3, bx = (blk & 1) * 8, y = (blk >> 1) * 4 + r;
-        const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
-        const ptrdiff_t base = (ptrdiff_t)((my >> 2) + y) * c.sy + (mx >> 2) + bx;
-        const u8 *pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy, *pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
-        const u8 *f = (const u8 *)c.fe + y * 16 + bx;
-        int d[8];
+    if (!satd) {
+        u32 s = 0;
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-            int p = (idx & 5) ? ((int)pa[x] + (int)pb[x] + 1) >> 1 : (int)pa[x];
-            d[x] = (int)f[x] - p;
-        }
-        u32 p0 = (u32)d[0] + ((u32)d[4] << 16), p1 = (u32)d[1] + ((u32)d[5] << 16);
-        u32 p2 = (u32)d[2] + ((u32)d[6] << 16), p3 = (u32)d[3] + ((u32)d[7] << 16);
-        u32 t0, t1, t2, t3;
-        wht4(t0, t1, t2, t3, p0, p1, p2, p3);
-        blk_satd = satd_rows4(t0, t1, t2, t3, c.lane);
-        if (r != 0) blk_satd = 0;
-    } else {
-        // lanes 32-63 still take part in the shuffles of satd_rows4's callers below
+        for (int y = 0; y < 4; y++) { s = sad4(f[y][0], p[y][0], s); s = sad4(f[y][1], p[y][1], s); }
+        return (int)s;
     }
-    return wave_sum(blk_satd);
+    u32 t[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        u32 d[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            d[x] = (u32)(byte_of(f[y][0], x) - byte_of(p[y][0], x)) + ((u32)(byte_of(f[y][1], x) - byte_of(p[y][1], x)) << 16);
+        wht4(t[y][0], t[y][1], t[y][2], t[y][3], d[0], d[1], d[2], d[3]);
+    }
+    u32 acc = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        u32 v0, v1, v2, v3;
+        wht4(v0, v1, v2, v3, t[0][x], t[1][x], t[2][x], t[3][x]);
+        acc += lanes_abs(v0) + lanes_abs(v1) + lanes_abs(v2) + lanes_abs(v3);
+    }
+    return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
 }
-// SATD 8x8 of a chroma plane predicted with mc_chroma at qpel vector (mx,my) (mbcmp[PIXEL_8x8])
-__device__ __forceinline__ int satd_chroma(const MxCtx &c, const u8 *plane, const u8 *fe, int mx, int my)
+
+// COST_MV_SATD's three sums (me.c:654-677) for up to four quarter-pel candidates in one trip:
+// outL = mbcmp_unaligned[16x16] of the get_ref prediction, outU / outV = mbcmp[8x8] of mc_chroma.
+// Lane = candidate (lane >> 4) x block: 0-7 luma 8x4 blocks, 8-9 U, 10-11 V.
+__device__ __forceinline__ void me_subpel_costs4(const MxCtx &c, const int qx[4], const int qy[4], int satd, int chroma,
+                                                 int outL[4], int outU[4], int outV[4])
 {
-    int blk_satd = 0;
-    if (c.lane < 8) {
-        const int blk = c.lane >> 2, r = c.lane & 3, y = blk * 4 + r;
+    const int g = c.lane >> 4, j = c.lane & 15;
+    const int mx = MX_PICK4(g, qx), my = MX_PICK4(g, qy);
+    int v = 0;
+    if (j < 8) {
+        const int bx = (j & 1) * 8, by = (j >> 1) * 4;
+        const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
+        const ptrdiff_t base = (ptrdiff_t)((my >> 2) + by) * c.sy + (mx >> 2) + bx;
+        const u8 *pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy, *pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+        u32 f[4][2], p[4][2];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            u32 t;
+            load9u(pa + (ptrdiff_t)y * c.sy, p[y][0], p[y][1], t);
+            if (idx & 5) {
+                u32 b0, b1;
+                load9u(pb + (ptrdiff_t)y * c.sy, b0, b1, t);
+                p[y][0] = avg4(p[y][0], b0); p[y][1] = avg4(p[y][1], b1);
+            }
+            f[y][0] = c.fe[(by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[(by + y) * 4 + (bx >> 2) + 1];
+        }
+        v = blk8x4_cost(f, p, satd);
+    } else if (chroma && j < 12) {
+        const int by = ((j - 8) & 1) * 4;
+        const u8 *plane = j < 10 ? c.cu : c.cv, *fe = j < 10 ? c.fe_u : c.fe_v;
         const int dx = mx & 7, dy = my & 7;
         const int ca = (8 - dx) * (8 - dy), cb = dx * (8 - dy), cc = (8 - dx) * dy, cd = dx * dy;
-        const u8 *s = plane + (ptrdiff_t)((my >> 3) + y) * c.sc + (mx >> 3);
-        int d[8];
+        const u8 *s = plane + (ptrdiff_t)((my >> 3) + by) * c.sc + (mx >> 3);
+        u32 r0[5], r1[5], r2[5];
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-            int p = (ca * s[x] + cb * s[x + 1] + cc * s[c.sc + x] + cd * s[c.sc + x + 1] + 32) >> 6;
-            d[x] = (int)fe[y * 8 + x] - p;
+        for (int y = 0; y < 5; y++) load9u(s + (ptrdiff_t)y * c.sc, r0[y], r1[y], r2[y]);
+        u32 f[4][2], p[4][2];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            u32 w0 = 0, w1 = 0;
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                const int a0 = x < 4 ? byte_of(r0[y], x) : byte_of(r1[y], x - 4), a1 = x < 3 ? byte_of(r0[y], x + 1) : x < 7 ? byte_of(r1[y], x - 3) : byte_of(r2[y], 0);
+                const int b0 = x < 4 ? byte_of(r0[y + 1], x) : byte_of(r1[y + 1], x - 4), b1 = x < 3 ? byte_of(r0[y + 1], x + 1) : x < 7 ? byte_of(r1[y + 1], x - 3) : byte_of(r2[y + 1], 0);
+                const u32 px = (u32)((ca * a0 + cb * a1 + cc * b0 + cd * b1 + 32) >> 6);
+                if (x < 4) w0 |= px << (8 * x); else w1 |= px << (8 * (x - 4));
+            }
+            p[y][0] = w0; p[y][1] = w1;
+            const u32 *fr = (const u32 *)(fe + (by + y) * 8);
+            f[y][0] = fr[0]; f[y][1] = fr[1];
         }
-        u32 p0 = (u32)d[0] + ((u32)d[4] << 16), p1 = (u32)d[1] + ((u32)d[5] << 16);
-        u32 p2 = (u32)d[2] + ((u32)d[6] << 16), p3 = (u32)d[3] + ((u32)d[7] << 16);
-        u32 t0, t1, t2, t3;
-        wht4(t0, t1, t2, t3, p0, p1, p2, p3);
-        blk_satd = satd_rows4(t0, t1, t2, t3, c.lane);
-        if (r != 0) blk_satd = 0;
+        v = blk8x4_cost(f, p, satd);
     }
-    return wave_sum(blk_satd);
+    const int s1 = v + __shfl_xor(v, 1, 64);
+    const int s2 = s1 + __shfl_xor(s1, 2, 64);
+    const int s4 = s2 + __shfl_xor(s2, 4, 64);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { outL[k] = __shfl(s4, 16 * k, 64); outU[k] = __shfl(s1, 16 * k + 8, 64); outV[k] = __shfl(s1, 16 * k + 10, 64); }
 }
-// SAD 8x8 of a chroma plane predicted with mc_chroma (mbcmp[PIXEL_8x8] at subme <= 1)
-__device__ __forceinline__ int sad_chroma(const MxCtx &c, const u8 *plane, const u8 *fe, int mx, int my)
+// COST_MV_SATD's running rule: chroma is added only while the sum is still below the best
+__device__ __forceinline__ int me_satd_total(const MxCtx &c, int chroma, int L, int U, int V, int mx, int my, int limit)
 {
-    const int x = c.lane & 7, y = c.lane >> 3;
-    const int dx = mx & 7, dy = my & 7;
-    const int ca = (8 - dx) * (8 - dy), cb = dx * (8 - dy), cc = (8 - dx) * dy, cd = dx * dy;
-    const u8 *s = plane + (ptrdiff_t)((my >> 3) + y) * c.sc + (mx >> 3) + x;
-    int p = (ca * s[0] + cb * s[1] + cc * s[c.sc] + cd * s[c.sc + 1] + 32) >> 6;
-    return wave_sum(iabs((int)fe[y * 8 + x] - p));
+    int cost = L + c.cost(mx, my);
+    if (chroma && cost < limit) { cost += U; if (cost < limit) cost += V; }
+    return cost;
 }
 
 // mv limits of one macroblock, R/encoder/analyse.c:258-298 (one thread, frame coding)
@@ -169,69 +243,78 @@ __device__ __forceinline__ MeLimits me_limits(int mbx, int mby, int mb_w, int mb
 }
 struct MeOpts { int method, me_range, subme, chroma_me; };
 
-// COST_MV_SATD (me.c:654-677): luma through mbcmp_unaligned (SATD above subme 1), then the chroma
-// planes while the sum is still below the best
-__device__ __forceinline__ int me_cost_satd(const MxCtx &c, int satd, int chroma_me, int mx, int my, int limit)
-{
-    int cost;
-    if (satd) cost = satd_qpel(c, mx, my);
-    else { int qx[4] = {mx, mx, mx, mx}, qy[4] = {my, my, my, my}, res[4]; sad_qpel4(c, qx, qy, res); cost = res[0]; }
-    cost += c.cmx[mx] + c.cmy[my];
-    if (chroma_me && cost < limit) {
-        cost += satd ? satd_chroma(c, c.cu, c.fe_u, mx, my) : sad_chroma(c, c.cu, c.fe_u, mx, my);
-        if (cost < limit) cost += satd ? satd_chroma(c, c.cv, c.fe_v, mx, my) : sad_chroma(c, c.cv, c.fe_v, mx, my);
-    }
-    return cost;
-}
-
-// x264_me_search_ref for PIXEL_16x16.  c.cmx / c.cmy must already be offset by the predictor.
+// x264_me_search_ref for PIXEL_16x16.  c.mvpx / c.mvpy = the predictor (m->mvp).
 // Returns m->cost (without the reference cost); thresh = p_halfpel_thresh or nullptr.
-__device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &o, int mvpx, int mvpy, const i16 *mvc, int n_mvc,
+__device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &o, const i16 *mvc, int n_mvc,
                                int *thresh, int &out_mvx, int &out_mvy, int &out_cost_mv)
 {
-    const int satd = o.subme > 1;
+    const int satd = o.subme > 1, mvpx = c.mvpx, mvpy = c.mvpy;
     int bmx = clip3(mvpx, L.fmin0 * 4, L.fmax0 * 4), bmy = clip3(mvpy, L.fmin1 * 4, L.fmax1 * 4);
     const int pmx = (bmx + 2) >> 2, pmy = (bmy + 2) >> 2;
     int bcost = MX_COST_MAX, bpx = 0, bpy = 0, bpcost = MX_COST_MAX;
     int cx[4], cy[4], res[4];
-#define FPEL1(mx_, my_) do { cx[0] = cx[1] = cx[2] = cx[3] = (mx_); cy[0] = cy[1] = cy[2] = cy[3] = (my_); sad_fpel4(c, cx, cy, res); \
-    int cost_ = res[0] + c.cmx[(mx_) << 2] + c.cmy[(my_) << 2]; if (cost_ < bcost) { bcost = cost_; bmx = (mx_); bmy = (my_); } } while (0)
 #define INRANGE(x_, y_) ((x_) >= L.fmin0 && (x_) <= L.fmax0 && (y_) >= L.fmin1 && (y_) <= L.fmax1)
     if (o.subme >= 3) {
+        // me.c:188-210: the predictor and every distinct non-zero candidate at quarter-pel precision (SAD)
         const int px = bmx, py = bmy;
-        cx[0] = cx[1] = cx[2] = cx[3] = px; cy[0] = cy[1] = cy[2] = cy[3] = py;
-        sad_qpel4(c, cx, cy, res);
-        { int cost = res[0] + c.cmx[px] + c.cmy[py]; if (cost < bpcost) { bpcost = cost; bpx = px; bpy = py; } }
-        for (int i = 0; i < n_mvc; i++) {
-            int vx = mvc[2 * i], vy = mvc[2 * i + 1];
-            if ((vx | vy) && (vx != (int)(i16)px || vy != (int)(i16)py)) {
-                int mx = clip3(vx, L.fmin0 * 4, L.fmax0 * 4), my = clip3(vy, L.fmin1 * 4, L.fmax1 * 4);
-                cx[0] = cx[1] = cx[2] = cx[3] = mx; cy[0] = cy[1] = cy[2] = cy[3] = my;
-                sad_qpel4(c, cx, cy, res);
-                int cost = res[0] + c.cmx[mx] + c.cmy[my];
-                if (cost < bpcost) { bpcost = cost; bpx = mx; bpy = my; }
+        for (int base = 0; base < 1 + n_mvc; base += 4) {
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = base + j;
+                ok[j] = false; cx[j] = px; cy[j] = py;
+                if (k == 0) ok[j] = true;
+                else if (k <= n_mvc) {
+                    const int vx = mvc[2 * (k - 1)], vy = mvc[2 * (k - 1) + 1];
+                    if ((vx | vy) && (vx != (int)(i16)px || vy != (int)(i16)py)) {
+                        ok[j] = true; cx[j] = clip3(vx, L.fmin0 * 4, L.fmax0 * 4); cy[j] = clip3(vy, L.fmin1 * 4, L.fmax1 * 4);
+                    }
+                }
             }
+            sad_qpel4(c, cx, cy, res);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ok[j]) { const int cost = res[j] + c.cost(cx[j], cy[j]); if (cost < bpcost) { bpcost = cost; bpx = cx[j]; bpy = cy[j]; } }
         }
         bmx = (bpx + 2) >> 2; bmy = (bpy + 2) >> 2;
-        { int tx = bmx, ty = bmy; FPEL1(tx, ty); }
+        // COST_MV(bmx, bmy); COST_MV(0, 0)
+        cx[0] = bmx; cy[0] = bmy; cx[1] = cx[2] = cx[3] = 0; cy[1] = cy[2] = cy[3] = 0;
+        sad_fpel4(c, cx, cy, res);
+        { const int tx = bmx, ty = bmy, c0 = res[0] + c.cost(tx << 2, ty << 2); if (c0 < bcost) { bcost = c0; bmx = tx; bmy = ty; } }
+        { const int c1 = res[1] + c.cost(0, 0); if (c1 < bcost) { bcost = c1; bmx = 0; bmy = 0; } }
     } else {
-        FPEL1(pmx, pmy);
-        bcost -= c.cmx[pmx << 2] + c.cmy[pmy << 2];
-        for (int i = 0; i < n_mvc; i++) {
-            int mx = (mvc[2 * i] + 2) >> 2, my = (mvc[2 * i + 1] + 2) >> 2;
-            if ((mx | my) && ((mx - bmx) | (my - bmy))) {
-                mx = clip3(mx, L.fmin0, L.fmax0); my = clip3(my, L.fmin1, L.fmax1);
-                FPEL1(mx, my);
+        // me.c:211-229: full-pel predictor (its mv cost taken out again), rounded candidates, then (0,0)
+        const int total = n_mvc + 2;
+        for (int base = 0; base < total; base += 4) {
+            int kind[4];                             // 0 none, 1 predictor, 2 candidate, 3 zero
+            int ux[4], uy[4];                        // unclipped candidate (the reference tests these against the running best)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = base + j;
+                kind[j] = 0; cx[j] = pmx; cy[j] = pmy; ux[j] = uy[j] = 0;
+                if (k == 0) kind[j] = 1;
+                else if (k <= n_mvc) {
+                    ux[j] = (mvc[2 * (k - 1)] + 2) >> 2; uy[j] = (mvc[2 * (k - 1) + 1] + 2) >> 2;
+                    if (ux[j] | uy[j]) { kind[j] = 2; cx[j] = clip3(ux[j], L.fmin0, L.fmax0); cy[j] = clip3(uy[j], L.fmin1, L.fmax1); }
+                } else if (k == n_mvc + 1) { kind[j] = 3; cx[j] = 0; cy[j] = 0; }
+            }
+            sad_fpel4(c, cx, cy, res);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (kind[j] == 0) continue;
+                if (kind[j] == 2 && !((ux[j] - bmx) | (uy[j] - bmy))) continue;
+                const int cost = res[j] + c.cost(cx[j] << 2, cy[j] << 2);
+                if (cost < bcost) { bcost = cost; bmx = cx[j]; bmy = cy[j]; }
+                if (kind[j] == 1) bcost -= c.cost(pmx << 2, pmy << 2);
             }
         }
     }
-    FPEL1(0, 0);
     // four candidates around (ox, oy) in the given order, strict '<' updates (COST_MV_X4)
 #define X4(ox_, oy_, ax, ay, bx_, by_, cx_, cy_, dx_, dy_) do { \
     cx[0] = (ox_) + (ax); cy[0] = (oy_) + (ay); cx[1] = (ox_) + (bx_); cy[1] = (oy_) + (by_); \
     cx[2] = (ox_) + (cx_); cy[2] = (oy_) + (cy_); cx[3] = (ox_) + (dx_); cy[3] = (oy_) + (dy_); \
     sad_fpel4(c, cx, cy, res); \
-    for (int k_ = 0; k_ < 4; k_++) { int cost_ = res[k_] + c.cmx[cx[k_] << 2] + c.cmy[cy[k_] << 2]; \
+    for (int k_ = 0; k_ < 4; k_++) { int cost_ = res[k_] + c.cost(cx[k_] << 2, cy[k_] << 2); \
         if (cost_ < bcost) { bcost = cost_; bmx = cx[k_]; bmy = cy[k_]; } } } while (0)
     if (o.method == 0) {
         int i = 0;
@@ -242,52 +325,56 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
             if (!INRANGE(bmx, bmy)) break;
         } while (++i < o.me_range);
     } else {
-        const int hex2[8][2] = {{-1,-2},{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2},{-2,0}};
-        const int mod6m1[8] = {5,0,1,2,3,4,5,0};
-        int dir = -2, costs[6];
-        cx[0] = bmx - 2; cy[0] = bmy; cx[1] = bmx - 1; cy[1] = bmy + 2; cx[2] = bmx + 1; cy[2] = bmy + 2; cx[3] = bmx + 2; cy[3] = bmy;
-        sad_fpel4(c, cx, cy, res);
-        for (int k = 0; k < 4; k++) costs[k] = res[k] + c.cmx[cx[k] << 2] + c.cmy[cy[k] << 2];
-        cx[0] = bmx + 1; cy[0] = bmy - 2; cx[1] = bmx - 1; cy[1] = bmy - 2; cx[2] = cx[0]; cy[2] = cy[0]; cx[3] = cx[0]; cy[3] = cy[0];
-        sad_fpel4(c, cx, cy, res);
-        for (int k = 0; k < 2; k++) costs[4 + k] = res[k] + c.cmx[cx[k] << 2] + c.cmy[cy[k] << 2];
-        for (int k = 0; k < 6; k++) if (costs[k] < bcost) { bcost = costs[k]; dir = k; }
+        int dir = -2, ex[8], ey[8], er[8];
+        // the first ring in one trip: (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2), me.c:254-262
+        ex[0] = bmx - 2; ey[0] = bmy; ex[1] = bmx - 1; ey[1] = bmy + 2; ex[2] = bmx + 1; ey[2] = bmy + 2; ex[3] = bmx + 2; ey[3] = bmy;
+        ex[4] = bmx + 1; ey[4] = bmy - 2; ex[5] = bmx - 1; ey[5] = bmy - 2; ex[6] = ex[7] = bmx; ey[6] = ey[7] = bmy;
+        sad_fpel8(c, ex, ey, er);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const int cost = er[k] + c.cost(ex[k] << 2, ey[k] << 2); if (cost < bcost) { bcost = cost; dir = k; } }
         if (dir != -2) {
-            bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+            bmx += c_hex2[dir + 1][0]; bmy += c_hex2[dir + 1][1];
             for (int i = 1; i < o.me_range / 2 && INRANGE(bmx, bmy); i++) {
-                const int odir = mod6m1[dir + 1];
-                for (int k = 0; k < 3; k++) { cx[k] = bmx + hex2[odir + k][0]; cy[k] = bmy + hex2[odir + k][1]; }
+                const int odir = c_mod6m1[dir + 1];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { cx[k] = bmx + c_hex2[odir + k][0]; cy[k] = bmy + c_hex2[odir + k][1]; }
                 cx[3] = cx[0]; cy[3] = cy[0];
                 sad_fpel4(c, cx, cy, res);
                 dir = -2;
+#pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    int cost = res[k] + c.cmx[cx[k] << 2] + c.cmy[cy[k] << 2];
+                    const int cost = res[k] + c.cost(cx[k] << 2, cy[k] << 2);
                     if (cost < bcost) { bcost = cost; dir = odir - 1 + k; }
                 }
                 if (dir == -2) break;
-                bmx += hex2[dir + 1][0]; bmy += hex2[dir + 1][1];
+                bmx += c_hex2[dir + 1][0]; bmy += c_hex2[dir + 1][1];
             }
         }
+        // square refine: (0,-1) (0,1) (-1,0) (1,0) (-1,-1) (-1,1) (1,-1) (1,1) around the hexagon's best, me.c:300-304
         const int ox = bmx, oyy = bmy;
-        X4(ox, oyy, 0, -1, 0, 1, -1, 0, 1, 0);
-        X4(ox, oyy, -1, -1, -1, 1, 1, -1, 1, 1);
+        ex[0] = ox; ey[0] = oyy - 1; ex[1] = ox; ey[1] = oyy + 1; ex[2] = ox - 1; ey[2] = oyy; ex[3] = ox + 1; ey[3] = oyy;
+        ex[4] = ox - 1; ey[4] = oyy - 1; ex[5] = ox - 1; ey[5] = oyy + 1; ex[6] = ox + 1; ey[6] = oyy - 1; ex[7] = ox + 1; ey[7] = oyy + 1;
+        sad_fpel8(c, ex, ey, er);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int cost = er[k] + c.cost(ex[k] << 2, ey[k] << 2); if (cost < bcost) { bcost = cost; bmx = ex[k]; bmy = ey[k]; } }
     }
     int mvx, mvy, mcost;
     if (bpcost < bcost) { mvx = bpx; mvy = bpy; mcost = bpcost; }
     else { mvx = bmx << 2; mvy = bmy << 2; mcost = bcost; }
-    out_cost_mv = c.cmx[mvx] + c.cmy[mvy];                                   // m->cost_mv, me.c:615
+    out_cost_mv = c.cost(mvx, mvy);                                          // m->cost_mv, me.c:615
     if (bmx == pmx && bmy == pmy && o.subme < 3) mcost += out_cost_mv;
     if (o.subme >= 2) {
-        const int sub_iters[10][2] = {{0,0},{0,0},{1,0},{1,0},{1,1},{1,2},{2,2},{2,2},{4,10},{4,10}};   // subpel_iterations[][2..3]
-        const int hpel = sub_iters[o.subme][0], qpel = sub_iters[o.subme][1];
+        // refine_subpel(.., b_refine_qpel = 0), me.c:680-778
+        const int hpel = c_subpel_iters[o.subme][2], qpel = c_subpel_iters[o.subme][3];
         int bx = mvx, by = mvy, bc = mcost, odir = -1, bdir;
+        int cl[4], cu[4], cv[4];
         bool early = false;
         if (hpel && o.subme < 3) {
             int mx = clip3(mvpx, L.smin0, L.smax0), my = clip3(mvpy, L.smin1, L.smax1);
             if ((mx - bx) | (my - by)) {
                 cx[0] = cx[1] = cx[2] = cx[3] = mx; cy[0] = cy[1] = cy[2] = cy[3] = my;
                 sad_qpel4(c, cx, cy, res);
-                int cost = res[0] + c.cmx[mx] + c.cmy[my];
+                int cost = res[0] + c.cost(mx, my);
                 if (cost < bc) { bc = cost; bx = mx; by = my; }
             }
         }
@@ -295,8 +382,8 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
             const int ox = bx, oyy = by;
             cx[0] = ox; cy[0] = oyy - 2; cx[1] = ox; cy[1] = oyy + 2; cx[2] = ox - 2; cy[2] = oyy; cx[3] = ox + 2; cy[3] = oyy;
             sad_qpel4(c, cx, cy, res);
-            int c0 = res[0] + c.cmx[ox] + c.cmy[oyy - 2], c1 = res[1] + c.cmx[ox] + c.cmy[oyy + 2];
-            int c2 = res[2] + c.cmx[ox - 2] + c.cmy[oyy], c3 = res[3] + c.cmx[ox + 2] + c.cmy[oyy];
+            int c0 = res[0] + c.cost(ox, oyy - 2), c1 = res[1] + c.cost(ox, oyy + 2);
+            int c2 = res[2] + c.cost(ox - 2, oyy), c3 = res[3] + c.cost(ox + 2, oyy);
             if (c0 < bc) { bc = c0; by = oyy - 2; }
             if (c1 < bc) { bc = c1; by = oyy + 2; }
             if (c2 < bc) { bc = c2; bx = ox - 2; by = oyy; }
@@ -305,7 +392,9 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
         }
         if (by > L.smax1) by = L.smax1;
         bc = MX_COST_MAX;
-        { int cost = me_cost_satd(c, satd, o.chroma_me, bx, by, bc); if (cost < bc) bc = cost; }
+        cx[0] = cx[1] = cx[2] = cx[3] = bx; cy[0] = cy[1] = cy[2] = cy[3] = by;
+        me_subpel_costs4(c, cx, cy, satd, o.chroma_me, cl, cu, cv);
+        { int cost = me_satd_total(c, o.chroma_me, cl[0], cu[0], cv[0], bx, by, bc); if (cost < bc) bc = cost; }
         if (thresh) {
             if (((bc * 7) >> 3) > *thresh) early = true;
             else if (bc < *thresh) *thresh = bc;
@@ -315,25 +404,27 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
             for (int i = qpel; i > 0; i--) {
                 const int ox = bx, oyy = by;
                 odir = bdir;
-#pragma unroll 1
+                cx[0] = ox; cy[0] = oyy - 1; cx[1] = ox; cy[1] = oyy + 1; cx[2] = ox - 1; cy[2] = oyy; cx[3] = ox + 1; cy[3] = oyy;
+                me_subpel_costs4(c, cx, cy, satd, o.chroma_me, cl, cu, cv);
+#pragma unroll
                 for (int d = 0; d < 4; d++) {
                     if ((d ^ 1) == odir) continue;
-                    const int mx = ox + (d == 2 ? -1 : d == 3 ? 1 : 0), my = oyy + (d == 0 ? -1 : d == 1 ? 1 : 0);
-                    int cost = me_cost_satd(c, satd, o.chroma_me, mx, my, bc);
-                    if (cost < bc) { bc = cost; bx = mx; by = my; bdir = d; }
+                    const int cost = me_satd_total(c, o.chroma_me, cl[d], cu[d], cv[d], cx[d], cy[d], bc);
+                    if (cost < bc) { bc = cost; bx = cx[d]; by = cy[d]; bdir = d; }
                 }
                 if (bx == ox && by == oyy) break;
             }
             if (by > L.smax1) {
                 by = L.smax1; bc = MX_COST_MAX;
-                int cost = me_cost_satd(c, satd, o.chroma_me, bx, by, bc); if (cost < bc) bc = cost;
+                cx[0] = cx[1] = cx[2] = cx[3] = bx; cy[0] = cy[1] = cy[2] = cy[3] = by;
+                me_subpel_costs4(c, cx, cy, satd, o.chroma_me, cl, cu, cv);
+                int cost = me_satd_total(c, o.chroma_me, cl[0], cu[0], cv[0], bx, by, bc); if (cost < bc) bc = cost;
             }
-            out_cost_mv = c.cmx[bx] + c.cmy[by];                             // me.c:777
+            out_cost_mv = c.cost(bx, by);                                    // me.c:777
         }
         mvx = bx; mvy = by; mcost = bc;
     } else if (mvy > L.smax1) mvy = L.smax1;
 #undef X4
-#undef FPEL1
 #undef INRANGE
     out_mvx = mvx; out_mvy = mvy;
     return mcost;
@@ -342,17 +433,16 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
 // x264_me_refine_qpel -> refine_subpel(.., b_refine_qpel = 1) for PIXEL_16x16 (me.c:634-644, 680-778):
 // half-pel diamond with SAD, quarter-pel diamond with mbcmp (all four directions every round).
 // cost comes in without the reference cost; returns the refined cost.
-__device__ int me_refine_qpel16(const MxCtx &c, const MeLimits &L, const MeOpts &o, int mvpx, int mvpy, int cost, int &mvx, int &mvy)
+__device__ int me_refine_qpel16(const MxCtx &c, const MeLimits &L, const MeOpts &o, int cost, int &mvx, int &mvy)
 {
-    const int it[10][2] = {{0,0},{1,1},{0,1},{0,2},{0,2},{0,2},{0,0},{0,0},{0,0},{0,0}};               // subpel_iterations[][0..1]
-    const int hpel = it[o.subme][0], qpel = it[o.subme][1], satd = o.subme > 1;
-    int bx = mvx, by = mvy, bc = cost, cx[4], cy[4], res[4];
+    const int hpel = c_subpel_iters[o.subme][0], qpel = c_subpel_iters[o.subme][1], satd = o.subme > 1;
+    int bx = mvx, by = mvy, bc = cost, cx[4], cy[4], res[4], cl[4], cu[4], cv[4];
     if (hpel && o.subme < 3) {
-        int mx = clip3(mvpx, L.smin0, L.smax0), my = clip3(mvpy, L.smin1, L.smax1);
+        int mx = clip3(c.mvpx, L.smin0, L.smax0), my = clip3(c.mvpy, L.smin1, L.smax1);
         if ((mx - bx) | (my - by)) {
             cx[0] = cx[1] = cx[2] = cx[3] = mx; cy[0] = cy[1] = cy[2] = cy[3] = my;
             sad_qpel4(c, cx, cy, res);
-            int cst = res[0] + c.cmx[mx] + c.cmy[my];
+            int cst = res[0] + c.cost(mx, my);
             if (cst < bc) { bc = cst; bx = mx; by = my; }
         }
     }
@@ -360,8 +450,8 @@ __device__ int me_refine_qpel16(const MxCtx &c, const MeLimits &L, const MeOpts 
         const int ox = bx, oyy = by;
         cx[0] = ox; cy[0] = oyy - 2; cx[1] = ox; cy[1] = oyy + 2; cx[2] = ox - 2; cy[2] = oyy; cx[3] = ox + 2; cy[3] = oyy;
         sad_qpel4(c, cx, cy, res);
-        int c0 = res[0] + c.cmx[ox] + c.cmy[oyy - 2], c1 = res[1] + c.cmx[ox] + c.cmy[oyy + 2];
-        int c2 = res[2] + c.cmx[ox - 2] + c.cmy[oyy], c3 = res[3] + c.cmx[ox + 2] + c.cmy[oyy];
+        int c0 = res[0] + c.cost(ox, oyy - 2), c1 = res[1] + c.cost(ox, oyy + 2);
+        int c2 = res[2] + c.cost(ox - 2, oyy), c3 = res[3] + c.cost(ox + 2, oyy);
         if (c0 < bc) { bc = c0; by = oyy - 2; }
         if (c1 < bc) { bc = c1; by = oyy + 2; }
         if (c2 < bc) { bc = c2; bx = ox - 2; by = oyy; }
@@ -370,17 +460,20 @@ __device__ int me_refine_qpel16(const MxCtx &c, const MeLimits &L, const MeOpts 
     }
     for (int i = qpel; i > 0; i--) {
         const int ox = bx, oyy = by;
-#pragma unroll 1
+        cx[0] = ox; cy[0] = oyy - 1; cx[1] = ox; cy[1] = oyy + 1; cx[2] = ox - 1; cy[2] = oyy; cx[3] = ox + 1; cy[3] = oyy;
+        me_subpel_costs4(c, cx, cy, satd, o.chroma_me, cl, cu, cv);
+#pragma unroll
         for (int d = 0; d < 4; d++) {
-            const int mx = ox + (d == 2 ? -1 : d == 3 ? 1 : 0), my = oyy + (d == 0 ? -1 : d == 1 ? 1 : 0);
-            int cst = me_cost_satd(c, satd, o.chroma_me, mx, my, bc);
-            if (cst < bc) { bc = cst; bx = mx; by = my; }
+            const int cst = me_satd_total(c, o.chroma_me, cl[d], cu[d], cv[d], cx[d], cy[d], bc);
+            if (cst < bc) { bc = cst; bx = cx[d]; by = cy[d]; }
         }
         if (bx == ox && by == oyy) break;
     }
     if (by > L.smax1) {
         by = L.smax1; bc = MX_COST_MAX;
-        int cst = me_cost_satd(c, satd, o.chroma_me, bx, by, bc); if (cst < bc) bc = cst;
+        cx[0] = cx[1] = cx[2] = cx[3] = bx; cy[0] = cy[1] = cy[2] = cy[3] = by;
+        me_subpel_costs4(c, cx, cy, satd, o.chroma_me, cl, cu, cv);
+        int cst = me_satd_total(c, o.chroma_me, cl[0], cu[0], cv[0], bx, by, bc); if (cst < bc) bc = cst;
     }
     mvx = bx; mvy = by;
     return bc;

@@ -37,7 +37,8 @@ class SliceParams(C.Structure):
                 ("analyse_inter", C.c_int), ("analyse_intra", C.c_int),
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p), ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
-                ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8)]
+                ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
+                ("profile", C.c_void_p)]
 
 
 def iframe_qp(qp, ip_factor=1.4):
@@ -85,6 +86,7 @@ class ChainEncoder:
         self.refs = []                 # [(picture, state, poc)], newest first
         self.t = 0
         self.last_idr = 0
+        self.profile = None            # DeviceArray [batch][mb_h][8] int64 when phase timing is wanted
 
     def cost_table(self, qp):
         if qp not in self.cost:
@@ -115,7 +117,8 @@ class ChainEncoder:
                         cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
                         quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
-                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc)
+                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc,
+                        profile=self.profile.ptr if self.profile else None)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]
         arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None

@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/sec of the per-frame hot-path pass on 1..N MI355X.
+"""bench.py -- frames/sec of the per-macroblock hot loop on 1..N MI355X.
 
-A "step" is one P-frame pass over one batch of B synthetic 1920x1080 frames
-already resident in HBM, one frame from each of B independent GOP chains
-(x264_vs2008_amd/pipeline.py has the exact kernel sequence): lowres + AQ
-energy, full-pel (exhaustive +-16, nine partitions) and sub-pel motion search
-against three references, 16x16 inter residual (8x8 transform, quant,
-decimate, dequant, idct), whole-frame deblock, border expansion, half-pel
-planes, SSD.  The reconstruction of each step is the nearest reference of the
-next one, per chain.  Chains shard across ranks with no data-path collective
-(independent GOPs); scaling is weak.
+A "step" advances B independent GOP chains by one 1920x1080 frame each; the source frames are
+already resident in HBM.  Per step and chain the GPU does what x264_slice_write +
+x264_fdec_filter_row do for one frame (R/encoder/encoder.c:1141-1291, 983-1056):
 
-What the number is NOT: it is not a bit-exact H.264 bitstream rate -- mode
-decision and entropy coding (the reference's serial spine) are not part of
-the pass.  DESIGN.md says so at length; `config.workload` names the pass.
+  x264hip_slice_sweep_frame  cache_load -> x264_macroblock_analyse -> x264_macroblock_encode ->
+                             cache_save for all 8160 macroblocks (one wavefront per macroblock row,
+                             2:1 wavefront order), all B chains in one launch
+  x264hip_deblock_frame      x264_frame_deblock_row for every row
+  x264hip_expand_border, x264hip_hpel_filter_frame   the frame becomes a reference
 
+with the analysis options named in config.workload (the part of the medium preset built so far:
+hex ME, subme 5, 3 references, chroma ME, fast P-skip, decimation, CABAC-side cbp; every frame I or P;
+CQP).  Every decision, level and pixel of this loop is bit-exact against the reference's own
+functions (tests/test_gpu_slice.py); entropy coding stays on the host and is not timed.
+
+Chains shard across ranks with no data-path collective (closed GOPs); scaling is weak.
 One JSON line on stdout (rank 0).  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 """
@@ -31,10 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from x264_vs2008_amd import lib as L, synth  # noqa: E402
-from x264_vs2008_amd.frame import FrameCtx, chroma_qp, cost_mv_table  # noqa: E402
-from x264_vs2008_amd.pipeline import COST_SPAN, LAMBDA_TAB, PFramePass, setup_event_api  # noqa: E402
+from x264_vs2008_amd import slice as sl  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ME_HEX = 1
 
 
 def load_cqm():
@@ -42,51 +44,46 @@ def load_cqm():
         return {k: z[k] for k in z.files}
 
 
-def cpu_baseline(args, cqm):
-    """The same pass on the host cores, 1 thread: a chain of whole 1080p frames (bounded sample).
-    Prefers the reference's own C table entries (oracle/_ref/libframe_ref.so, built from
-    the reference sources); falls back to our restatement."""
-    from oracle import hostpic
-    ref_so = os.path.join(ROOT, "oracle", "_ref", "libframe_ref.so")
+def analysis_options(args):
+    return dict(qp=args.qp, me_method=ME_HEX, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
+                chroma_me=1, cabac=1, deblock=1, keyint=args.keyint)
+
+
+def cpu_baseline(args):
+    """The same loop on one host core: the REFERENCE's own x264_macroblock_cache_load / _analyse /
+    _encode / _cache_save + x264_frame_deblock_row + x264_frame_filter, compiled from the reference's
+    sources where they lie (oracle/_ref/libx264ref.so via oracle/ref_slice.c); our restatement
+    (liboracle.so) when that library is not there.  A bounded chain of whole frames."""
+    from oracle import refslice as rs
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
+    n = args.cpu_frames
+    y, u, v = rs.clip(args.width, args.height, n)
+    p = rs.make_params(args.width, args.height, n, **analysis_options(args))
     if os.path.exists(ref_so):
-        lib, prefix, kind = hostpic.load_lazy(ref_so), "x264r_", "reference"
+        lib, fn, kind = rs.reference_lib(), "refslice_encode_chain", "reference"
     else:
-        lib, prefix, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "x264o_", "port"
-    g = hostpic.Geometry(args.width, args.height)
-    refs = []
-    for t in (2, 1, 0):
-        hp = hostpic.HostPic(g)
-        hp.load_yuv(lib, prefix, *synth.frame(args.width, args.height, t))
-        hostpic.make_reference(lib, prefix, hp)
-        refs.append(hp)
-    tab = cost_mv_table(LAMBDA_TAB[args.qp], COST_SPAN)
-    frames, spent = 0, 0.0
-    while frames < args.cpu_frames and spent < args.cpu_seconds:
-        cur = hostpic.HostPic(g)
-        cur.load_yuv(lib, prefix, *synth.frame(args.width, args.height, 3 + frames))
-        recon = hostpic.HostPic(g)
-        t0 = time.perf_counter()
-        hostpic.cpu_pframe_pass(lib, prefix, g, cur, refs, recon, cqm, args.qp, chroma_qp(args.qp), tab, COST_SPAN, 16, 1)
-        spent += time.perf_counter() - t0
-        frames += 1
-        refs = [recon] + refs[:2]
-    return {"value": round(frames / spent, 4), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "%d chained %dx%d frames through the same pass (%.1f s of CPU, C tables compiled -O3, no asm)"
-                      % (frames, args.width, args.height, spent)}
+        lib, fn, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "x264o_encode_chain", "port"
+    t0 = time.perf_counter()
+    rs.run(lib, fn, p, y, u, v)
+    spent = time.perf_counter() - t0
+    return {"value": round(n / spent, 4), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "one chain of %d %dx%d frames through the same per-macroblock loop, same options (%.1f s of CPU; C compiled -O3, "
+                      "no asm, no entropy coding on either side)" % (n, args.width, args.height, spent)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="independent GOP chains advanced per step on each GPU")
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=14, help="independent GOP chains advanced per step on each GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--refs", type=int, default=3)
-    ap.add_argument("--cpu-frames", type=int, default=12)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--subme", type=int, default=5)
+    ap.add_argument("--keyint", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -107,38 +104,26 @@ def main():
     if ndev <= 0:
         raise SystemExit("bench.py: no MI355X visible to libx264hip.so (there is no CPU fallback)")
     hip = L.load(local % ndev)                       # one rank per GPU; wraps only when rehearsing on fewer GPUs
-    setup_event_api(hip)
-    cqm = load_cqm()
     B = args.batch
-    ctx = FrameCtx(hip, args.width, args.height, batch=B)
-    pas = PFramePass(hip, ctx, cqm, qp=args.qp, transform8x8=1, n_refs=args.refs)
+    enc = sl.ChainEncoder(hip, args.width, args.height, load_cqm(), batch=B, **analysis_options(args))
+    ctx = enc.ctx
     d = ctx.dims
     px = d.mb_w * 16 * d.lines_y
 
-    # resident working set: a ring of source pictures and reconstructions, each holding B frames
-    # (one per chain).  A pool of distinct synthetic frames is dealt so that neighbouring chains
-    # and neighbouring steps see different content.
-    n_src, pool_n = 6, 12
+    # resident working set: a ring of source pictures, each holding one frame of every chain.  Chains and
+    # steps see different frames of the synthetic clip (rank-dependent offset).
+    n_src, pool_n = 8, 16
     pool = [synth.frame(args.width, args.height, rank * 97 + i) for i in range(pool_n)]
     srcs = []
     for i in range(n_src):
-        p = ctx.new_picture()
+        pic = ctx.new_picture()
         for b in range(B):
-            ctx.upload(p, *pool[(i + 5 * b) % pool_n], b=b)
-        srcs.append(p)
-    recs = [ctx.new_picture() for _ in range(args.refs + 1)]
-    for i in range(args.refs):                       # initial references = other source frames
-        for b in range(B):
-            ctx.upload(recs[i], *pool[(7 + i + 5 * b) % pool_n], b=b)
-        pas.make_reference(recs[i])
-    ring = list(range(args.refs + 1))                # ring[0..refs-1] = references (nearest first), ring[-1] = free
+            ctx.upload(pic, *pool[(i + 3 * b) % pool_n], b=b)
+        srcs.append(pic)
 
     def one_step(k):
-        cur = srcs[k % n_src]
-        refs = [recs[j] for j in ring[:args.refs]]
-        out = recs[ring[-1]]
-        pas.step(cur, refs, out)
-        ring.insert(0, ring.pop())                   # the reconstruction becomes the nearest reference
+        enc.encode_frame(srcs[k % n_src])
+        enc.finish_frame()
 
     def sync_all():
         assert hip.x264hip_device_synchronize() == 0
@@ -146,9 +131,10 @@ def main():
     for k in range(args.warmup):
         one_step(k)
     sync_all()
+    enc.status()
     if dist is not None:
         dist.barrier()
-    pas.me_events = []
+    enc.events = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k)
@@ -156,50 +142,53 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    enc.status()                                     # a sweep that gave up waiting would have produced garbage: fail loudly
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
 
-    # dominant-kernel duration measured live with HIP events on the launch stream
-    ms = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b in pas.me_events]
-    for a, b in pas.me_events:
+    # the dominant kernel (k_slice_sweep), timed live with HIP events on its launch stream
+    ms_p = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, st, nr in enc.events if st == sl.SLICE_P and nr == args.refs]
+    ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, st, nr in enc.events]
+    for a, b, _, _ in enc.events:
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
-    me_ms = float(np.mean(ms)) if ms else float("nan")
-    n_mb = d.mb_w * d.mb_h
-    # algorithmic bytes of one full-pel launch: per frame, source luma + reference luma read once,
-    # vectors/costs written; B frames per launch
-    me_bytes = B * (2 * px + n_mb * 9 * (4 + 4))
-    achieved = me_bytes / (me_ms * 1e-3) / 1e9
+    sweep_ms = float(np.mean(ms_p)) if ms_p else float(np.mean(ms_all))
+    # algorithmic bytes of one P sweep launch (SURVEY 8(d) terms that belong to this kernel): per frame the
+    # source (1.5 B/px), each reference's four luma planes + chroma (4.5 B/px) and the reconstruction (1.5 B/px)
+    sweep_bytes = int(B * px * (1.5 + 4.5 * args.refs + 1.5))
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
 
     if rank == 0:
         fps = world * B * args.steps / dt
-        # whole-pass algorithmic bytes per frame (SURVEY 8(d) terms), for the secondary figure
-        pass_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0 + 2.0)
+        frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)       # + deblock read/write + hpel planes
+        n_i = sum(1 for e in enc.events if e[2] == sl.SLICE_I)
         line = {
             "metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d P-frame hot-path pass (lowres, AQ var, exhaustive +-16 full-pel ME x9 partitions + "
-                                   "SATD sub-pel on %d refs, 16x16 inter residual dct8/quant/decimate/idct, deblock, border, "
-                                   "hpel planes, SSD); arithmetic bit-exact vs the reference's C table entries; NO mode "
-                                   "decision / entropy coding, so not a bitstream rate" % (args.width, args.height, args.refs),
-                       "qp": args.qp, "refs": args.refs, "me_range": 16, "frames_per_step": B,
-                       "parallelism": "B independent GOP chains per GPU batched into every launch; chains shard across "
-                                      "GPUs with no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_me_fullpel<16>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "avg_launch_ms": round(me_ms, 5), "algorithmic_bytes_per_launch": me_bytes,
-                         "note": "full-pel ME is VALU/LDS-bound (1089 candidates x 256 px per MB-ref), not HBM-bound; "
-                                 "whole-pass algorithmic bytes/frame = %d -> %.1f GB/s at this fps"
-                                 % (pass_bytes, pass_bytes * (fps / world) / 1e9)},
+            "config": {"workload": "%dx%d I/P chains through the reference's per-macroblock loop on the GPU (cache_load, "
+                                   "x264_macroblock_analyse, x264_macroblock_encode, cache_save, deblock, borders, half-pel planes): "
+                                   "hex ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; "
+                                   "macroblock types built so far: I_16x16 / P_L0 16x16 / P_SKIP (no sub-partitions, i4x4/i8x8, "
+                                   "8x8dct, B-frames, RD or trellis yet -- the medium preset minus those); entropy coding on the "
+                                   "host, not timed" % (args.width, args.height, args.subme, args.refs, args.qp, args.keyint),
+                       "frames_per_step": B, "i_frames_in_timed_steps": n_i,
+                       "parallelism": "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); "
+                                      "chains shard across GPUs with no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_slice_sweep", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
+                         "note": "P-frame launches only; the sweep is bound by the macroblock dependency chain (mb_w + 2*mb_h = %d "
+                                 "serial macroblock steps per frame), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s "
+                                 "at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:
-            line["cpu_baseline"] = cpu_baseline(args, cqm)
+            line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
-    ctx.close()
+    enc.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@ for name in which:
     for B in batches:
         enc = sl.ChainEncoder(lib, W, H, cqm, batch=B, **cfgs[name])
         from x264_vs2008_amd.frame import DeviceArray
-        enc.profile = DeviceArray(lib, (B, enc.ctx.dims.mb_h, 8), np.int64)
+        enc.profile = DeviceArray(lib, (B, enc.ctx.dims.mb_h, 8), np.int64) if os.environ.get('SW_PROF', '1') == '1' else None
         ev = [lib.x264hip_event_create() for _ in range(3)]
         lib.x264hip_event_create.restype = C.c_void_p
         lib.x264hip_event_elapsed_ms.restype = C.c_float
@@ -41,7 +41,7 @@ for name in which:
             enc.ctx.sync()
             ms_s = lib.x264hip_event_elapsed_ms(ev[0], ev[1]); ms_f = lib.x264hip_event_elapsed_ms(ev[1], ev[2])
             ty = state.get("mb_type")[0]
-            pr = enc.profile.get()[0].astype(np.float64) / 100.0 / enc.ctx.dims.mb_w   # us per macroblock
+            pr = (enc.profile.get()[0].astype(np.float64) if enc.profile else np.zeros((enc.ctx.dims.mb_h, 8))) / 100.0 / enc.ctx.dims.mb_w   # us per macroblock
             print("   us/MB (mean over rows): wait %.1f load %.1f inter %.1f intra %.1f encode %.1f store %.1f publish %.1f | row0 wait %.1f" % (
                 pr[:, 0].mean(), pr[:, 1].mean(), pr[:, 2].mean(), pr[:, 6].mean(), pr[:, 3].mean(), pr[:, 4].mean(), pr[:, 5].mean(), pr[0, 0]))
             print("%s B=%d frame %d type %d: sweep %.2f ms, filter %.2f ms -> %.1f fps  (types %s)" % (

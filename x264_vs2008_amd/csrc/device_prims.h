@@ -19,12 +19,20 @@ __device__ __forceinline__ int clip_u8(int v) { return v < 0 ? 0 : (v > 255 ? 25
 __device__ __forceinline__ int clip3(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
-// ---- wave64 reductions (DPP-free, shuffle based; every lane gets the sum) ----
+// ---- wave64 reductions on the DPP cross-lane path (VALU latency, no LDS round trip per step) ----
+// Call these with every lane of the groups involved active.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#define DPP_XOR1 0xB1          /* quad_perm [1,0,3,2]: lane ^ 1 */
+#define DPP_XOR2 0x4E          /* quad_perm [2,3,0,1]: lane ^ 2 */
+// every lane gets the sum of its aligned group of 4 / 8 / 16 lanes
+__device__ __forceinline__ int quad_sum4(int v) { v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); return v; }
+__device__ __forceinline__ int half_sum8(int v) { v += dpp_mov<0x141>(v); return quad_sum4(v); }                       // row_half_mirror first
+__device__ __forceinline__ int row_sum16(int v) { v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v); return v; }  // row_ror 8,4,2,1
+// sum over the whole wave, returned as a scalar (uniform) value
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v = row_sum16(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 __device__ __forceinline__ u32 wave_sum_u32(u32 v)
 {

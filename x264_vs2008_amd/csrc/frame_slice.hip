@@ -85,8 +85,9 @@ struct SwLds {
     i16 costl[2 * MX_COST_LDS + 2];
 };
 
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
-                         __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+// lanes exchange data through LDS only: order LDS traffic (lgkmcnt) and leave global loads / stores in flight
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
 __device__ __forceinline__ void sw_blk_xy(int k, int &x, int &y)
 {
@@ -308,7 +309,7 @@ __device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, i
         s.keep8 = cbp;
     }
     WAVE_SYNC();
-    const int keep = s.keep8;
+    const int keep = __builtin_amdgcn_readfirstlane(s.keep8);
     sw_luma4x4_add(s, lane, keep);
     return keep;
 }
@@ -361,7 +362,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
         s.keep8 = cbp; s.nzdc16 = nz != 0;
     }
     WAVE_SYNC();
-    const int keep = s.keep8, nzdc = s.nzdc16;
+    const int keep = __builtin_amdgcn_readfirstlane(s.keep8), nzdc = __builtin_amdgcn_readfirstlane(s.nzdc16);
     if (keep) {
         if (lane < 16) {
             int bx, by;
@@ -454,7 +455,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
         }
     }
     WAVE_SYNC();
-    const int m0 = s.cmode[0], m1 = s.cmode[1];
+    const int m0 = __builtin_amdgcn_readfirstlane(s.cmode[0]), m1 = __builtin_amdgcn_readfirstlane(s.cmode[1]);
     return ((m0 & 15) == 2 || (m1 & 15) == 2) ? 2 : (((m0 | m1) & 16) ? 1 : 0);
 }
 // x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883); leaves the P-skip prediction in s.fd
@@ -494,12 +495,12 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
     }
     int luma_sum = 0, c_sum[2] = {0, 0}, c_ssd[2] = {0, 0}, c_dc[2][4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) luma_sum += __shfl(score, k, 64);
+    for (int k = 0; k < 16; k++) luma_sum += __builtin_amdgcn_readlane(score, k);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        c_sum[k >> 2] += __shfl(score, 16 + k, 64);
-        c_ssd[k >> 2] += __shfl(ssd, 16 + k, 64);
-        c_dc[k >> 2][k & 3] = __shfl(dc, 16 + k, 64);
+        c_sum[k >> 2] += __builtin_amdgcn_readlane(score, 16 + k);
+        c_ssd[k >> 2] += __builtin_amdgcn_readlane(ssd, 16 + k);
+        c_dc[k >> 2][k & 3] = __builtin_amdgcn_readlane(dc, 16 + k);
     }
     int ok = luma_sum < 6;
     const u16 *mf = s.qmf[3], *bs = s.qbias[3];
@@ -517,7 +518,11 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
 
 __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
+// WPE = waves per SIMD the register allocation is held to.  A row wave spends most of its time waiting
+// on dependent LDS / L2 round trips, so throughput comes from other chains' waves filling those gaps:
+// fewer registers per wave (some spilled) and more waves resident beats one fat wave per SIMD.
+template <int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs)
 {
     __shared__ SwLds s;
     const int lane = threadIdx.x;
@@ -547,6 +552,14 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
 #define PROF(k_) do { if (a.prof) { long long now_ = (long long)wall_clock64(); pacc[k_] += now_ - ptime; ptime = now_; } } while (0)
     // the left neighbour = this wave's previous macroblock
     int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0;
+    u32 pre_y;
+    u8 pre_u, pre_v;
+    {
+        const ptrdiff_t oy0 = (ptrdiff_t)16 * mby * a.sy, oc0 = (ptrdiff_t)8 * mby * a.sc;
+        pre_y = *(const u32 *)(a.fy + oy0 + (ptrdiff_t)(lane >> 2) * a.sy + (lane & 3) * 4);
+        pre_u = a.fu[oc0 + (ptrdiff_t)(lane >> 3) * a.sc + (lane & 7)];
+        pre_v = a.fv[oc0 + (ptrdiff_t)(lane >> 3) * a.sc + (lane & 7)];
+    }
 
     for (int mbx = 0; mbx < a.mb_w; mbx++) {
         const int mb = mby * a.mb_w + mbx;
@@ -573,26 +586,32 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
             else if (lane < 24) s.fd[FDU + (lane - 16) * FD - 1] = s.fd[FDU + (lane - 16) * FD + 7];
             else if (lane < 32) s.fd[FDV + (lane - 24) * FD - 1] = s.fd[FDV + (lane - 24) * FD + 7];
         }
-        {
+        {   // source pixels: fetched one macroblock ahead (they depend on nothing), parked in registers meanwhile
             const int r = lane >> 2, x = (lane & 3) * 4, cx = lane & 7, cy = lane >> 3;
-            *(u32 *)(s.fe + r * 16 + x) = *(const u32 *)(a.fy + oy + (ptrdiff_t)r * a.sy + x);
-            s.fe[256 + lane] = a.fu[oc + (ptrdiff_t)cy * a.sc + cx];
-            s.fe[320 + lane] = a.fv[oc + (ptrdiff_t)cy * a.sc + cx];
+            *(u32 *)(s.fe + r * 16 + x) = pre_y;
+            s.fe[256 + lane] = pre_u;
+            s.fe[320 + lane] = pre_v;
         }
-        WAVE_SYNC();
         if (mby > 0) {      // the row above, still unfiltered: x = -1 .. w*3/2-1
             if (lane < 25) s.fd[FDY - FD - 1 + lane] = a.dy[oy - a.sy - 1 + lane];
             else if (lane >= 32 && lane < 45) s.fd[FDU - FD - 1 + (lane - 32)] = a.du[oc - a.sc - 1 + (lane - 32)];
             else if (lane >= 48 && lane < 61) s.fd[FDV - FD - 1 + (lane - 48)] = a.dv[oc - a.sc - 1 + (lane - 48)];
         }
+        if (mbx + 1 < a.mb_w) {     // issued after the loads above so that waiting for those leaves these in flight
+            const int r = lane >> 2, x = (lane & 3) * 4, cx = lane & 7, cy = lane >> 3;
+            pre_y = *(const u32 *)(a.fy + oy + 16 + (ptrdiff_t)r * a.sy + x);
+            pre_u = a.fu[oc + 8 + (ptrdiff_t)cy * a.sc + cx];
+            pre_v = a.fv[oc + 8 + (ptrdiff_t)cy * a.sc + cx];
+        }
         WAVE_SYNC();
         PROF(1);
         // ---- neighbour availability and types ----
         int nb = 0, type_top = -1, type_topleft = -1, type_topright = -1;
-        if (mby > 0) { nb |= NB_TOP; type_top = a.mb_type[mb - a.mb_w]; }
+#define UNI(x_) __builtin_amdgcn_readfirstlane((int)(x_))      /* a wave-uniform load: keep the value in a scalar register */
+        if (mby > 0) { nb |= NB_TOP; type_top = UNI(a.mb_type[mb - a.mb_w]); }
         if (mbx > 0) nb |= NB_LEFT;
-        if (mbx < a.mb_w - 1 && mby > 0) { nb |= NB_TOPRIGHT; type_topright = a.mb_type[mb - a.mb_w + 1]; }
-        if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = a.mb_type[mb - a.mb_w - 1]; }
+        if (mbx < a.mb_w - 1 && mby > 0) { nb |= NB_TOPRIGHT; type_topright = UNI(a.mb_type[mb - a.mb_w + 1]); }
+        if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = UNI(a.mb_type[mb - a.mb_w - 1]); }
 
         int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0;
         int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
@@ -625,9 +644,9 @@ __global__ __launch_bounds__(64) void k_slice_sweep(SwArgs a, SwRefs refs)
             // ---- motion neighbours: what cache_load puts around the block (R/common/macroblock.c:1040-1128) ----
             int ra = left_ref, ax = left_mvx, ay = left_mvy;                 // A
             int rb = -2, bx = 0, byv = 0, rc = -2, cx = 0, cy = 0;            // B, C (or D)
-            if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = a.ref[o * 4 + 2]; bx = a.mv[(o * 16 + 12) * 2]; byv = a.mv[(o * 16 + 12) * 2 + 1]; }
-            if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = a.ref[o * 4 + 2]; cx = a.mv[(o * 16 + 12) * 2]; cy = a.mv[(o * 16 + 12) * 2 + 1]; }
-            else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = a.ref[o * 4 + 3]; cx = a.mv[(o * 16 + 15) * 2]; cy = a.mv[(o * 16 + 15) * 2 + 1]; }
+            if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = UNI(a.ref[o * 4 + 2]); bx = UNI(a.mv[(o * 16 + 12) * 2]); byv = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
+            if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = UNI(a.ref[o * 4 + 2]); cx = UNI(a.mv[(o * 16 + 12) * 2]); cy = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
+            else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = UNI(a.ref[o * 4 + 3]); cx = UNI(a.mv[(o * 16 + 15) * 2]); cy = UNI(a.mv[(o * 16 + 15) * 2 + 1]); }
             // x264_mb_predict_mv_16x16, :90-128
             auto predict16 = [&](int i_ref, int &px, int &py) {
                 const int cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
@@ -914,7 +933,19 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         t.u[i] = r->plane[1]; t.v[i] = r->plane[2];
     }
     HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
-    hipLaunchKernelGGL(k_slice_sweep, dim3((unsigned)(a.batch_pad * a.mb_h)), dim3(64), 0, c->stream, a, t);
+    static int wpe = 0;
+    if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..4
+        const char *e = getenv("X264HIP_SWEEP_WPE");
+        wpe = e ? atoi(e) : 2;
+        if (wpe < 1 || wpe > 4) wpe = 2;
+    }
+    const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
+    switch (wpe) {
+    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
+    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
+    case 4: hipLaunchKernelGGL(k_slice_sweep<4>, grid, block, 0, c->stream, a, t); break;
+    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
+    }
     HIPCHK(hipGetLastError());
     // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
     out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;

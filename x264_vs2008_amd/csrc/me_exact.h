@@ -59,7 +59,8 @@ struct MxCtx {
     int sy, sc, lane;
     __device__ __forceinline__ int cost1(int d) const
     {
-        return (cost_l && (unsigned)(d + MX_COST_LDS) <= 2u * MX_COST_LDS) ? (int)cost_l[d + MX_COST_LDS] : (int)cost_g[d];
+        // d is wave-uniform: keep the looked-up cost in a scalar register
+        return __builtin_amdgcn_readfirstlane((cost_l && (unsigned)(d + MX_COST_LDS) <= 2u * MX_COST_LDS) ? (int)cost_l[d + MX_COST_LDS] : (int)cost_g[d]);
     }
     __device__ __forceinline__ int cost(int mx, int my) const { return cost1(mx - mvpx) + cost1(my - mvpy); }   // p_cost_mvx[mx] + p_cost_mvy[my]
 };
@@ -75,8 +76,8 @@ __device__ __forceinline__ void sad_fpel4(const MxCtx &c, const int fx[4], const
     const u32 *f = c.fe + 4 * row;
     u32 s = sad4(r[0], f[0], 0); s = sad4(r[1], f[1], s); s = sad4(r[2], f[2], s); s = sad4(r[3], f[3], s);
     int v = (int)s;
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-    out[0] = __shfl(v, 0, 64); out[1] = __shfl(v, 16, 64); out[2] = __shfl(v, 32, 64); out[3] = __shfl(v, 48, 64);
+    v = row_sum16(v);
+    out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16); out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
 }
 // the same for eight candidates: 8 lanes each, two picture rows per lane
 __device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const int fy[8], int out[8])
@@ -92,9 +93,9 @@ __device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const
     u32 s = sad4(a[0], f0[0], 0); s = sad4(a[1], f0[1], s); s = sad4(a[2], f0[2], s); s = sad4(a[3], f0[3], s);
     s = sad4(b[0], f1[0], s); s = sad4(b[1], f1[1], s); s = sad4(b[2], f1[2], s); s = sad4(b[3], f1[3], s);
     int v = (int)s;
-    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    v = half_sum8(v);
 #pragma unroll
-    for (int k = 0; k < 8; k++) out[k] = __shfl(v, 8 * k, 64);
+    for (int k = 0; k < 8; k++) out[k] = __builtin_amdgcn_readlane(v, 8 * k);
 }
 // SAD 16x16 of up to four quarter-pel candidates through get_ref's blend (mc.c:181-202)
 __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const int qy[4], int out[4])
@@ -114,8 +115,8 @@ __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const
     const u32 *f = c.fe + 4 * row;
     u32 s = sad4(a[0], f[0], 0); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
     int v = (int)s;
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-    out[0] = __shfl(v, 0, 64); out[1] = __shfl(v, 16, 64); out[2] = __shfl(v, 32, 64); out[3] = __shfl(v, 48, 64);
+    v = row_sum16(v);
+    out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16); out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
 }
 // vertical half of the 8x4 SATD when the four rows of a block sit in lanes l, l^1, l^2, l^3
 __device__ __forceinline__ int satd_rows4(u32 t0, u32 t1, u32 t2, u32 t3, int lane)
@@ -123,14 +124,13 @@ __device__ __forceinline__ int satd_rows4(u32 t0, u32 t1, u32 t2, u32 t3, int la
     u32 t[4] = {t0, t1, t2, t3}, acc = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        u32 v = t[k], o = (u32)__shfl_xor((int)v, 1, 64);
+        u32 v = t[k], o = (u32)dpp_mov<DPP_XOR1>((int)v);
         v = (lane & 1) ? o - v : v + o;                 // rows (0,1) and (2,3): sum / difference
-        o = (u32)__shfl_xor((int)v, 2, 64);
+        o = (u32)dpp_mov<DPP_XOR2>((int)v);
         v = (lane & 2) ? o - v : v + o;                 // second butterfly level
         acc += lanes_abs(v);
     }
-    acc += (u32)__shfl_xor((int)acc, 1, 64);
-    acc += (u32)__shfl_xor((int)acc, 2, 64);
+    acc = (u32)quad_sum4((int)acc);
     return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
 }
 
@@ -216,11 +216,10 @@ __device__ __forceinline__ void me_subpel_costs4(const MxCtx &c, const int qx[4]
         }
         v = blk8x4_cost(f, p, satd);
     }
-    const int s1 = v + __shfl_xor(v, 1, 64);
-    const int s2 = s1 + __shfl_xor(s1, 2, 64);
-    const int s4 = s2 + __shfl_xor(s2, 4, 64);
+    const int s1 = v + dpp_mov<DPP_XOR1>(v);         // pairs: the two 8x4 halves of a chroma plane
+    const int s4 = half_sum8(v);                     // the eight luma blocks
 #pragma unroll
-    for (int k = 0; k < 4; k++) { outL[k] = __shfl(s4, 16 * k, 64); outU[k] = __shfl(s1, 16 * k + 8, 64); outV[k] = __shfl(s1, 16 * k + 10, 64); }
+    for (int k = 0; k < 4; k++) { outL[k] = __builtin_amdgcn_readlane(s4, 16 * k); outU[k] = __builtin_amdgcn_readlane(s1, 16 * k + 8); outV[k] = __builtin_amdgcn_readlane(s1, 16 * k + 10); }
 }
 // COST_MV_SATD's running rule: chroma is added only while the sum is still below the best
 __device__ __forceinline__ int me_satd_total(const MxCtx &c, int chroma, int L, int U, int V, int mx, int my, int limit)
@@ -265,7 +264,7 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
                 ok[j] = false; cx[j] = px; cy[j] = py;
                 if (k == 0) ok[j] = true;
                 else if (k <= n_mvc) {
-                    const int vx = mvc[2 * (k - 1)], vy = mvc[2 * (k - 1) + 1];
+                    const int vx = __builtin_amdgcn_readfirstlane((int)mvc[2 * (k - 1)]), vy = __builtin_amdgcn_readfirstlane((int)mvc[2 * (k - 1) + 1]);
                     if ((vx | vy) && (vx != (int)(i16)px || vy != (int)(i16)py)) {
                         ok[j] = true; cx[j] = clip3(vx, L.fmin0 * 4, L.fmax0 * 4); cy[j] = clip3(vy, L.fmin1 * 4, L.fmax1 * 4);
                     }
@@ -294,7 +293,7 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
                 kind[j] = 0; cx[j] = pmx; cy[j] = pmy; ux[j] = uy[j] = 0;
                 if (k == 0) kind[j] = 1;
                 else if (k <= n_mvc) {
-                    ux[j] = (mvc[2 * (k - 1)] + 2) >> 2; uy[j] = (mvc[2 * (k - 1) + 1] + 2) >> 2;
+                    ux[j] = (__builtin_amdgcn_readfirstlane((int)mvc[2 * (k - 1)]) + 2) >> 2; uy[j] = (__builtin_amdgcn_readfirstlane((int)mvc[2 * (k - 1) + 1]) + 2) >> 2;
                     if (ux[j] | uy[j]) { kind[j] = 2; cx[j] = clip3(ux[j], L.fmin0, L.fmax0); cy[j] = clip3(uy[j], L.fmin1, L.fmax1); }
                 } else if (k == n_mvc + 1) { kind[j] = 3; cx[j] = 0; cy[j] = 0; }
             }

@@ -87,6 +87,9 @@ class ChainEncoder:
         self.t = 0
         self.last_idr = 0
         self.profile = None            # DeviceArray [batch][mb_h][8] int64 when phase timing is wanted
+        self.events = None             # set to [] to collect (start, stop, slice_type, n_refs) HIP events per sweep launch
+        lib.x264hip_event_create.restype = C.c_void_p
+        lib.x264hip_event_elapsed_ms.restype = C.c_float
 
     def cost_table(self, qp):
         if qp not in self.cost:
@@ -97,10 +100,11 @@ class ChainEncoder:
     def upload(self, y, u, v, b=0):
         self.ctx.upload(self.fenc, y, u, v, b=b)
 
-    def encode_frame(self):
-        """Sweep + loop filter + reference preparation for the frame uploaded to every batch element.
-        Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync()."""
+    def encode_frame(self, src=None):
+        """The macroblock sweep for the frame held by `src` (default: the picture upload() fills) in every
+        batch element.  Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync()."""
         L, c, o = self.lib, self.ctx, self.opt
+        fenc = self.fenc if src is None else src
         idr = (self.t % o["keyint"] == 0) if o["keyint"] > 0 else self.t == 0
         if idr:
             self.refs, self.last_idr = [], self.t
@@ -123,9 +127,15 @@ class ChainEncoder:
             p.ref_poc[i] = r[2]
         arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None
         l0 = C.byref(refs[0][1].st) if refs else None
-        c.check(L.x264hip_slice_sweep_frame(c.h, C.byref(self.fenc), arr, len(refs), C.byref(recon), C.byref(p), l0, C.byref(state.st)),
+        ev = None
+        if self.events is not None:            # HIP events on the launch stream around the sweep kernel (bench.py)
+            ev = (L.x264hip_event_create(), L.x264hip_event_create())
+            L.x264hip_event_record(C.c_void_p(ev[0]), C.c_void_p(c.stream))
+        c.check(L.x264hip_slice_sweep_frame(c.h, C.byref(fenc), arr, len(refs), C.byref(recon), C.byref(p), l0, C.byref(state.st)),
                 "slice_sweep_frame")
-        self.unfiltered = None
+        if ev:
+            L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
+            self.events.append((ev[0], ev[1], stype, len(refs)))
         self.last = (recon, state)
         return stype, qp, state
 

@@ -50,8 +50,10 @@ struct SwArgs {
     int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS];
     int l0_n_ref0, l0_inv_ref_poc[SW_MAX_REFS];
     int me_method, me_range, subme, chroma_me, fast_pskip, dct_decimate, cabac, mv_range;
-    const u16 *q4mf, *q4bias;
-    const int *dq4;
+    int flags_intra;            // X264_ANALYSE_I4x4 | I8x8 bits that apply to this slice type (param.analyse.intra / .inter)
+    int transform8x8;
+    const u16 *q4mf, *q4bias, *q8mf, *q8bias;
+    const int *dq4, *dq8;
     const i16 *cost_mv;
     int cost_center;
     const u8 *fy, *fu, *fv;
@@ -79,6 +81,17 @@ struct SwLds {
     u8 nnz[32];
     i16 mvc[8][2];
     i16 left_mvr[SW_MAX_REFS][2];
+    // intra 4x4 / 8x8 analysis: prediction-mode cache in x264_scan8 layout, edge arrays, and what the reference keeps
+    // when i_skip_intra is set (the partly encoded macroblock of the analysis is the final one, macroblock.c:527-577)
+    signed char i4c[48];
+    u8 e4[16], edge8[40];
+    u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
+    i16 lv_y8[256];             // levels of the 8x8 transform (h->dct.luma8x8), separate from the 4x4 ones like the reference's
+    i16 t8[256];                // 8x8 transform: intermediate between the two 1-D passes
+    signed char left_i4[4];     // the left macroblock's modes of blocks 5, 7, 13, 15
+    signed char pred4[16], pred8[4];
+    u16 q8mf[2][64], q8bias[2][64];
+    int q8dq[2][64];
     // this frame's quantiser rows (cat 0 intra Y, 1 inter Y at qp; 2 intra C, 3 inter C at the chroma qp) and the centre of p_cost_mv
     u16 qmf[4][16], qbias[4][16];
     int qdq[4][16];
@@ -516,6 +529,253 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
     return ok;
 }
 
+// ---- 8x8 transform path (R/common/dct.c:238-349, quant 8x8, scan, decimate_score64) --------------
+// forward transform + quant + scan of the 8x8 luma blocks in `mask`, all at once: lane = (block b, column / row k)
+// for the two 1-D passes (32 lanes), then 64 lanes x one coefficient per block.  Leaves the quantised
+// coefficients (transposed storage) in s.coef[4*b..][..] = [4][64], levels in s.lv_y8, per block
+// s.score[b] = decimate_score64 | nz << 8.  cat: 0 intra, 1 inter.
+__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane)
+{
+    i16 *tmp = s.t8, *coef = &s.coef[0][0];
+    const int b = lane >> 3, k8 = lane & 7;
+    const bool on = lane < 32 && ((mask >> b) & 1);
+    if (on) {
+        const u8 *p1 = s.fe + (b >> 1) * 8 * 16 + (b & 1) * 8 + k8, *p2 = s.fd + FDY + (b >> 1) * 8 * FD + (b & 1) * 8 + k8;
+        int v[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (int)p1[k * 16] - (int)p2[k * FD];
+        fwd8_1d(o, v);                                 // column k8
+#pragma unroll
+        for (int k = 0; k < 8; k++) tmp[64 * b + k * 8 + k8] = (i16)o[k];
+    }
+    WAVE_SYNC();
+    if (on) {
+        int v[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = tmp[64 * b + k8 * 8 + k];
+        fwd8_1d(o, v);                                 // row k8, stored transposed (dct.c:278-283)
+#pragma unroll
+        for (int k = 0; k < 8; k++) coef[64 * b + k * 8 + k8] = (i16)o[k];
+    }
+    WAVE_SYNC();
+    const int mfl = s.q8mf[cat][lane], bsl = s.q8bias[cat][lane];
+    unsigned long long nzmask[4] = {0, 0, 0, 0}, bigmask[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((mask >> j) & 1) {
+            int q = quant_one(coef[64 * j + lane], mfl, bsl);
+            coef[64 * j + lane] = (i16)q;
+            nzmask[j] = __ballot(q != 0);
+        }
+    WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((mask >> j) & 1) {
+            int lvv = nzmask[j] ? (int)coef[64 * j + c_scan8[0][lane]] : 0;
+            s.lv_y8[64 * j + lane] = (i16)lvv;
+            nzmask[j] = __ballot(lvv != 0);
+            bigmask[j] = __ballot((unsigned)(lvv + 1) > 2u);
+        }
+    if (lane < 4 && ((mask >> lane) & 1)) {
+        unsigned long long m = lane == 0 ? nzmask[0] : lane == 1 ? nzmask[1] : lane == 2 ? nzmask[2] : nzmask[3];
+        unsigned long long bg = lane == 0 ? bigmask[0] : lane == 1 ? bigmask[1] : lane == 2 ? bigmask[2] : bigmask[3];
+        int sc = 0;
+        if (bg) sc = 9;
+        else {
+            int idx = m ? 63 - __clzll(m) : -1;
+            while (idx >= 0) {
+                unsigned long long below = idx ? (m & ((1ull << idx) - 1)) : 0ull;
+                int prev = below ? 63 - __clzll(below) : -1;
+                sc += c_decimate8[idx - prev - 1];
+                idx = prev;
+            }
+        }
+        s.score[lane] = sc | ((m != 0) << 8);
+    }
+    WAVE_SYNC();
+}
+// dequant + inverse 8x8 + add for the blocks in `keep`
+__device__ __forceinline__ void sw_luma8x8_add(SwLds &s, int cat, int qp, int keep, int lane)
+{
+    i16 *coef = &s.coef[0][0];
+    const int b = lane >> 3, k8 = lane & 7, bits = qp / 6 - 6, dql = s.q8dq[cat][lane];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((keep >> j) & 1) {
+            int v = dequant_one(coef[64 * j + lane], dql, bits);
+            if (lane == 0) v = (int)(i16)(v + 32);           // rounding term, dct.c:326
+            coef[64 * j + lane] = (i16)v;
+        }
+    WAVE_SYNC();
+    const bool on = lane < 32 && ((keep >> b) & 1);
+    if (on) {
+        int v[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = coef[64 * b + k * 8 + k8];
+        inv8_1d(o, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) coef[64 * b + k * 8 + k8] = (i16)o[k];
+    }
+    WAVE_SYNC();
+    if (on) {
+        u8 *dst = s.fd + FDY + (b >> 1) * 8 * FD + (b & 1) * 8;
+        int v[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = coef[64 * b + k8 * 8 + k];
+        inv8_1d(o, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { u8 *p = dst + k8 + k * FD; *p = (u8)clip_u8((int)*p + (o[k] >> 6)); }
+    }
+    WAVE_SYNC();
+}
+// inter, 8x8 transform (R/encoder/macroblock.c:627-669); returns cbp_luma, fills s.nnz[0..15]
+__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane)
+{
+    sw_luma8x8_fwd(s, 1, 0xf, lane);
+    int cbp = 0, dec_mb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = __builtin_amdgcn_readfirstlane(s.score[i]);
+        if (v >> 8) {
+            if (a.dct_decimate) { dec_mb += v & 255; if ((v & 255) >= 4) cbp |= 1 << i; }
+            else cbp |= 1 << i;
+        }
+    }
+    if (a.dct_decimate && dec_mb < 6) cbp = 0;
+    if (lane < 16) s.nnz[lane] = (u8)((cbp >> (lane >> 2)) & 1);
+    WAVE_SYNC();
+    sw_luma8x8_add(s, 1, a.qp, cbp, lane);
+    return cbp;
+}
+// x264_mb_encode_i8x8 for block idx (prediction already in s.fd)
+__device__ __forceinline__ void sw_encode_i8x8(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
+{
+    sw_luma8x8_fwd(s, 0, 1 << idx, lane);
+    const int nz = (__builtin_amdgcn_readfirstlane(s.score[idx]) >> 8) & 1;
+    if (lane < 4) s.nnz[4 * idx + lane] = (u8)nz;
+    WAVE_SYNC();
+    if (nz) { cbp_luma |= 1 << idx; sw_luma8x8_add(s, 0, a.qp, 1 << idx, lane); }
+}
+// x264_mb_encode_i4x4 for block idx (prediction already in s.fd): one lane, a 4x4 block is 16 coefficients
+__device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
+{
+    int bx, by;
+    sw_blk_xy(idx, bx, by);
+    if (lane == 0) {
+        int r[16], res[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
+        i16 c[16], lv[16];
+        fwd4x4(c, r);
+        int nz = 0;
+        const int bits = a.qp / 6 - 4;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], s.qmf[0][i], s.qbias[0][i]); c[i] = (i16)q; nz |= q; }
+        s.nnz[idx] = (u8)(nz != 0);
+        if (nz) {
+            SCAN4_FRAME(lv, c);
+#pragma unroll
+            for (int i = 0; i < 16; i++) { s.lv_y[16 * idx + i] = lv[i]; c[i] = (i16)dequant_one(c[i], s.qdq[0][i], bits); }
+            inv4x4(res, c);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) { u8 *p = s.fd + FDY + (by + j) * FD + bx + i; *p = (u8)clip_u8((int)*p + res[4 * j + i]); }
+        }
+        s.keep8 = nz != 0;
+    }
+    WAVE_SYNC();
+    if (__builtin_amdgcn_readfirstlane(s.keep8)) cbp_luma |= 1 << (idx >> 2);
+}
+
+// ---- intra 4x4 / 8x8 analysis helpers ------------------------------------------------------------
+// i_neighbour4 / i_neighbour8 (R/common/macroblock.c:733-743, 1172-1186)
+__device__ __forceinline__ int sw_nb4(int idx, int nb)
+{
+    const int all = NB_LEFT | NB_TOP | NB_TOPLEFT | NB_TOPRIGHT;
+    switch (idx) {
+    case 0: return (nb & (NB_TOP | NB_LEFT | NB_TOPLEFT)) | ((nb & NB_TOP) ? NB_TOPRIGHT : 0);
+    case 1: case 4: return NB_LEFT | ((nb & NB_TOP) ? (NB_TOP | NB_TOPLEFT | NB_TOPRIGHT) : 0);
+    case 2: case 8: case 10: return NB_TOP | NB_TOPRIGHT | ((nb & NB_LEFT) ? (NB_LEFT | NB_TOPLEFT) : 0);
+    case 5: return NB_LEFT | (nb & NB_TOPRIGHT) | ((nb & NB_TOP) ? NB_TOP | NB_TOPLEFT : 0);
+    case 6: case 9: case 12: case 14: return all;
+    default: return NB_LEFT | NB_TOP | NB_TOPLEFT;          // 3 7 11 13 15
+    }
+}
+__device__ __forceinline__ int sw_nb8(int idx, int nb)
+{
+    switch (idx) {
+    case 0: return (nb & (NB_TOP | NB_LEFT | NB_TOPLEFT)) | ((nb & NB_TOP) ? NB_TOPRIGHT : 0);
+    case 1: return NB_LEFT | (nb & NB_TOPRIGHT) | ((nb & NB_TOP) ? NB_TOP | NB_TOPLEFT : 0);
+    case 2: return NB_TOP | NB_TOPRIGHT | ((nb & NB_LEFT) ? (NB_LEFT | NB_TOPLEFT) : 0);
+    default: return NB_LEFT | NB_TOP | NB_TOPLEFT;
+    }
+}
+// predict_4x4_mode_available (R/encoder/analyse.c:435-471) as a nibble list: mode i = (list >> 4i) & 15
+__device__ __forceinline__ unsigned long long sw_modes4(int nb, int &n)
+{
+    if ((nb & NB_LEFT) && (nb & NB_TOP)) {
+        if (nb & NB_TOPLEFT) { n = 9; return 0x876543012ull; }
+        n = 6; return 0x873012ull;
+    }
+    if (nb & NB_LEFT) { n = 3; return 0x819ull; }
+    if (nb & NB_TOP) { n = 4; return 0x730Aull; }
+    n = 1; return 0xBull;
+}
+__device__ __forceinline__ int sw_scan8(int i) { int x, y; sw_blk_xy(i, x, y); return 4 + 1 * 8 + (x >> 2) + 8 * (y >> 2); }
+__device__ __forceinline__ int sw_fix4(int m) { return m < 0 ? -1 : m < 9 ? m : 2; }      // x264_mb_pred_mode4x4_fix
+// x264_mb_predict_intra4x4_mode (R/common/macroblock.h:423-434)
+__device__ __forceinline__ int sw_pred_i4mode(const SwLds &s, int idx)
+{
+    const int ma = sw_fix4(__builtin_amdgcn_readfirstlane((int)s.i4c[sw_scan8(idx) - 1]));
+    const int mb = sw_fix4(__builtin_amdgcn_readfirstlane((int)s.i4c[sw_scan8(idx) - 8]));
+    const int m = ma < mb ? ma : mb;
+    return m < 0 ? 2 : m;
+}
+// SATD / SAD of a 4x4 block from one row of differences per lane (rows of a block in lanes l, l^1, l^2, l^3); pixel.c:187-212
+__device__ __forceinline__ int sw_cost4x4_rows(int d0, int d1, int d2, int d3, int satd, int lane)
+{
+    if (!satd) return quad_sum4(iabs(d0) + iabs(d1) + iabs(d2) + iabs(d3));
+    const u32 e0 = (u32)(d0 + d1) + ((u32)(d0 - d1) << 16), e1 = (u32)(d2 + d3) + ((u32)(d2 - d3) << 16);
+    u32 c[2] = {e0 + e1, e0 - e1}, acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        u32 v = c[k], o = (u32)dpp_mov<DPP_XOR1>((int)v);
+        v = (lane & 1) ? o - v : v + o;
+        o = (u32)dpp_mov<DPP_XOR2>((int)v);
+        v = (lane & 2) ? o - v : v + o;
+        acc += lanes_abs(v);
+    }
+    acc = (u32)quad_sum4((int)acc);
+    return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
+}
+// unnormalised 8x8 Hadamard SATD of a block from one row per lane (rows in 8 consecutive lanes); pixel.c:256-289
+__device__ __forceinline__ int sw_sa8d_rows(const u8 *f, const u8 *p, int lane)
+{
+    u32 e[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int d0 = (int)f[2 * k] - (int)p[2 * k], d1 = (int)f[2 * k + 1] - (int)p[2 * k + 1];
+        e[k] = (u32)(d0 + d1) + ((u32)(d0 - d1) << 16);
+    }
+    wht4(t[0], t[1], t[2], t[3], e[0], e[1], e[2], e[3]);
+    u32 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 v = t[k], o = (u32)dpp_mov<DPP_XOR1>((int)v);
+        v = (lane & 1) ? o - v : v + o;
+        o = (u32)dpp_mov<DPP_XOR2>((int)v);
+        v = (lane & 2) ? o - v : v + o;
+        o = (u32)__shfl_xor((int)v, 4, 64);
+        v = (lane & 4) ? o - v : v + o;
+        acc += lanes_abs(v);
+    }
+    return half_sum8((int)((acc & 0xffffu) + (acc >> 16)));
+}
+
 __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // WPE = waves per SIMD the register allocation is held to.  A row wave spends most of its time waiting
@@ -545,13 +805,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
         if (is_p)
             for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = a.cost_mv[a.cost_center - MX_COST_LDS + k];
+        if (a.transform8x8)
+            for (int c8 = 0; c8 < 2; c8++) {
+                s.q8mf[c8][lane] = a.q8mf[(c8 * 52 + a.qp) * 64 + lane]; s.q8bias[c8][lane] = a.q8bias[(c8 * 52 + a.qp) * 64 + lane];
+                s.q8dq[c8][lane] = a.dq8[c8 * 384 + (a.qp % 6) * 64 + lane];
+            }
     }
     WAVE_SYNC();
 
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptime = a.prof ? (long long)wall_clock64() : 0;
 #define PROF(k_) do { if (a.prof) { long long now_ = (long long)wall_clock64(); pacc[k_] += now_ - ptime; ptime = now_; } } while (0)
     // the left neighbour = this wave's previous macroblock
-    int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0;
+    int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0, row_intra = 0;
     u32 pre_y;
     u8 pre_u, pre_v;
     {
@@ -618,6 +883,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 
         int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0;
         int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
+        int satd_i8 = MX_COST_MAX, satd_i4 = MX_COST_MAX, i8_cbp = 0, i4_cbp = 0, t8 = 0;
+        if (a.flags_intra & 3) {
+            // intra4x4_pred_mode cache (R/common/macroblock.c:907-980): -1 where there is no neighbour; the frame array holds
+            // I_PRED_4x4_DC for every macroblock that is not I_4x4 / I_8x8
+            if (lane < 48) s.i4c[lane] = -1;
+            WAVE_SYNC();
+            if ((nb & NB_TOP) && lane < 4)
+                s.i4c[4 + lane] = a.i4mode[(size_t)(mb - a.mb_w) * 16 + (lane == 0 ? 10 : lane == 1 ? 11 : lane == 2 ? 14 : 15)];
+            if ((nb & NB_LEFT) && lane >= 8 && lane < 12) s.i4c[11 + 8 * (lane - 8)] = s.left_i4[lane - 8];
+            WAVE_SYNC();
+        }
         int stat_intra = 0, stat_inter = 0, analysed = 0;
 
         // x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610
@@ -630,19 +906,159 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 if (c < satd_chroma) { satd_chroma = c; predc = m[i]; }
             }
         };
-        // x264_mb_analyse_intra, :612-658 (16x16 part)
-        auto analyse_intra16 = [&]() {
-            int m[4], n = sw_modes16(nb, m);
-            for (int i = 0; i < n; i++) {
-                sw_pred16(s, m[i], lane);
-                int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m[i]));
-                if (c < satd_i16) { satd_i16 = c; pred16 = m[i]; }
+        // a->b_fast_intra (R/encoder/analyse.c:345-362), evaluated only when its value matters.  Its last term counts
+        // the intra macroblocks BEFORE this one in raster order, some of which (to the right in the rows above) may
+        // not be coded yet: bound the count from what the rows above have published, and wait only while the
+        // bounds leave the answer open (the rows above never wait for this one, so this terminates).
+        auto fast_intra_now = [&]() -> int {
+            if (!is_p || mb <= 4) return 0;
+            if (IS_INTRA_T(left_type) || IS_INTRA_T(type_top) || IS_INTRA_T(type_topleft) || IS_INTRA_T(type_topright)) return 0;
+            if (a.l0_type && IS_INTRA_T(UNI(a.l0_type[mb]))) return 0;
+            for (int spins = 0;; spins++) {
+                int known = row_intra, pending = 0;
+                for (int r0 = 0; r0 < mby; r0 += 64) {
+                    const int r = r0 + lane;
+                    const int v = r < mby ? __hip_atomic_load(prog + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    known += wave_sum(r < mby ? v >> 16 : 0);
+                    pending += wave_sum(r < mby ? a.mb_w - (v & 0xffff) : 0);
+                }
+                if (mb < 3 * known) return 0;
+                if (mb >= 3 * (known + pending)) return 1;
+                __builtin_amdgcn_s_sleep(100);
+                if (spins > SW_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+            }
+        };
+        // x264_mb_analyse_intra, R/encoder/analyse.c:612-843
+        auto analyse_intra = [&](int satd_inter) {
+            {
+                int m[4], n = sw_modes16(nb, m);
+                for (int i = 0; i < n; i++) {
+                    sw_pred16(s, m[i], lane);
+                    int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m[i]));
+                    if (c < satd_i16) { satd_i16 = c; pred16 = m[i]; }
+                }
+            }
+            if (!(a.flags_intra & 3)) return;
+            if (satd_i16 > 2 * satd_inter && fast_intra_now()) return;
+            if (a.flags_intra & 2) {                                   // X264_ANALYSE_I8x8
+                const int thresh = min(satd_inter, satd_i16);
+                int cost = 0, idx, acbp = 0;
+                for (idx = 0;; idx++) {
+                    const int bx = 8 * (idx & 1), by = 8 * (idx >> 1), pm = sw_pred_i4mode(s, 4 * idx), nb8 = sw_nb8(idx, nb);
+                    int n;
+                    const unsigned long long list = sw_modes4(nb8, n);
+                    if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + by * FD + bx, FD, nb8, 0xf);
+                    WAVE_SYNC();
+                    int best = MX_COST_MAX, bmode = 0;
+#pragma unroll
+                    for (int pass = 0; pass < 2; pass++) {
+                        const int g = (lane >> 3) + 8 * pass, r = lane & 7;
+                        int c = 0;
+                        if (g < n) {
+                            const int mode = (int)((list >> (4 * g)) & 15);
+                            u8 pr[8];
+#pragma unroll
+                            for (int x = 0; x < 8; x++) pr[x] = (u8)pred8_px(mode, s.edge8, x, r);
+                            const u8 *f = s.fe + (by + r) * 16 + bx;
+                            if (satd) c = sw_sa8d_rows(f, pr, lane);
+                            else {
+                                int sd = 0;
+#pragma unroll
+                                for (int x = 0; x < 8; x++) sd += iabs((int)f[x] - (int)pr[x]);
+                                c = half_sum8(sd);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int slot = k + 8 * pass;
+                            if (slot < n) {
+                                const int mode = (int)((list >> (4 * slot)) & 15);
+                                int ck = __builtin_amdgcn_readlane(c, 8 * k);
+                                if (satd) ck = (ck + 2) >> 2;
+                                ck += a.lambda * (pm == sw_fix4(mode) ? 1 : 4);
+                                if (ck < best) { best = ck; bmode = mode; }
+                            }
+                        }
+                    }
+                    cost += best;
+                    if (lane == 0) s.pred8[idx] = (signed char)bmode;
+                    if (idx == 3 || cost > thresh) break;
+                    {
+                        const int v = pred8_px(bmode, s.edge8, lane & 7, lane >> 3);
+                        WAVE_SYNC();
+                        s.fd[FDY + (by + (lane >> 3)) * FD + bx + (lane & 7)] = (u8)v;
+                        if (lane < 4) s.i4c[sw_scan8(4 * idx) + (lane & 1) + 8 * (lane >> 1)] = (signed char)bmode;
+                        WAVE_SYNC();
+                    }
+                    sw_encode_i8x8(s, a, idx, acbp, lane);
+                }
+                if (idx == 3) {
+                    satd_i8 = cost; i8_cbp = acbp;
+                    *(u32 *)(s.i8_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
+                    if (lane < 16) s.i8_nnz[lane] = s.nnz[lane];
+                    WAVE_SYNC();
+                } else {
+                    satd_i8 = MX_COST_MAX;
+                    cost = (cost * (idx == 0 ? 1024 : idx == 1 ? 512 : 341)) >> 8;
+                }
+                if (min(cost, satd_i16) > satd_inter * 5 / 4) return;
+            }
+            if (a.flags_intra & 1) {                                   // X264_ANALYSE_I4x4
+                const int thresh = min(min(satd_inter, satd_i16), satd_i8);
+                int cost = a.lambda * 24, idx, acbp = 0;
+                for (idx = 0;; idx++) {
+                    int bx, by, n;
+                    sw_blk_xy(idx, bx, by);
+                    const int pm = sw_pred_i4mode(s, idx), nb4 = sw_nb4(idx, nb);
+                    const unsigned long long list = sw_modes4(nb4, n);
+                    u8 *dst = s.fd + FDY + by * FD + bx;
+                    if ((nb4 & (NB_TOPRIGHT | NB_TOP)) == NB_TOP && lane < 4) dst[4 - FD + lane] = dst[3 - FD];    // emulate missing topright samples
+                    WAVE_SYNC();
+                    if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
+                    WAVE_SYNC();
+                    int c = 0;
+                    {
+                        const int g = lane >> 2, r = lane & 3;
+                        if (g < n) {
+                            const int mode = (int)((list >> (4 * g)) & 15);
+                            const u8 *f = s.fe + (by + r) * 16 + bx;
+                            const int d0 = (int)f[0] - pred4_px(mode, s.e4, 0, r), d1 = (int)f[1] - pred4_px(mode, s.e4, 1, r);
+                            const int d2 = (int)f[2] - pred4_px(mode, s.e4, 2, r), d3 = (int)f[3] - pred4_px(mode, s.e4, 3, r);
+                            c = sw_cost4x4_rows(d0, d1, d2, d3, satd, lane);
+                        }
+                    }
+                    int best = MX_COST_MAX, bmode = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (k < n) {
+                            const int mode = (int)((list >> (4 * k)) & 15);
+                            const int ck = __builtin_amdgcn_readlane(c, 4 * k) + a.lambda * (pm == sw_fix4(mode) ? 1 : 4);
+                            if (ck < best) { best = ck; bmode = mode; }
+                        }
+                    cost += best;
+                    if (lane == 0) s.pred4[idx] = (signed char)bmode;
+                    if (cost > thresh || idx == 15) break;
+                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)pred4_px(bmode, s.e4, lane & 3, lane >> 2);
+                    if (lane == 0) s.i4c[sw_scan8(idx)] = (signed char)bmode;
+                    WAVE_SYNC();
+                    sw_encode_i4x4(s, a, idx, acbp, lane);
+                }
+                if (idx == 15) {
+                    satd_i4 = cost; i4_cbp = acbp;
+                    *(u32 *)(s.i4_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
+                    if (lane < 16) s.i4_nnz[lane] = s.nnz[lane];
+                    WAVE_SYNC();
+                } else
+                    satd_i4 = MX_COST_MAX;
             }
         };
 
         if (!is_p) {
-            analyse_intra16();
+            analyse_intra(MX_COST_MAX);
             type = T_I_16x16;
+            int i_cost = satd_i16;
+            if (satd_i4 < i_cost) { i_cost = satd_i4; type = T_I_4x4; }
+            if (satd_i8 < i_cost) { i_cost = satd_i8; type = T_I_8x8; }
         } else {
             // ---- motion neighbours: what cache_load puts around the block (R/common/macroblock.c:1040-1128) ----
             int ra = left_ref, ax = left_mvx, ay = left_mvy;                 // A
@@ -741,15 +1157,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     int i_cost = best;
                     if (a.chroma_me) {
                         analyse_chroma();
-                        analyse_intra16();
-                        satd_i16 += satd_chroma;
+                        analyse_intra(i_cost - satd_chroma);
+                        satd_i16 += satd_chroma; satd_i8 += satd_chroma; satd_i4 += satd_chroma;
                     } else
-                        analyse_intra16();
-                    int icost = satd_i16;
-                    stat_inter = i_cost;
-                    if (icost < i_cost) { i_cost = icost; type = T_I_16x16; }
+                        analyse_intra(i_cost);
+                    // analyse.c:2372-2400: best intra type (16x16, then 8x8, then 4x4 on strict improvement) against inter
+                    int itype = T_I_16x16, icost = satd_i16;
+                    if (satd_i8 < icost) { icost = satd_i8; itype = T_I_8x8; }
+                    if (satd_i4 < icost) { icost = satd_i4; itype = T_I_4x4; }
+                    if (icost < i_cost) { i_cost = icost; type = itype; }
                     stat_intra = icost; analysed = 1;
-                    stat_inter = type == T_P_L0 ? i_cost : icost;
+                    stat_inter = i_cost;
                 }
             }
         }
@@ -775,15 +1193,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 cbp_luma = sw_encode_i16x16(s, a, lane);
                 sw_pred8c(s, predc, lane);
                 cbp_chroma = sw_encode_chroma(s, a, 0, lane);
+            } else if (type == T_I_8x8 || type == T_I_4x4) {
+                // x264_analyse_update_cache: the winner's modes into the cache; then macroblock.c:527-590 with i_skip_intra:
+                // the analysis already encoded all blocks but the last, take its state and finish
+                const bool i8 = type == T_I_8x8;
+                if (lane < 16) s.i4c[sw_scan8(lane)] = i8 ? s.pred8[lane >> 2] : s.pred4[lane];
+                analyse_chroma();
+                *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)((i8 ? s.i8_fdec : s.i4_fdec) + lane * 4);
+                if (lane < 16) s.nnz[lane] = i8 ? s.i8_nnz[lane] : s.i4_nnz[lane];
+                cbp_luma = i8 ? i8_cbp : i4_cbp;
+                WAVE_SYNC();
+                if (i8) {
+                    t8 = 1;
+                    const int mode = __builtin_amdgcn_readfirstlane((int)s.pred8[3]), nb8 = sw_nb8(3, nb);
+                    // x264_pred_i4x4_neighbors (R/common/macroblock.h:40-54)
+                    const int need = mode == 0 || mode == 10 ? NB_TOP : mode == 1 || mode == 8 || mode == 9 ? NB_LEFT : mode == 2 ? NB_LEFT | NB_TOP
+                                   : mode == 3 || mode == 7 ? NB_TOP | NB_TOPRIGHT : mode == 11 ? 0 : NB_LEFT | NB_TOPLEFT | NB_TOP;
+                    if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + 8 * FD + 8, FD, nb8, need);
+                    WAVE_SYNC();
+                    const int v = pred8_px(mode, s.edge8, lane & 7, lane >> 3);
+                    WAVE_SYNC();
+                    s.fd[FDY + (8 + (lane >> 3)) * FD + 8 + (lane & 7)] = (u8)v;
+                    WAVE_SYNC();
+                    sw_encode_i8x8(s, a, 3, cbp_luma, lane);
+                } else {
+                    u8 *dst = s.fd + FDY + 12 * FD + 12;
+                    const int mode = __builtin_amdgcn_readfirstlane((int)s.pred4[15]);
+                    if ((sw_nb4(15, nb) & (NB_TOPRIGHT | NB_TOP)) == NB_TOP && lane < 4) dst[4 - FD + lane] = dst[3 - FD];
+                    WAVE_SYNC();
+                    if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
+                    WAVE_SYNC();
+                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)pred4_px(mode, s.e4, lane & 3, lane >> 2);
+                    WAVE_SYNC();
+                    sw_encode_i4x4(s, a, 15, cbp_luma, lane);
+                }
+                sw_pred8c(s, predc, lane);
+                cbp_chroma = sw_encode_chroma(s, a, 0, lane);
             } else {
                 sw_mc16(s, refs, a, ref, mvx, mvy, oy, oc, by_, bc_, lane, true);
                 WAVE_SYNC();
-                cbp_luma = sw_encode_inter_luma(s, a, lane);
+                if (a.transform8x8) {
+                    // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
+                    int raw = 0;
+                    if (lane < 32) {
+                        const int blk = lane >> 3, r = lane & 7;
+                        raw = sw_sa8d_rows(s.fe + ((blk >> 1) * 8 + r) * 16 + (blk & 1) * 8, s.fd + FDY + ((blk >> 1) * 8 + r) * FD + (blk & 1) * 8, lane);
+                    }
+                    const int c8 = (__builtin_amdgcn_readlane(raw, 0) + __builtin_amdgcn_readlane(raw, 8) + __builtin_amdgcn_readlane(raw, 16)
+                                    + __builtin_amdgcn_readlane(raw, 24) + 2) >> 2;
+                    const int c4 = sw_cmp_luma16(s, 1, lane);
+                    t8 = c8 < c4;
+                }
+                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane) : sw_encode_inter_luma(s, a, lane);
                 cbp_chroma = sw_encode_chroma(s, a, 1, lane);
                 if (!(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
             }
         }
         const int intra = IS_INTRA_T(type);
+        if (cbp_luma == 0 && type != T_I_8x8) t8 = 0;           // x264_macroblock_cache_save, R/common/macroblock.c:1273-1275
         PROF(3);
 
         // ---- x264_macroblock_cache_save: reconstruction, per-macroblock state, levels ----
@@ -798,7 +1265,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (lane < 16) {
             a.mv[((size_t)mb * 16 + lane) * 2] = (i16)(intra ? 0 : mvx);
             a.mv[((size_t)mb * 16 + lane) * 2 + 1] = (i16)(intra ? 0 : mvy);
-            a.i4mode[(size_t)mb * 16 + lane] = 2;
+            const bool i48 = type == T_I_4x4 || type == T_I_8x8;
+            a.i4mode[(size_t)mb * 16 + lane] = i48 ? s.i4c[sw_scan8(lane)] : (signed char)2;
+            if (lane == 5 || lane == 7 || lane == 13 || lane == 15)       // what the next macroblock sees to its left
+                s.left_i4[lane == 5 ? 0 : lane == 7 ? 1 : lane == 13 ? 2 : 3] = i48 ? s.i4c[sw_scan8(lane)] : (signed char)2;
         }
         if (lane < 4) a.ref[(size_t)mb * 4 + lane] = (signed char)(is_p ? (intra ? -1 : ref) : -1);
         if (lane < 27) a.nnz[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
@@ -809,7 +1279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             a.i16mode[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
             a.chroma_mode[mb] = (signed char)(intra ? predc : 0);
             a.qp_out[mb] = (signed char)a.qp;
-            a.t8[mb] = 0;
+            a.t8[mb] = (signed char)t8;
             a.cbp[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
             a.cost_intra[mb] = stat_intra; a.cost_inter[mb] = stat_inter;
         }
@@ -819,7 +1289,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int i = lane + 64 * k, blk = i >> 4;
-                ly[i] = (coded && ((cbp_luma >> (blk >> 2)) & 1) && s.nnz[blk]) ? s.lv_y[i] : (i16)0;
+                ly[i] = (coded && ((cbp_luma >> (blk >> 2)) & 1) && s.nnz[blk]) ? (t8 ? s.lv_y8[i] : s.lv_y[i]) : (i16)0;
             }
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -834,7 +1304,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // ---- publish: everything this macroblock wrote is visible before the count moves ----
         __threadfence();
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(prog + mby, mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        row_intra += intra;
+        if (lane == 0) __hip_atomic_store(prog + mby, (mbx + 1) | (row_intra << 16), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         PROF(5);
     }
     if (a.prof && lane < 8) {
@@ -892,7 +1363,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
     if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
     if (p->me_method < 0 || p->me_method > 1) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX)", p->me_method); return -1; }
-    if ((p->analyse_inter | p->analyse_intra) != 0 || p->transform8x8) { set_error("slice_sweep: sub-partitions / i4x4 / i8x8 / 8x8dct not built yet"); return -1; }
+    if (p->analyse_inter & 0x30) { set_error("slice_sweep: sub-16x16 inter partitions (p8x8, p4x4) not built yet"); return -1; }
+    if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
     SwArgs a;
@@ -918,6 +1390,11 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.chroma_me = p->chroma_me && is_p && p->subme >= 5;            // h->mb.b_chroma_me, analyse.c:234-235
     a.fast_pskip = p->fast_pskip; a.dct_decimate = p->dct_decimate; a.cabac = p->cabac; a.mv_range = p->mv_range > 0 ? p->mv_range : 512;
     a.q4mf = p->quant4_mf; a.q4bias = p->quant4_bias; a.dq4 = p->dequant4_mf;
+    a.q8mf = p->quant8_mf; a.q8bias = p->quant8_bias; a.dq8 = p->dequant8_mf;
+    a.transform8x8 = p->transform8x8 != 0;
+    // x264_mb_analyse_intra takes its flags from param.analyse.intra in I slices and from .inter in P slices (analyse.c:614);
+    // i8x8 needs the 8x8 transform (x264_validate_parameters, R/encoder/encoder.c:487-491)
+    a.flags_intra = (is_p ? p->analyse_inter : p->analyse_intra) & (a.transform8x8 ? 3 : 1);
     a.cost_mv = p->cost_mv; a.cost_center = p->cost_mv_range;
     a.fy = fenc->plane[0]; a.fu = fenc->plane[1]; a.fv = fenc->plane[2];
     a.dy = recon->plane[0]; a.du = recon->plane[1]; a.dv = recon->plane[2];

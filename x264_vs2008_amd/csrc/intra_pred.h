@@ -6,11 +6,12 @@
 // Directional intra prediction of pixel (x,y) of an NxN block from an edge
 // array e[] with e[n-1-k] = left k, e[n] = top-left, e[n+1+k] = top k
 // (H.264 8.3.1.2 / 8.3.2.2; R/common/predict.c:398-497, :618-751).
-__device__ int dir_pred_px(int n, int mode, const int *e, int x, int y)
+template <typename E>   // const int * (private array) or const u8 * (edge bytes in LDS)
+__device__ int dir_pred_px(int n, int mode, E e, int x, int y)
 {
-#define EL(k) e[n - 1 - (k)]
-#define ET(k) e[n + 1 + (k)]
-#define EZ(k) e[n + (k)]
+#define EL(k) ((int)e[n - 1 - (k)])
+#define ET(k) ((int)e[n + 1 + (k)])
+#define EZ(k) ((int)e[n + (k)])
 #define F1(a, b) (((a) + (b) + 1) >> 1)
 #define F2(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
     switch (mode) {
@@ -103,5 +104,64 @@ __device__ int pred_px(int fam, int mode, const u8 *s, int ls, int x, int y)
     e[4] = PX(-1, -1);
     for (int k = 0; k < 8; k++) e[5 + k] = PX(k, -1);
     return dir_pred_px(4, mode, e, x, y);
+#undef PX
+}
+
+// ---- the same predictors from an edge array in LDS (no private arrays) ------------------------
+// 4x4: e4[0..3] = left 3..0, e4[4] = top-left, e4[5..12] = top 0..7 (dir_pred_px's layout for n = 4)
+__device__ __forceinline__ void pred4_edges(u8 *e4, const u8 *s, int ls, int k /* 0..12: one entry per caller */)
+{
+    e4[k] = k < 4 ? s[-1 + (3 - k) * ls] : k == 4 ? s[-1 - ls] : s[(k - 5) - ls];
+}
+__device__ __forceinline__ int pred4_px(int mode, const u8 *e4, int x, int y)
+{   // table slots: V,H,DC,DDL,DDR,VR,HD,VL,HU,DC_LEFT,DC_TOP,DC_128 (R/common/predict.h:60-76)
+    if (mode == 0) return e4[5 + x];
+    if (mode == 1) return e4[3 - y];
+    if (mode == 11) return 128;
+    if (mode == 2 || mode == 9 || mode == 10) {
+        const int t = e4[5] + e4[6] + e4[7] + e4[8], l = e4[0] + e4[1] + e4[2] + e4[3];
+        return mode == 2 ? (t + l + 4) >> 3 : mode == 9 ? (l + 2) >> 2 : (t + 2) >> 2;
+    }
+    return dir_pred_px(4, mode, e4, x, y);
+}
+// 8x8: edge[] as x264_predict_8x8_filter leaves it (R/common/predict.c:499-540): edge[14-k] = left k,
+// edge[15] = top-left, edge[16+k] = top k (k < 16)
+__device__ __forceinline__ int pred8_px(int mode, const u8 *edge, int x, int y)
+{
+    if (mode == 0) return edge[16 + x];
+    if (mode == 1) return edge[14 - y];
+    if (mode == 11) return 128;
+    if (mode == 2 || mode == 9 || mode == 10) {
+        int l = 0, t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { l += edge[7 + i]; t += edge[16 + i]; }
+        return mode == 2 ? (l + t + 8) >> 4 : mode == 9 ? (l + 4) >> 3 : (t + 4) >> 3;
+    }
+    return dir_pred_px(8, mode, edge + 7, x, y);
+}
+// x264_predict_8x8_filter for the block at s (row -1 / column -1 reachable, stride ls); one lane runs it
+__device__ __forceinline__ void pred8_filter(u8 *edge, const u8 *s, int ls, int neigh, int filt)
+{
+#define PX(xx, yy) ((int)s[(xx) + (yy) * ls])
+    const int have_tl = neigh & 8;       // MB_TOPLEFT
+    if (filt & 1) {                      // MB_LEFT
+        edge[15] = (u8)((PX(0, -1) + 2 * PX(-1, -1) + PX(-1, 0) + 2) >> 2);
+        edge[14] = (u8)(((have_tl ? PX(-1, -1) : PX(-1, 0)) + 2 * PX(-1, 0) + PX(-1, 1) + 2) >> 2);
+        for (int y = 1; y < 7; y++) edge[14 - y] = (u8)((PX(-1, y - 1) + 2 * PX(-1, y) + PX(-1, y + 1) + 2) >> 2);
+        edge[7] = (u8)((PX(-1, 6) + 3 * PX(-1, 7) + 2) >> 2);
+    }
+    if (filt & 2) {                      // MB_TOP
+        const int have_tr = neigh & 4;   // MB_TOPRIGHT
+        edge[16] = (u8)(((have_tl ? PX(-1, -1) : PX(0, -1)) + 2 * PX(0, -1) + PX(1, -1) + 2) >> 2);
+        for (int x = 1; x < 7; x++) edge[16 + x] = (u8)((PX(x - 1, -1) + 2 * PX(x, -1) + PX(x + 1, -1) + 2) >> 2);
+        edge[23] = (u8)((PX(6, -1) + 2 * PX(7, -1) + (have_tr ? PX(8, -1) : PX(7, -1)) + 2) >> 2);
+        if (filt & 4) {
+            if (have_tr) {
+                for (int x = 8; x < 15; x++) edge[16 + x] = (u8)((PX(x - 1, -1) + 2 * PX(x, -1) + PX(x + 1, -1) + 2) >> 2);
+                edge[31] = edge[32] = (u8)((PX(14, -1) + 3 * PX(15, -1) + 2) >> 2);
+            } else
+                for (int i = 24; i < 33; i++) edge[i] = (u8)PX(7, -1);
+        }
+    }
 #undef PX
 }

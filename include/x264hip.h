@@ -224,6 +224,7 @@ typedef struct {
     uint8_t *nnz;          /* [n][27] */
     int16_t *luma, *luma_dc, *chroma_dc, *chroma_ac;   /* [n][256] [n][16] [n][2][4] [n][8][16] */
     int32_t *cost_intra, *cost_inter;                  /* per macroblock terms of h->stat.frame.i_intra_cost / i_inter_cost */
+    int32_t *cost_intra_alt;                           /* scratch of the sweep: b_fast_intra's raster-order term, settled after the frame */
     int32_t *progress;     /* [batch][mb_h] + abort flag: the sweep's row counters */
     int poc, n_ref0, inv_ref_poc[8];                   /* x264_frame_t.i_poc / i_ref[0] / inv_ref_poc, filled by the sweep */
 } x264hip_mb_state;

@@ -64,7 +64,7 @@ struct SwArgs {
     i16 *mv, *mvr, *cbp;
     u8 *nnz;
     i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
-    int *cost_intra, *cost_inter;
+    int *cost_intra, *cost_inter, *cost_alt;
     int *progress, *abort_flag;
     long long *prof;            // optional [batch][mb_h][8] accumulated wall-clock ticks per phase (developer aid)
 };
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     a.mb_type += nmb * bz; a.partition += nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz; a.i16mode += nmb * bz;
     a.chroma_mode += nmb * bz; a.qp_out += nmb * bz; a.t8 += nmb * bz; a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
     a.cbp += nmb * bz; a.nnz += 27 * nmb * bz; a.luma += 256 * nmb * bz; a.luma_dc += 16 * nmb * bz; a.chroma_dc += 8 * nmb * bz;
-    a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz;
+    a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz; a.cost_alt += nmb * bz;
     if (a.l0_type) { a.l0_type += nmb * bz; a.l0_ref += 4 * nmb * bz; a.l0_mv += 32 * nmb * bz; }
     int *prog = a.progress + (size_t)bz * a.mb_h;
     const int satd = a.subme > 1, is_p = a.slice_type == 0;
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 
         int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0;
         int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
-        int satd_i8 = MX_COST_MAX, satd_i4 = MX_COST_MAX, i8_cbp = 0, i4_cbp = 0, t8 = 0;
+        int satd_i8 = MX_COST_MAX, satd_i4 = MX_COST_MAX, i8_cbp = 0, i4_cbp = 0, t8 = 0, fi_open = 0, stat_alt = -1;
         if (a.flags_intra & 3) {
             // intra4x4_pred_mode cache (R/common/macroblock.c:907-980): -1 where there is no neighbour; the frame array holds
             // I_PRED_4x4_DC for every macroblock that is not I_4x4 / I_8x8
@@ -910,7 +910,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // the intra macroblocks BEFORE this one in raster order, some of which (to the right in the rows above) may
         // not be coded yet: bound the count from what the rows above have published, and wait only while the
         // bounds leave the answer open (the rows above never wait for this one, so this terminates).
-        auto fast_intra_now = [&]() -> int {
+        // wait = 0: answer 0 / 1, or 2 when the bounds do not decide it yet; wait = 1: poll until they do
+        auto fast_intra_now = [&](int wait) -> int {
             if (!is_p || mb <= 4) return 0;
             if (IS_INTRA_T(left_type) || IS_INTRA_T(type_top) || IS_INTRA_T(type_topleft) || IS_INTRA_T(type_topright)) return 0;
             if (a.l0_type && IS_INTRA_T(UNI(a.l0_type[mb]))) return 0;
@@ -924,6 +925,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 }
                 if (mb < 3 * known) return 0;
                 if (mb >= 3 * (known + pending)) return 1;
+                if (!wait) return 2;
                 __builtin_amdgcn_s_sleep(100);
                 if (spins > SW_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
             }
@@ -939,7 +941,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 }
             }
             if (!(a.flags_intra & 3)) return;
-            if (satd_i16 > 2 * satd_inter && fast_intra_now()) return;
+            if (satd_i16 > 2 * satd_inter) {
+                // b_fast_intra would end the analysis here.  If the raster-order count behind it is not decidable yet, go on
+                // as if it were 0: the extra analysis only matters if 8x8 / 4x4 then beat the inter cost, which the caller
+                // checks (and only then waits for the exact answer); the statistics term is settled after the frame.
+                const int fi = fast_intra_now(0);
+                if (fi == 1) return;
+                fi_open = fi == 2;
+            }
             if (a.flags_intra & 2) {                                   // X264_ANALYSE_I8x8
                 const int thresh = min(satd_inter, satd_i16);
                 int cost = 0, idx, acbp = 0;
@@ -1161,6 +1170,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         satd_i16 += satd_chroma; satd_i8 += satd_chroma; satd_i4 += satd_chroma;
                     } else
                         analyse_intra(i_cost);
+                    if (fi_open) {
+                        if (min(satd_i8, satd_i4) < i_cost) {        // the answer decides the macroblock type: it must be exact
+                            if (fast_intra_now(1)) satd_i8 = satd_i4 = MX_COST_MAX;
+                            fi_open = 0;
+                        } else
+                            stat_alt = satd_i16;                     // i_intra_cost if b_fast_intra turns out to be 1
+                    }
                     // analyse.c:2372-2400: best intra type (16x16, then 8x8, then 4x4 on strict improvement) against inter
                     int itype = T_I_16x16, icost = satd_i16;
                     if (satd_i8 < icost) { icost = satd_i8; itype = T_I_8x8; }
@@ -1281,7 +1297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             a.qp_out[mb] = (signed char)a.qp;
             a.t8[mb] = (signed char)t8;
             a.cbp[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
-            a.cost_intra[mb] = stat_intra; a.cost_inter[mb] = stat_inter;
+            a.cost_intra[mb] = stat_intra; a.cost_inter[mb] = stat_inter; a.cost_alt[mb] = stat_alt;
         }
         {   // coefficient levels, masked by what the entropy coder reads (cbp, then nnz)
             const bool coded = type != T_P_SKIP;
@@ -1315,6 +1331,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 #undef PROF
 }
 
+// b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
+// knowing it (it could not change their type) recorded the statistics term for the other answer in cost_alt.
+// One wave per chain, 64 macroblocks per step, running count of intra macroblocks via ballot.
+__global__ __launch_bounds__(64) void k_resolve_fast_intra(const signed char *mb_type, int *cost_intra, const int *cost_alt, int n_mb)
+{
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * n_mb;
+    int before = 0;                                    // intra macroblocks before this group of 64
+    for (int m0 = 0; m0 < n_mb; m0 += 64) {
+        const int mb = m0 + lane;
+        const int t = mb < n_mb ? (int)mb_type[base + mb] : 99;
+        const unsigned long long im = __ballot(t >= 0 && t <= 3);
+        const int count = before + __popcll(im & ((1ull << lane) - 1));
+        if (mb < n_mb) {
+            const int alt = cost_alt[base + mb];
+            if (alt >= 0 && !(mb < 3 * count)) cost_intra[base + mb] = alt;     // b_fast_intra was 1
+        }
+        before += __popcll(im);
+    }
+}
+
 // ------------------------------------------------------------------ host
 static const int k_lambda_tab[52] = {    // x264_lambda_tab, R/encoder/analyse.c:140-149
     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
@@ -1336,7 +1373,7 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
         {(void **)&st->i16mode, n}, {(void **)&st->chroma_mode, n}, {(void **)&st->qp, n}, {(void **)&st->t8, n},
         {(void **)&st->mv, 64 * n}, {(void **)&st->mvr, 4 * SW_MAX_REFS * n}, {(void **)&st->cbp, 2 * n}, {(void **)&st->nnz, 27 * n},
         {(void **)&st->luma, 512 * n}, {(void **)&st->luma_dc, 32 * n}, {(void **)&st->chroma_dc, 16 * n}, {(void **)&st->chroma_ac, 256 * n},
-        {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n},
+        {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n}, {(void **)&st->cost_intra_alt, 4 * n},
         {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}};
     for (auto &it : items) {
         HIPCHK(hipMalloc(it.p, it.bytes));
@@ -1348,7 +1385,7 @@ extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st
 {
     (void)c;
     void *ps[] = {st->mb_type, st->partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
-                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->progress};
+                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress};
     for (void *p : ps) if (p) (void)hipFree(p);
     memset(st, 0, sizeof(*st));
 }
@@ -1403,7 +1440,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.i4mode = (signed char *)out->i4mode; a.i16mode = (signed char *)out->i16mode; a.chroma_mode = (signed char *)out->chroma_mode;
     a.qp_out = (signed char *)out->qp; a.t8 = (signed char *)out->t8; a.mv = out->mv; a.mvr = out->mvr; a.cbp = out->cbp; a.nnz = out->nnz;
     a.luma = out->luma; a.luma_dc = out->luma_dc; a.chroma_dc = out->chroma_dc; a.chroma_ac = out->chroma_ac;
-    a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter;
+    a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter; a.cost_alt = out->cost_intra_alt;
     a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
     a.prof = (long long *)p->profile;
     SwRefs t;
@@ -1426,6 +1463,9 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     case 4: hipLaunchKernelGGL(k_slice_sweep<4>, grid, block, 0, c->stream, a, t); break;
     default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
     }
+    if (is_p && a.flags_intra)
+        hipLaunchKernelGGL(k_resolve_fast_intra, dim3(c->batch), dim3(64), 0, c->stream, (const signed char *)out->mb_type, out->cost_intra,
+                           (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
     HIPCHK(hipGetLastError());
     // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
     out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;

@@ -22,7 +22,7 @@ STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("ref", np
                 ("i16mode", np.int8, ()), ("chroma_mode", np.int8, ()), ("qp", np.int8, ()), ("t8", np.int8, ()),
                 ("mv", np.int16, (16, 2)), ("mvr", np.int16, None), ("cbp", np.int16, ()), ("nnz", np.uint8, (27,)),
                 ("luma", np.int16, (256,)), ("luma_dc", np.int16, (16,)), ("chroma_dc", np.int16, (8,)), ("chroma_ac", np.int16, (128,)),
-                ("cost_intra", np.int32, ()), ("cost_inter", np.int32, ())]
+                ("cost_intra", np.int32, ()), ("cost_inter", np.int32, ()), ("cost_intra_alt", np.int32, ())]
 
 
 class MbState(C.Structure):

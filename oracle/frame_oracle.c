@@ -306,6 +306,7 @@ typedef struct {
     int sy, sc;
     const i16 *cmx, *cmy;             /* cost tables already offset by the predictor */
     int fmin[2], fmax[2], smin[2], smax[2];
+    int pix, bw, bh;                  /* block: X264HIP_PIXEL_16x16 / 16x8 / 8x16 / 8x8 and its size (pointers already offset to it) */
 } me_ctx;
 static const int me_subpel_iters[10][4] = {{0,0,0,0},{1,1,0,0},{0,1,1,0},{0,2,1,0},{0,2,1,1},{0,2,1,2},{0,0,2,2},{0,0,2,2},{0,0,4,10},{0,0,4,10}};
 static const int me_hex2[8][2] = {{-1,-2},{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2},{-2,0}};
@@ -314,25 +315,25 @@ static const int me_mod6m1[8] = {5,0,1,2,3,4,5,0};
 
 static int me_fpel_cost(const me_ctx *c, int mx, int my)
 {   /* COST_MV's cost, me.c:54-62 */
-    return pixf.sad[X264HIP_PIXEL_16x16](c->fenc, c->sy, c->fref[0] + my * c->sy + mx, c->sy) + c->cmx[mx << 2] + c->cmy[my << 2];
+    return pixf.sad[c->pix](c->fenc, c->sy, c->fref[0] + my * c->sy + mx, c->sy) + c->cmx[mx << 2] + c->cmy[my << 2];
 }
 static int me_qpel_cmp(const me_ctx *c, int mx, int my, int satd)
 {   /* get_ref + fpelcmp / mbcmp_unaligned, me.c:64-71,644-652 */
     u8 pix[16 * 16];
     int stride = 16;
-    u8 *src = mcf.get_ref(pix, &stride, (u8 **)c->fref, c->sy, mx, my, 16, 16);
-    return (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_16x16](c->fenc, c->sy, src, stride) + c->cmx[mx] + c->cmy[my];
+    u8 *src = mcf.get_ref(pix, &stride, (u8 **)c->fref, c->sy, mx, my, c->bw, c->bh);
+    return (satd ? pixf.satd : pixf.sad)[c->pix](c->fenc, c->sy, src, stride) + c->cmx[mx] + c->cmy[my];
 }
 static int me_satd_chroma(const me_ctx *c, int mx, int my, int bcost, int chroma_me, int satd)
 {   /* COST_MV_SATD's cost with the chroma terms, me.c:654-677 */
     int cost = me_qpel_cmp(c, mx, my, satd);
     if (chroma_me && cost < bcost) {
         u8 pix[8 * 8];
-        mcf.mc_chroma(pix, 8, c->fref[4], c->sc, mx, my, 8, 8);
-        cost += (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](c->fenc_u, c->sc, pix, 8);
+        mcf.mc_chroma(pix, 8, c->fref[4], c->sc, mx, my, c->bw / 2, c->bh / 2);
+        cost += (satd ? pixf.satd : pixf.sad)[c->pix + 3](c->fenc_u, c->sc, pix, 8);
         if (cost < bcost) {
-            mcf.mc_chroma(pix, 8, c->fref[5], c->sc, mx, my, 8, 8);
-            cost += (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](c->fenc_v, c->sc, pix, 8);
+            mcf.mc_chroma(pix, 8, c->fref[5], c->sc, mx, my, c->bw / 2, c->bh / 2);
+            cost += (satd ? pixf.satd : pixf.sad)[c->pix + 3](c->fenc_v, c->sc, pix, 8);
         }
     }
     return cost;
@@ -469,7 +470,7 @@ void x264o_frame_me_search16(u8 *fy, u8 *fu, u8 *fv, u8 *const *refs /* [n][6] *
         for (int r = 0; r < n_refs; r++) {
             me_ctx c;
             const i16 *p = mvp + ((size_t)mb * n_refs + r) * 2;
-            c.fenc = fy + oy; c.fenc_u = fu + oc; c.fenc_v = fv + oc; c.sy = sy; c.sc = sc;
+            c.fenc = fy + oy; c.fenc_u = fu + oc; c.fenc_v = fv + oc; c.sy = sy; c.sc = sc; c.pix = X264HIP_PIXEL_16x16; c.bw = c.bh = 16;
             for (int k = 0; k < 4; k++) c.fref[k] = refs[6 * r + k] + oy;
             c.fref[4] = refs[6 * r + 4] + oc; c.fref[5] = refs[6 * r + 5] + oc;
             c.cmx = cost_mv + cost_center - p[0]; c.cmy = cost_mv + cost_center - p[1];

@@ -24,6 +24,9 @@ CASES = [
                                                  transform8x8=1, cabac=1, deblock=1)),
     ("nodecimate", (200, 120), 4, "moving", dict(qp=34, subme=3, intra=0x1, inter=0x1, n_refs=2, deblock=1, dct_decimate=0,
                                                   fast_pskip=0)),
+    ("parts", (200, 120), 4, "static", dict(qp=30, subme=2, me_method=rs.ME_HEX, inter=0x10, n_refs=2)),
+    ("medium_ip", (208, 144), 5, "static", dict(qp=26, subme=5, me_method=rs.ME_HEX, n_refs=3, inter=0x13, intra=0x3, transform8x8=1,
+                                                  mixed_refs=1, cabac=1, deblock=1)),
 ]
 
 

@@ -39,7 +39,7 @@ typedef struct {
 
 /* mb types / partitions / slice types with the reference's numbering (R/common/macroblock.h:55-102, R/common/common.h:128-134) */
 enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6 };
-enum { S_D_16x16 = 16 };
+enum { S_D_L0_8x8 = 3, S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
 enum { S_SLICE_P = 0, S_SLICE_I = 2 };
 enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
 #define S_COST_MAX (1 << 28)
@@ -137,6 +137,12 @@ typedef struct {
     i16 luma4[16][16], luma8[4][64], dc16[16], cdc[2][4], cac[8][16];
     int cbp_luma, cbp_chroma, type, t8, i16mode, chroma_mode, skip_mc;
     int mvx, mvy, ref;                   /* the 16x16 vector */
+    int partition;                       /* D_16x16 / D_16x8 / D_8x16 / D_8x8 */
+    i16 mv4[16][2];                      /* final vectors per 4x4 block (raster inside the macroblock) and references per 8x8 */
+    int8_t ref8[4];
+    int8_t cref[48];                     /* h->mb.cache.ref / mv for list 0, x264_scan8 layout */
+    i16 cmv[48][2];
+    i16 l0mvc[16][5][2];                 /* a->l0.mvc[ref][0 = 16x16, 1..4 = 8x8 blocks] */
     i16 pskip_mv[2];
     /* analysis */
     int satd_i16, satd_i8, satd_i4, satd_chroma, fast_intra, pred16, pred8[4], pred4[16], predc;
@@ -426,6 +432,20 @@ static void mc_16x16(const ssl *S, smb *m, int ref, int mvx, int mvy)
     mcf.mc_chroma(m->fd[1], FDEC, r->plane[1] + oc, S->sc, mvx, mvy, 8, 8);
     mcf.mc_chroma(m->fd[2], FDEC, r->plane[2] + oc, S->sc, mvx, mvy, 8, 8);
 }
+/* x264_mb_mc for any of the partitions above: per 4x4 block, its vector and its 8x8's reference (R/common/macroblock.c:462-546) */
+static void mc_parts(const ssl *S, smb *m)
+{
+    for (int by = 0; by < 4; by++)
+        for (int bx = 0; bx < 4; bx++) {
+            const sframe *r = S->fref[m->ref8[(by >> 1) * 2 + (bx >> 1)]];
+            const i16 *v = m->mv4[by * 4 + bx];
+            int o = (16 * m->mby + 4 * by) * S->sy + 16 * m->mbx + 4 * bx, oc = (8 * m->mby + 2 * by) * S->sc + 8 * m->mbx + 2 * bx;
+            u8 *src4[4] = {r->filt[0] + o, r->filt[1] + o, r->filt[2] + o, r->filt[3] + o};
+            mcf.mc_luma(m->fd[0] + 4 * by * FDEC + 4 * bx, FDEC, src4, S->sy, v[0], v[1], 4, 4);
+            mcf.mc_chroma(m->fd[1] + 2 * by * FDEC + 2 * bx, FDEC, r->plane[1] + oc, S->sc, v[0], v[1], 2, 2);
+            mcf.mc_chroma(m->fd[2] + 2 * by * FDEC + 2 * bx, FDEC, r->plane[2] + oc, S->sc, v[0], v[1], 2, 2);
+        }
+}
 static void mv_clip_frame(const ssl *S, const smb *m, int *mvx, int *mvy)
 {   /* h->mb.mv_min / mv_max, R/encoder/analyse.c:258-259,290-291 */
     *mvx = clip3i(*mvx, 4 * (-16 * m->mbx - 24), 4 * (16 * (S->mb_w - m->mbx - 1) + 24));
@@ -635,12 +655,27 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
     m->nb4[6] = m->nb4[9] = m->nb4[12] = m->nb4[14] = all;
     m->nb4[3] = m->nb4[7] = m->nb4[11] = m->nb4[13] = m->nb4[15] = m->nb8[3] = NB_LEFT | NB_TOP | NB_TOPLEFT;
     m->satd_i16 = m->satd_i8 = m->satd_i4 = m->satd_chroma = S_COST_MAX;
-    if (S->slice_type == S_SLICE_P) predict_mv_pskip(S, m, m->pskip_mv);
+    if (S->slice_type == S_SLICE_P) {
+        predict_mv_pskip(S, m, m->pskip_mv);
+        /* h->mb.cache.ref / mv around the macroblock (R/common/macroblock.c:1040-1128): -2 = not available */
+        memset(m->cref, -2, sizeof(m->cref)); memset(m->cmv, 0, sizeof(m->cmv));
+        const i16 *fmv = S->fdec->mv;
+        const int8_t *fref = S->fdec->ref;
+#define NBSET(k_, o_, blk_) do { m->cref[k_] = fref[(o_) * 4 + ((blk_) >> 3) * 2 + (((blk_) & 3) >> 1)]; \
+                                 m->cmv[k_][0] = fmv[((o_) * 16 + (blk_)) * 2]; m->cmv[k_][1] = fmv[((o_) * 16 + (blk_)) * 2 + 1]; } while (0)
+        if (m->nb & NB_TOPLEFT) NBSET(3, m->mb - S->mb_w - 1, 15);
+        if (m->nb & NB_TOP) for (int i = 0; i < 4; i++) NBSET(4 + i, m->mb - S->mb_w, 12 + i);
+        if (m->nb & NB_TOPRIGHT) NBSET(8, m->mb - S->mb_w + 1, 12);
+        if (m->nb & NB_LEFT) for (int i = 0; i < 4; i++) NBSET(11 + 8 * i, m->mb - 1, 3 + 4 * i);
+#undef NBSET
+    }
+    m->partition = S_D_16x16;
 }
 
-static void set_me_ctx(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c)
+static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by)
 {
-    int oy = 16 * m->mby * S->sy + 16 * m->mbx, oc = 8 * m->mby * S->sc + 8 * m->mbx, sp[4], fp[4];
+    static const u8 bw[4] = {16, 16, 8, 8}, bh[4] = {16, 8, 16, 8};
+    int oy = (16 * m->mby + by) * S->sy + 16 * m->mbx + bx, oc = (8 * m->mby + by / 2) * S->sc + 8 * m->mbx + bx / 2, sp[4], fp[4];
     const sframe *r = S->fref[ref];
     mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, 512, sp, fp);
     c->fenc = S->fenc->plane[0] + oy; c->fenc_u = S->fenc->plane[1] + oc; c->fenc_v = S->fenc->plane[2] + oc;
@@ -650,6 +685,38 @@ static void set_me_ctx(const ssl *S, const smb *m, int ref, const i16 mvp[2], me
     c->cmx = S->cost_mv - mvp[0]; c->cmy = S->cost_mv - mvp[1];
     c->fmin[0] = fp[0]; c->fmax[0] = fp[1]; c->fmin[1] = fp[2]; c->fmax[1] = fp[3];
     c->smin[0] = sp[0]; c->smax[0] = sp[1]; c->smin[1] = sp[2]; c->smax[1] = sp[3];
+    c->pix = pix; c->bw = bw[pix]; c->bh = bh[pix];
+}
+static void set_me_ctx(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c) { set_me_ctx_blk(S, m, ref, mvp, c, X264HIP_PIXEL_16x16, 0, 0); }
+/* h->mb.cache.ref / mv helpers: x264_macroblock_cache_ref / _mv (R/common/macroblock.h) on a w x h run of 4x4 blocks */
+static void cache_set(smb *m, int x, int y, int w, int h, int ref, int mvx, int mvy, int set_mv)
+{
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            int k = 4 + 1 * 8 + x + i + 8 * (y + j);
+            m->cref[k] = (int8_t)ref;
+            if (set_mv) { m->cmv[k][0] = (i16)mvx; m->cmv[k][1] = (i16)mvy; }
+        }
+}
+/* x264_mb_predict_mv, R/common/macroblock.c:28-88 */
+static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
+{
+    const int i8 = s_scan8(idx), i_ref = m->cref[i8];
+    int ra = m->cref[i8 - 1], rb = m->cref[i8 - 8], rc = m->cref[i8 - 8 + width], cnt;
+    const i16 *a = m->cmv[i8 - 1], *b = m->cmv[i8 - 8], *c = m->cmv[i8 - 8 + width];
+    if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { rc = m->cref[i8 - 8 - 1]; c = m->cmv[i8 - 8 - 1]; }
+    if (m->partition == S_D_16x8) {
+        if (idx == 0 && rb == i_ref) { mvp[0] = b[0]; mvp[1] = b[1]; return; }
+        if (idx != 0 && ra == i_ref) { mvp[0] = a[0]; mvp[1] = a[1]; return; }
+    } else if (m->partition == S_D_8x16) {
+        if (idx == 0 && ra == i_ref) { mvp[0] = a[0]; mvp[1] = a[1]; return; }
+        if (idx != 0 && rc == i_ref) { mvp[0] = c[0]; mvp[1] = c[1]; return; }
+    }
+    cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
+    if (cnt > 1) { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
+    else if (cnt == 1) { const i16 *s = ra == i_ref ? a : rb == i_ref ? b : c; mvp[0] = s[0]; mvp[1] = s[1]; }
+    else if (rb == -2 && rc == -2 && ra != -2) { mvp[0] = a[0]; mvp[1] = a[1]; }
+    else { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
 }
 /* x264_me_refine_qpel -> refine_subpel(.., b_refine_qpel = 1), R/encoder/me.c:634-778, 16x16 */
 static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
@@ -735,17 +802,121 @@ static void analyse_mb(ssl *S, smb *m)
                 thresh += S->ref_cost[r];
                 if (cost < best) { best = cost; bmx = mvx; bmy = mvy; bref = r; bmvp[0] = mvp[0]; bmvp[1] = mvp[1]; }
                 S->mvr[((size_t)r * S->n + m->mb) * 2] = mvx; S->mvr[((size_t)r * S->n + m->mb) * 2 + 1] = mvy;
+                m->l0mvc[r][0][0] = mvx; m->l0mvc[r][0][1] = mvy;
             }
             m->type = S_P_L0;
-            /* x264_me_refine_qpel on the winner (:2289-2294; the reference cost leaves the sum, me.c:639-640) */
-            {
+            cache_set(m, 0, 0, 4, 4, bref, 0, 0, 0);
+            /* ---- sub-16x16 partitions (X264_ANALYSE_PSUB16x16), R/encoder/analyse.c:2222-2265 ---- */
+            struct { int mvx, mvy, cost, cost_mv, ref, ref_cost; i16 mvp[2]; } me8[4], me16x8[2], me8x16[2];
+            int cost8x8 = S_COST_MAX, cost16x8 = S_COST_MAX, cost8x16 = S_COST_MAX, part = S_D_16x16;
+            i_cost = best;
+            if (p->inter & 0x10) {
+                m->partition = S_D_8x8;
+                if (p->mixed_refs) {                                 /* x264_mb_analyse_inter_p8x8_mixed_ref, :1146-1219 */
+                    int maxref = S->n_ref - 1;
+                    if (maxref > 0 && bref == 0 && m->type_top && m->type_left) {
+                        static const int8_t look[6] = {3, 4, 6, 8, 11, 27};
+                        maxref = 0;
+                        for (int k = 0; k < 6; k++) if (m->cref[look[k]] > maxref) maxref = m->cref[look[k]];
+                    }
+                    for (int i = 0; i < 4; i++) {
+                        me8[i].cost = 0x7fffffff;
+                        for (int r = 0; r <= maxref; r++) {
+                            me_ctx c; i16 mvp[2]; int mx, my, cmv = 0, cost;
+                            cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, r, 0, 0, 0);
+                            predict_mv_blk(m, 4 * i, 2, mvp);
+                            set_me_ctx_blk(S, m, r, mvp, &c, X264HIP_PIXEL_8x8, 8 * (i & 1), 8 * (i >> 1));
+                            cost = me_search16(&c, mvp, (const i16 (*)[2])m->l0mvc[r], i + 1, p->me_method, p->me_range, p->subme, chroma_me, 0, &mx, &my, &cmv);
+                            cost += S->ref_cost[r];
+                            m->l0mvc[r][i + 1][0] = mx; m->l0mvc[r][i + 1][1] = my;
+                            if (cost < me8[i].cost) { me8[i].cost = cost; me8[i].mvx = mx; me8[i].mvy = my; me8[i].cost_mv = cmv; me8[i].ref = r;
+                                                      me8[i].ref_cost = S->ref_cost[r]; me8[i].mvp[0] = mvp[0]; me8[i].mvp[1] = mvp[1]; }
+                        }
+                        cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, me8[i].ref, me8[i].mvx, me8[i].mvy, 1);
+                        me8[i].cost += S->lambda * 1;                /* i_sub_mb_p_cost_table[D_L0_8x8] */
+                    }
+                    cost8x8 = me8[0].cost + me8[1].cost + me8[2].cost + me8[3].cost;
+                    if (!p->cabac && !(me8[0].ref | me8[1].ref | me8[2].ref | me8[3].ref)) cost8x8 -= S->ref_cost[0] * 4;
+                } else {                                             /* x264_mb_analyse_inter_p8x8, :1221-1272 */
+                    const int r = bref, ref_cost = p->cabac || r ? S->ref_cost[r] : 0;
+                    int n_mvc = 1;
+                    m->l0mvc[r][0][0] = bmx; m->l0mvc[r][0][1] = bmy;
+                    for (int i = 0; i < 4; i++) {
+                        me_ctx c; i16 mvp[2]; int mx, my, cmv = 0, cost;
+                        predict_mv_blk(m, 4 * i, 2, mvp);
+                        set_me_ctx_blk(S, m, r, mvp, &c, X264HIP_PIXEL_8x8, 8 * (i & 1), 8 * (i >> 1));
+                        cost = me_search16(&c, mvp, (const i16 (*)[2])m->l0mvc[r], n_mvc, p->me_method, p->me_range, p->subme, chroma_me, 0, &mx, &my, &cmv);
+                        cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, r, mx, my, 1);
+                        m->l0mvc[r][n_mvc][0] = mx; m->l0mvc[r][n_mvc][1] = my; n_mvc++;
+                        me8[i].cost = cost + ref_cost + S->lambda * 1; me8[i].mvx = mx; me8[i].mvy = my; me8[i].cost_mv = cmv; me8[i].ref = r;
+                        me8[i].ref_cost = ref_cost; me8[i].mvp[0] = mvp[0]; me8[i].mvp[1] = mvp[1];
+                    }
+                    cost8x8 = me8[0].cost + me8[1].cost + me8[2].cost + me8[3].cost;
+                    if (p->cabac) cost8x8 -= ref_cost;
+                }
+                if (cost8x8 < best) { m->type = S_P_8x8; part = S_D_8x8; i_cost = cost8x8; }
+                const int thresh16x8 = me8[1].cost_mv + me8[2].cost_mv;
+                if (cost8x8 < best + thresh16x8) {
+                    for (int dir = 0; dir < 2; dir++) {              /* 0: x264_mb_analyse_inter_p16x8 (:1274), 1: _p8x16 (:1324) */
+                        int sum = 0;
+                        m->partition = dir ? S_D_8x16 : S_D_16x8;
+                        for (int i = 0; i < 2; i++) {
+                            const int ra = dir ? me8[i].ref : me8[2 * i].ref, rb = dir ? me8[i + 2].ref : me8[2 * i + 1].ref;
+                            const int rr[2] = {ra, rb}, nr = ra == rb ? 1 : 2;
+                            int bcost = 0x7fffffff, bx = 0, by = 0, br = 0, bcm = 0; i16 bp[2] = {0, 0};
+                            for (int j = 0; j < nr; j++) {
+                                const int r = rr[j];
+                                me_ctx c; i16 mvp[2], mvc3[3][2]; int mx, my, cmv = 0, cost;
+                                const int k1 = dir ? i + 1 : 2 * i + 1, k2 = dir ? i + 3 : 2 * i + 2;
+                                mvc3[0][0] = m->l0mvc[r][0][0]; mvc3[0][1] = m->l0mvc[r][0][1];
+                                mvc3[1][0] = m->l0mvc[r][k1][0]; mvc3[1][1] = m->l0mvc[r][k1][1];
+                                mvc3[2][0] = m->l0mvc[r][k2][0]; mvc3[2][1] = m->l0mvc[r][k2][1];
+                                if (dir) cache_set(m, 2 * i, 0, 2, 4, r, 0, 0, 0); else cache_set(m, 0, 2 * i, 4, 2, r, 0, 0, 0);
+                                predict_mv_blk(m, dir ? 4 * i : 8 * i, dir ? 2 : 4, mvp);
+                                set_me_ctx_blk(S, m, r, mvp, &c, dir ? X264HIP_PIXEL_8x16 : X264HIP_PIXEL_16x8, dir ? 8 * i : 0, dir ? 0 : 8 * i);
+                                cost = me_search16(&c, mvp, (const i16 (*)[2])mvc3, 3, p->me_method, p->me_range, p->subme, chroma_me, 0, &mx, &my, &cmv);
+                                cost += S->ref_cost[r];
+                                if (cost < bcost) { bcost = cost; bx = mx; by = my; br = r; bcm = cmv; bp[0] = mvp[0]; bp[1] = mvp[1]; }
+                            }
+                            if (dir) cache_set(m, 2 * i, 0, 2, 4, br, bx, by, 1); else cache_set(m, 0, 2 * i, 4, 2, br, bx, by, 1);
+                            typeof(me16x8[0]) *d = dir ? &me8x16[i] : &me16x8[i];
+                            d->cost = bcost; d->mvx = bx; d->mvy = by; d->ref = br; d->cost_mv = bcm; d->ref_cost = S->ref_cost[br]; d->mvp[0] = bp[0]; d->mvp[1] = bp[1];
+                            sum += bcost;
+                        }
+                        if (dir) cost8x16 = sum; else cost16x8 = sum;
+                        if (sum < i_cost) { i_cost = sum; m->type = S_P_L0; part = dir ? S_D_8x16 : S_D_16x8; }
+                    }
+                }
+            }
+            m->partition = part;
+            /* x264_me_refine_qpel on the winning partition (:2289-2352; the reference cost leaves every block's sum, me.c:639-640) */
+            if (part == S_D_16x16) {
                 me_ctx c;
                 set_me_ctx(S, m, bref, bmvp, &c);
                 best -= S->ref_cost[bref];
                 best = refine_qpel16(S, &c, best, &bmx, &bmy, bmvp);
+                i_cost = best;
+                for (int i = 0; i < 16; i++) { m->mv4[i][0] = bmx; m->mv4[i][1] = bmy; }
+                for (int i = 0; i < 4; i++) m->ref8[i] = bref;
+            } else {
+                i_cost = 0;
+                for (int i = 0; i < (part == S_D_8x8 ? 4 : 2); i++) {
+                    typeof(me8[0]) *d = part == S_D_8x8 ? &me8[i] : part == S_D_16x8 ? &me16x8[i] : &me8x16[i];
+                    const int pix = part == S_D_8x8 ? X264HIP_PIXEL_8x8 : part == S_D_16x8 ? X264HIP_PIXEL_16x8 : X264HIP_PIXEL_8x16;
+                    const int bx = part == S_D_8x8 ? 8 * (i & 1) : part == S_D_8x16 ? 8 * i : 0, by = part == S_D_8x8 ? 8 * (i >> 1) : part == S_D_16x8 ? 8 * i : 0;
+                    const int w4 = part == S_D_16x8 ? 4 : 2, h4 = part == S_D_8x16 ? 4 : 2;
+                    me_ctx c;
+                    set_me_ctx_blk(S, m, d->ref, d->mvp, &c, pix, bx, by);
+                    d->cost = refine_qpel16(S, &c, d->cost - d->ref_cost, &d->mvx, &d->mvy, d->mvp);
+                    i_cost += d->cost;
+                    for (int y = 0; y < h4; y++)
+                        for (int x = 0; x < w4; x++) { m->mv4[(by / 4 + y) * 4 + bx / 4 + x][0] = d->mvx; m->mv4[(by / 4 + y) * 4 + bx / 4 + x][1] = d->mvy; }
+                    for (int y = 0; y < h4 / 2; y++)
+                        for (int x = 0; x < w4 / 2; x++) m->ref8[(by / 8 + y) * 2 + bx / 8 + x] = d->ref;
+                }
             }
             m->mvx = bmx; m->mvy = bmy; m->ref = bref;
-            i_cost = best;
+            (void)cost16x8; (void)cost8x16;
             if (chroma_me) {
                 analyse_intra_chroma(S, m);
                 analyse_intra(S, m, i_cost - m->satd_chroma);
@@ -781,13 +952,15 @@ static void update_mb(ssl *S, smb *m)
         analyse_intra_chroma(S, m);
         break;
     case S_P_SKIP:
-        m->mvx = m->pskip_mv[0]; m->mvy = m->pskip_mv[1]; m->ref = 0;
+        m->mvx = m->pskip_mv[0]; m->mvy = m->pskip_mv[1]; m->ref = 0; m->partition = S_D_16x16;
+        for (int i = 0; i < 16; i++) { m->mv4[i][0] = m->pskip_mv[0]; m->mv4[i][1] = m->pskip_mv[1]; }
+        memset(m->ref8, 0, 4);
         break;
     default:
         break;
     }
-    if (m->type == S_P_L0 && S->p->transform8x8) {
-        mc_16x16(S, m, m->ref, m->mvx, m->mvy);
+    if ((m->type == S_P_L0 || m->type == S_P_8x8) && S->p->transform8x8) {
+        mc_parts(S, m);
         int c8 = pixf.sa8d[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
         int c4 = pixf.satd[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
         m->t8 = c8 < c4;
@@ -836,12 +1009,13 @@ static void encode_mb(ssl *S, smb *m)
             enc_i4x4(S, m, 15);
         }
     } else {
-        if (!m->skip_mc) mc_16x16(S, m, m->ref, m->mvx, m->mvy);
+        if (!m->skip_mc) mc_parts(S, m);
         enc_inter_luma(S, m);
     }
     if (S_IS_INTRA(m->type)) { s_p8c[m->chroma_mode](m->fd[1]); s_p8c[m->chroma_mode](m->fd[2]); }
     enc_chroma(S, m, !S_IS_INTRA(m->type));
-    if (m->type == S_P_L0 && !(m->cbp_luma | m->cbp_chroma) && m->mvx == m->pskip_mv[0] && m->mvy == m->pskip_mv[1] && m->ref == 0)
+    if (m->type == S_P_L0 && m->partition == S_D_16x16 && !(m->cbp_luma | m->cbp_chroma) && m->mv4[0][0] == m->pskip_mv[0]
+        && m->mv4[0][1] == m->pskip_mv[1] && m->ref8[0] == 0)
         m->type = S_P_SKIP;
 }
 
@@ -864,14 +1038,14 @@ static void save_mb(ssl *S, smb *m)
     S->t8[m->mb] = m->t8;
     memcpy(S->nnz + m->mb * 27, m->nnz, 27);
     for (int i = 0; i < 16; i++) {
-        S->fdec->mv[(m->mb * 16 + i) * 2] = intra ? 0 : m->mvx;
-        S->fdec->mv[(m->mb * 16 + i) * 2 + 1] = intra ? 0 : m->mvy;
+        S->fdec->mv[(m->mb * 16 + i) * 2] = intra ? 0 : m->mv4[i][0];
+        S->fdec->mv[(m->mb * 16 + i) * 2 + 1] = intra ? 0 : m->mv4[i][1];
     }
-    for (int i = 0; i < 4; i++) S->fdec->ref[m->mb * 4 + i] = intra ? -1 : m->ref;
+    for (int i = 0; i < 4; i++) S->fdec->ref[m->mb * 4 + i] = intra ? -1 : m->ref8[i];
     if (intra) S->intra_count++;
 
-    o->mb_type[M] = m->type; o->partition[M] = S_D_16x16;
-    memset(o->sub_partition + M * 4, 0, 4);
+    o->mb_type[M] = m->type; o->partition[M] = intra || m->type == S_P_SKIP ? S_D_16x16 : m->partition;
+    memset(o->sub_partition + M * 4, m->type == S_P_8x8 ? S_D_L0_8x8 : 0, 4);
     memcpy(o->nnz + M * 27, m->nnz, 27);
     o->qp[M] = S->qp;
     o->cbp[M] = m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
@@ -908,7 +1082,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     sframe *refs[16] = {0};
     int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
     s_setup();
-    if ((p->inter & 0x30) || p->subme > 5 || p->me_method > 1 || p->mixed_refs) return -3;
+    if ((p->inter & 0x20) || p->subme > 5 || p->me_method > 1) return -3;
     memset(&S, 0, sizeof(S));
     S.p = p; S.o = o;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;

@@ -41,7 +41,11 @@ def compare(a, b, p):
 
 if __name__ == "__main__":
     ora = C.CDLL(os.path.join(os.path.dirname(rs.HERE), "oracle", "liboracle.so"))
-    cfgs = [dict(subme=0), dict(subme=1), dict(subme=2, me_method=1), dict(subme=5, me_method=1, n_refs=3, cabac=1, deblock=1),
+    cfgs = [dict(subme=2, me_method=1, inter=0x10, n_refs=1), dict(subme=5, me_method=1, inter=0x13, intra=0x3, transform8x8=1, n_refs=3, cabac=1, deblock=1),
+            dict(subme=5, me_method=1, inter=0x13, intra=0x3, transform8x8=1, n_refs=3, cabac=1, deblock=1, mixed_refs=1),
+            dict(subme=1, inter=0x10, n_refs=2, mixed_refs=1, fast_pskip=0), dict(subme=4, me_method=1, inter=0x11, intra=0x1, n_refs=2, mixed_refs=1, dct_decimate=0, deblock=1),
+            dict(subme=3, inter=0x10, n_refs=2, cabac=1),
+            dict(subme=0), dict(subme=1), dict(subme=2, me_method=1), dict(subme=5, me_method=1, n_refs=3, cabac=1, deblock=1),
             dict(subme=4, me_method=1, n_refs=2, inter=0x3, intra=0x3, transform8x8=1, cabac=1, deblock=1),
             dict(subme=3, intra=0x1, inter=0x1, n_refs=2, deblock=1, dct_decimate=0, fast_pskip=0)]
     for size in ((208, 144), (200, 120)):

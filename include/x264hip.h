@@ -240,6 +240,7 @@ typedef struct {
     const int16_t *cost_mv;            /* device: p_cost_mv for this qp's lambda, centred at cost_mv_range */
     int cost_mv_range;
     int poc, ref_poc[8];               /* fdec->i_poc and fdec->ref_poc[0][] */
+    int mixed_refs;                    /* param.analyse.b_mixed_references (p8x8 blocks search every reference) */
     int64_t *profile;                  /* NULL, or device [batch][mb_h][8]: 100 MHz ticks each row wave spent
                                           0 waiting 1 loading 2 inter search 3 encode 4 stores 5 publish 6 intra analysis */
 } x264hip_slice_params;

@@ -14,7 +14,7 @@ from x264_vs2008_amd import slice as sl
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [c for c in CASES if not (c[4].get("inter", 0) & 0x30)]        # everything but sub-16x16 inter partitions
+SUPPORTED = [c for c in CASES if not (c[4].get("inter", 0) & 0x20)]        # everything but sub-8x8 inter partitions
 STATE = ["mb_type", "partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc",
          "chroma_dc", "chroma_ac"]
 

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
 
     for (int r = 0; r < g.n_refs; r++) {     // the loop of x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1090-1127
         MxCtx c;
-        c.fe = s_fe[wave]; c.fe_u = s_fc[wave]; c.fe_v = s_fc[wave] + 64; c.sy = g.sy; c.sc = g.sc; c.lane = lane;
+        c.fe = s_fe[wave]; c.fe_u = s_fc[wave]; c.fe_v = s_fc[wave] + 64; c.sy = g.sy; c.sc = g.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
 #pragma unroll
         for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + g.bs_y * bz + oy;
         c.cu = refs.u[r] + g.bs_c * bz + oc; c.cv = refs.v[r] + g.bs_c * bz + oc;

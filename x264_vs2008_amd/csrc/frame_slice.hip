@@ -50,6 +50,7 @@ struct SwArgs {
     int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS];
     int l0_n_ref0, l0_inv_ref_poc[SW_MAX_REFS];
     int me_method, me_range, subme, chroma_me, fast_pskip, dct_decimate, cabac, mv_range;
+    int flags_inter, mixed_refs; // X264_ANALYSE_PSUB16x16 (0x10) of param.analyse.inter; param.analyse.b_mixed_references
     int flags_intra;            // X264_ANALYSE_I4x4 | I8x8 bits that apply to this slice type (param.analyse.intra / .inter)
     int transform8x8;
     const u16 *q4mf, *q4bias, *q8mf, *q8bias;
@@ -90,6 +91,15 @@ struct SwLds {
     i16 t8[256];                // 8x8 transform: intermediate between the two 1-D passes
     signed char left_i4[4];     // the left macroblock's modes of blocks 5, 7, 13, 15
     signed char pred4[16], pred8[4];
+    // P partitions: the motion cache (h->mb.cache.ref / mv, x264_scan8 layout), a->l0.mvc, candidate records, final vectors
+    signed char cref[48];
+    i16 cmv[48][2];
+    i16 l0mvc[SW_MAX_REFS][5][2];
+    int pme[8][8];
+    i16 mv4[16][2];
+    signed char ref8[4];
+    i16 left_mv4[4][2];         // the left macroblock's vectors of blocks 3, 7, 11, 15 and references of its 8x8 blocks 1, 3
+    signed char left_r8[2];
     u16 q8mf[2][64], q8bias[2][64];
     int q8dq[2][64];
     // this frame's quantiser rows (cat 0 intra Y, 1 inter Y at qp; 2 intra C, 3 inter C at the chroma qp) and the centre of p_cost_mv
@@ -138,6 +148,32 @@ __device__ __forceinline__ void sw_mc16(SwLds &s, const SwRefs &refs, const SwAr
     }
     if (do_chroma) {
         const int cx = lane & 7, cy = lane >> 3;
+        const int dx = mvx & 7, dyy = mvy & 7;
+        const int ca = (8 - dx) * (8 - dyy), cb = dx * (8 - dyy), cc = (8 - dx) * dyy, cd = dx * dyy;
+        const ptrdiff_t cbase = oc + (ptrdiff_t)((mvy >> 3) + cy) * a.sc + (mvx >> 3) + cx + (ptrdiff_t)bc;
+        const u8 *pu = refs.u[ri] + cbase, *pv = refs.v[ri] + cbase;
+        s.fd[FDU + cy * FD + cx] = (u8)((ca * pu[0] + cb * pu[1] + cc * pu[a.sc] + cd * pu[a.sc + 1] + 32) >> 6);
+        s.fd[FDV + cy * FD + cx] = (u8)((ca * pv[0] + cb * pv[1] + cc * pv[a.sc] + cd * pv[a.sc + 1] + 32) >> 6);
+    }
+}
+
+// x264_mb_mc for any P partition: every pixel with the vector of its 4x4 block and the reference of its 8x8 (s.mv4 / s.ref8)
+__device__ __forceinline__ void sw_mc_parts(SwLds &s, const SwRefs &refs, const SwArgs &a, ptrdiff_t oy, ptrdiff_t oc, size_t by, size_t bc, int lane)
+{
+    {
+        const int r = lane >> 2, x = (lane & 3) * 4, blk = (r >> 2) * 4 + (x >> 2);
+        const int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1], ri = s.ref8[(r >> 3) * 2 + (x >> 3)];
+        const int qx = mvx & 3, qy = mvy & 3, idx = qy * 4 + qx;
+        const ptrdiff_t base = oy + (ptrdiff_t)((mvy >> 2) + r) * a.sy + (mvx >> 2) + x + (ptrdiff_t)by;
+        const u8 *pa = refs.y[ri][c_qpel_a[idx]] + base + (qy == 3) * a.sy;
+        const u8 *pb = refs.y[ri][c_qpel_b[idx]] + base + (qx == 3);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            s.fd[FDY + r * FD + x + i] = (idx & 5) ? (u8)(((int)pa[i] + (int)pb[i] + 1) >> 1) : pa[i];
+    }
+    {
+        const int cx = lane & 7, cy = lane >> 3, blk = (cy >> 1) * 4 + (cx >> 1);
+        const int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1], ri = s.ref8[(cy >> 2) * 2 + (cx >> 2)];
         const int dx = mvx & 7, dyy = mvy & 7;
         const int ca = (8 - dx) * (8 - dyy), cb = dx * (8 - dyy), cc = (8 - dx) * dyy, cd = dx * dyy;
         const ptrdiff_t cbase = oc + (ptrdiff_t)((mvy >> 3) + cy) * a.sc + (mvx >> 3) + cx + (ptrdiff_t)bc;
@@ -881,7 +917,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (mbx < a.mb_w - 1 && mby > 0) { nb |= NB_TOPRIGHT; type_topright = UNI(a.mb_type[mb - a.mb_w + 1]); }
         if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = UNI(a.mb_type[mb - a.mb_w - 1]); }
 
-        int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0;
+        int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0, part = 16;
         int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
         int satd_i8 = MX_COST_MAX, satd_i4 = MX_COST_MAX, i8_cbp = 0, i4_cbp = 0, t8 = 0, fi_open = 0, stat_alt = -1;
         if (a.flags_intra & 3) {
@@ -1075,6 +1111,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = UNI(a.ref[o * 4 + 2]); bx = UNI(a.mv[(o * 16 + 12) * 2]); byv = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
             if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = UNI(a.ref[o * 4 + 2]); cx = UNI(a.mv[(o * 16 + 12) * 2]); cy = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
             else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = UNI(a.ref[o * 4 + 3]); cx = UNI(a.mv[(o * 16 + 15) * 2]); cy = UNI(a.mv[(o * 16 + 15) * 2 + 1]); }
+            if (a.flags_inter & 0x10) {
+                // the full motion cache for x264_mb_predict_mv on partitions: -2 = not available, neighbours as cache_load leaves them
+                if (lane < 48) { s.cref[lane] = -2; s.cmv[lane][0] = 0; s.cmv[lane][1] = 0; }
+                WAVE_SYNC();
+                if ((nb & NB_TOP) && lane < 4) {
+                    const int o = mb - a.mb_w;
+                    s.cref[4 + lane] = a.ref[o * 4 + 2 + (lane >> 1)];
+                    s.cmv[4 + lane][0] = a.mv[(o * 16 + 12 + lane) * 2]; s.cmv[4 + lane][1] = a.mv[(o * 16 + 12 + lane) * 2 + 1];
+                }
+                if ((nb & NB_TOPLEFT) && lane == 4) {
+                    const int o = mb - a.mb_w - 1;
+                    s.cref[3] = a.ref[o * 4 + 3]; s.cmv[3][0] = a.mv[(o * 16 + 15) * 2]; s.cmv[3][1] = a.mv[(o * 16 + 15) * 2 + 1];
+                }
+                if ((nb & NB_TOPRIGHT) && lane == 5) {
+                    const int o = mb - a.mb_w + 1;
+                    s.cref[8] = a.ref[o * 4 + 2]; s.cmv[8][0] = a.mv[(o * 16 + 12) * 2]; s.cmv[8][1] = a.mv[(o * 16 + 12) * 2 + 1];
+                }
+                if ((nb & NB_LEFT) && lane >= 8 && lane < 12) {
+                    const int i = lane - 8;
+                    s.cref[11 + 8 * i] = s.left_r8[i >> 1]; s.cmv[11 + 8 * i][0] = s.left_mv4[i][0]; s.cmv[11 + 8 * i][1] = s.left_mv4[i][1];
+                }
+                WAVE_SYNC();
+            }
             // x264_mb_predict_mv_16x16, :90-128
             auto predict16 = [&](int i_ref, int &px, int &py) {
                 const int cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
@@ -1100,7 +1159,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 // ---- x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1077-1143 ----
                 const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
                 MxCtx c;
-                c.fe = (const u32 *)s.fe; c.fe_u = s.fe + 256; c.fe_v = s.fe + 320; c.sy = a.sy; c.sc = a.sc; c.lane = lane;
+                c.fe = (const u32 *)s.fe; c.fe_u = s.fe + 256; c.fe_v = s.fe + 320; c.sy = a.sy; c.sc = a.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
                 c.cost_g = a.cost_mv + a.cost_center; c.cost_l = s.costl;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
@@ -1150,20 +1209,168 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (lane == 0) {
                         a.mvr[((size_t)r * nmb + mb) * 2] = (i16)smx; a.mvr[((size_t)r * nmb + mb) * 2 + 1] = (i16)smy;
                         s.left_mvr[r][0] = (i16)smx; s.left_mvr[r][1] = (i16)smy;
+                        s.l0mvc[r][0][0] = (i16)smx; s.l0mvc[r][0][1] = (i16)smy;          // a->l0.mvc[i_ref][0]
                     }
                 }
                 if (early_skip) { type = T_P_SKIP; skip_mc = 1; }
                 else {
                     type = T_P_L0;
-                    // x264_me_refine_qpel on the winner (analyse.c:2289-2294); the reference cost leaves the sum (me.c:639-640)
+                    // point the search context at a block of reference r (LOAD_HPELS, analyse.c:1065-1072)
+                    auto aim = [&](int r, int w, int h, int bx, int by) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) c.pl[k] = refs.y[ref][k] + by_ + oy;
-                    c.cu = refs.u[ref] + bc_ + oc; c.cv = refs.v[ref] + bc_ + oc;
-                    c.mvpx = bmvpx; c.mvpy = bmvpy;
-                    best -= a.ref_cost[ref];
-                    best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
-                    PROF(2);
+                        for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + by_ + oy + (ptrdiff_t)by * a.sy + bx;
+                        c.cu = refs.u[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1); c.cv = refs.v[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1);
+                        c.set_block(w, h, bx, by);
+                    };
+                    // candidate records of the partition analysis (x264_me_t's mv / cost / cost_mv / i_ref / i_ref_cost / mvp):
+                    // slots 0-3 me8x8, 4-5 me16x8, 6-7 me8x16.  Wave-uniform values, parked in LDS because they are indexed.
+                    auto pme_put = [&](int slot, int vx, int vy, int cost, int cost_mv, int r, int ref_cost, int px, int py) {
+                        if (lane == 0) { int *d = s.pme[slot]; d[0] = vx; d[1] = vy; d[2] = cost; d[3] = cost_mv; d[4] = r; d[5] = ref_cost; d[6] = px; d[7] = py; }
+                        WAVE_SYNC();
+                    };
+                    auto pme = [&](int slot, int f) -> int { return UNI(s.pme[slot][f]); };
+                    // x264_macroblock_cache_ref / _mv on a run of 4x4 blocks of the motion cache
+                    auto cache_set = [&](int x, int y, int w, int h, int r, int vx, int vy, int set_mv) {
+                        if (lane < 16) {
+                            const int i = lane & 3, j = lane >> 2, k = 12 + i + 8 * j;
+                            if (i >= x && i < x + w && j >= y && j < y + h) {
+                                s.cref[k] = (signed char)r;
+                                if (set_mv) { s.cmv[k][0] = (i16)vx; s.cmv[k][1] = (i16)vy; }
+                            }
+                        }
+                        WAVE_SYNC();
+                    };
+                    // x264_mb_predict_mv (R/common/macroblock.c:28-88) from the cache; cur_part = h->mb.i_partition
+                    auto predict_blk = [&](int cur_part, int idx, int width, int &px, int &py) {
+                        const int i8 = sw_scan8(idx), i_ref = UNI(s.cref[i8]);
+                        int ra = UNI(s.cref[i8 - 1]), rb = UNI(s.cref[i8 - 8]), rc = UNI(s.cref[i8 - 8 + width]), kc = i8 - 8 + width;
+                        if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { kc = i8 - 8 - 1; rc = UNI(s.cref[kc]); }
+                        const int ax = UNI(s.cmv[i8 - 1][0]), ay = UNI(s.cmv[i8 - 1][1]), bx = UNI(s.cmv[i8 - 8][0]), byv = UNI(s.cmv[i8 - 8][1]);
+                        const int cx = UNI(s.cmv[kc][0]), cy = UNI(s.cmv[kc][1]);
+                        if (cur_part == 14) {                       // D_16x8
+                            if (idx == 0 && rb == i_ref) { px = bx; py = byv; return; }
+                            if (idx != 0 && ra == i_ref) { px = ax; py = ay; return; }
+                        } else if (cur_part == 15) {                // D_8x16
+                            if (idx == 0 && ra == i_ref) { px = ax; py = ay; return; }
+                            if (idx != 0 && rc == i_ref) { px = cx; py = cy; return; }
+                        }
+                        const int cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
+                        if (cnt > 1) { px = sw_median(ax, bx, cx); py = sw_median(ay, byv, cy); }
+                        else if (cnt == 1) { if (ra == i_ref) { px = ax; py = ay; } else if (rb == i_ref) { px = bx; py = byv; } else { px = cx; py = cy; } }
+                        else if (rb == -2 && rc == -2 && ra != -2) { px = ax; py = ay; }
+                        else { px = sw_median(ax, bx, cx); py = sw_median(ay, byv, cy); }
+                    };
                     int i_cost = best;
+                    part = 16;                                       // D_16x16
+                    if (a.flags_inter & 0x10) {
+                        // ---- X264_ANALYSE_PSUB16x16: p8x8, then p16x8 / p8x16 (R/encoder/analyse.c:2222-2265) ----
+                        cache_set(0, 0, 4, 4, ref, 0, 0, 0);
+                        int cost8x8;
+                        if (a.mixed_refs) {                          // x264_mb_analyse_inter_p8x8_mixed_ref, :1146-1219
+                            int maxref = a.n_refs - 1;
+                            const int tt = type_top == T_I_8x8 ? 0 : type_top, tl = left_type == T_I_8x8 ? 0 : left_type;   // as cache_save stores them
+                            if (maxref > 0 && ref == 0 && tt && tl) {
+                                maxref = 0;
+                                maxref = max(maxref, UNI(s.cref[3])); maxref = max(maxref, UNI(s.cref[4])); maxref = max(maxref, UNI(s.cref[6]));
+                                maxref = max(maxref, UNI(s.cref[8])); maxref = max(maxref, UNI(s.cref[11])); maxref = max(maxref, UNI(s.cref[27]));
+                            }
+                            for (int i = 0; i < 4; i++) {
+                                int bcost = 0x7fffffff, bvx = 0, bvy = 0, bcm = 0, br = 0, bpx = 0, bpy = 0;
+                                for (int r = 0; r <= maxref; r++) {
+                                    cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, r, 0, 0, 0);
+                                    int px, py, vx, vy, cm;
+                                    predict_blk(13, 4 * i, 2, px, py);
+                                    aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
+                                    c.mvpx = px; c.mvpy = py;
+                                    int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + a.ref_cost[r];
+                                    if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
+                                    WAVE_SYNC();
+                                    if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
+                                }
+                                cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, br, bvx, bvy, 1);
+                                pme_put(i, bvx, bvy, bcost + a.lambda, bcm, br, a.ref_cost[br], bpx, bpy);      // + lambda * i_sub_mb_p_cost_table[D_L0_8x8]
+                            }
+                            cost8x8 = pme(0, 2) + pme(1, 2) + pme(2, 2) + pme(3, 2);
+                            if (!a.cabac && !(pme(0, 4) | pme(1, 4) | pme(2, 4) | pme(3, 4))) cost8x8 -= a.ref_cost[0] * 4;
+                        } else {                                     // x264_mb_analyse_inter_p8x8, :1221-1272
+                            const int r = ref, ref_cost = a.cabac || r ? a.ref_cost[r] : 0;
+                            if (lane == 0) { s.l0mvc[r][0][0] = (i16)mvx; s.l0mvc[r][0][1] = (i16)mvy; }
+                            WAVE_SYNC();
+                            for (int i = 0; i < 4; i++) {
+                                int px, py, vx, vy, cm;
+                                predict_blk(13, 4 * i, 2, px, py);
+                                aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
+                                c.mvpx = px; c.mvpy = py;
+                                const int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm);
+                                cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, r, vx, vy, 1);
+                                if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
+                                pme_put(i, vx, vy, cost + ref_cost + a.lambda, cm, r, ref_cost, px, py);
+                            }
+                            cost8x8 = pme(0, 2) + pme(1, 2) + pme(2, 2) + pme(3, 2);
+                            if (a.cabac) cost8x8 -= ref_cost;
+                        }
+                        if (cost8x8 < best) { type = T_P_8x8; part = 13; i_cost = cost8x8; }
+                        const int thresh16x8 = pme(1, 3) + pme(2, 3);
+                        if (cost8x8 < best + thresh16x8)
+                            for (int dir = 0; dir < 2; dir++) {      // 0: x264_mb_analyse_inter_p16x8 (:1274), 1: _p8x16 (:1324)
+                                int sum = 0;
+                                for (int i = 0; i < 2; i++) {
+                                    const int ra = dir ? pme(i, 4) : pme(2 * i, 4), rb = dir ? pme(i + 2, 4) : pme(2 * i + 1, 4), nr = ra == rb ? 1 : 2;
+                                    int bcost = 0x7fffffff, bvx = 0, bvy = 0, bcm = 0, br = 0, bpx = 0, bpy = 0;
+                                    for (int j = 0; j < nr; j++) {
+                                        const int r = j ? rb : ra, k1 = dir ? i + 1 : 2 * i + 1, k2 = dir ? i + 3 : 2 * i + 2;
+                                        WAVE_SYNC();
+                                        if (lane < 6) {
+                                            const int k = lane >> 1 == 0 ? 0 : lane >> 1 == 1 ? k1 : k2;
+                                            s.mvc[lane >> 1][lane & 1] = s.l0mvc[r][k][lane & 1];
+                                        }
+                                        if (dir) cache_set(2 * i, 0, 2, 4, r, 0, 0, 0); else cache_set(0, 2 * i, 4, 2, r, 0, 0, 0);
+                                        int px, py, vx, vy, cm;
+                                        predict_blk(dir ? 15 : 14, dir ? 4 * i : 8 * i, dir ? 2 : 4, px, py);
+                                        aim(r, dir ? 8 : 16, dir ? 16 : 8, dir ? 8 * i : 0, dir ? 0 : 8 * i);
+                                        c.mvpx = px; c.mvpy = py;
+                                        const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + a.ref_cost[r];
+                                        if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
+                                    }
+                                    if (dir) cache_set(2 * i, 0, 2, 4, br, bvx, bvy, 1); else cache_set(0, 2 * i, 4, 2, br, bvx, bvy, 1);
+                                    pme_put(4 + 2 * dir + i, bvx, bvy, bcost, bcm, br, a.ref_cost[br], bpx, bpy);
+                                    sum += bcost;
+                                }
+                                if (sum < i_cost) { i_cost = sum; type = T_P_L0; part = dir ? 15 : 14; }
+                            }
+                    }
+                    // x264_me_refine_qpel on the winning partition (analyse.c:2289-2352); the reference cost leaves every block's sum (me.c:639-640)
+                    if (part == 16) {
+                        aim(ref, 16, 16, 0, 0);
+                        c.mvpx = bmvpx; c.mvpy = bmvpy;
+                        best -= a.ref_cost[ref];
+                        best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
+                        i_cost = best;
+                        if (lane < 16) { s.mv4[lane][0] = (i16)mvx; s.mv4[lane][1] = (i16)mvy; }
+                        if (lane < 4) s.ref8[lane] = (signed char)ref;
+                    } else {
+                        i_cost = 0;
+                        const int nblk = part == 13 ? 4 : 2, slot0 = part == 13 ? 0 : part == 14 ? 4 : 6;
+                        for (int i = 0; i < nblk; i++) {
+                            const int bx = part == 13 ? 8 * (i & 1) : part == 15 ? 8 * i : 0, by = part == 13 ? 8 * (i >> 1) : part == 14 ? 8 * i : 0;
+                            const int w = part == 14 ? 16 : 8, h = part == 15 ? 16 : 8, r = pme(slot0 + i, 4);
+                            int vx = pme(slot0 + i, 0), vy = pme(slot0 + i, 1);
+                            aim(r, w, h, bx, by);
+                            c.mvpx = pme(slot0 + i, 6); c.mvpy = pme(slot0 + i, 7);
+                            i_cost += me_refine_qpel16(c, L, mo, pme(slot0 + i, 2) - pme(slot0 + i, 5), vx, vy);
+                            WAVE_SYNC();
+                            if (lane < 16) {
+                                const int x4 = (lane & 3) * 4, y4 = (lane >> 2) * 4;
+                                if (x4 >= bx && x4 < bx + w && y4 >= by && y4 < by + h) { s.mv4[lane][0] = (i16)vx; s.mv4[lane][1] = (i16)vy; }
+                            }
+                            if (lane < 4) {
+                                const int x8 = (lane & 1) * 8, y8 = (lane >> 1) * 8;
+                                if (x8 >= bx && x8 < bx + w && y8 >= by && y8 < by + h) s.ref8[lane] = (signed char)r;
+                            }
+                        }
+                    }
+                    WAVE_SYNC();
+                    PROF(2);
                     if (a.chroma_me) {
                         analyse_chroma();
                         analyse_intra(i_cost - satd_chroma);
@@ -1196,6 +1403,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         WAVE_SYNC();
         if (type == T_P_SKIP) {
             mvx = pskx; mvy = psky; ref = 0;
+            if (lane < 16) { s.mv4[lane][0] = (i16)pskx; s.mv4[lane][1] = (i16)psky; }
+            if (lane < 4) s.ref8[lane] = 0;
+            WAVE_SYNC();
             if (!skip_mc) {
                 const int vx = clip3(mvx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
                 const int vy = clip3(mvy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
@@ -1246,7 +1456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 sw_pred8c(s, predc, lane);
                 cbp_chroma = sw_encode_chroma(s, a, 0, lane);
             } else {
-                sw_mc16(s, refs, a, ref, mvx, mvy, oy, oc, by_, bc_, lane, true);
+                sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
                 WAVE_SYNC();
                 if (a.transform8x8) {
                     // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
@@ -1262,7 +1472,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 }
                 cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane) : sw_encode_inter_luma(s, a, lane);
                 cbp_chroma = sw_encode_chroma(s, a, 1, lane);
-                if (!(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
+                if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
             }
         }
         const int intra = IS_INTRA_T(type);
@@ -1279,19 +1489,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             }
         }
         if (lane < 16) {
-            a.mv[((size_t)mb * 16 + lane) * 2] = (i16)(intra ? 0 : mvx);
-            a.mv[((size_t)mb * 16 + lane) * 2 + 1] = (i16)(intra ? 0 : mvy);
+            a.mv[((size_t)mb * 16 + lane) * 2] = (i16)(intra ? 0 : s.mv4[lane][0]);
+            a.mv[((size_t)mb * 16 + lane) * 2 + 1] = (i16)(intra ? 0 : s.mv4[lane][1]);
+            if ((lane & 3) == 3) { s.left_mv4[lane >> 2][0] = (i16)(intra ? 0 : s.mv4[lane][0]); s.left_mv4[lane >> 2][1] = (i16)(intra ? 0 : s.mv4[lane][1]); }
             const bool i48 = type == T_I_4x4 || type == T_I_8x8;
             a.i4mode[(size_t)mb * 16 + lane] = i48 ? s.i4c[sw_scan8(lane)] : (signed char)2;
             if (lane == 5 || lane == 7 || lane == 13 || lane == 15)       // what the next macroblock sees to its left
                 s.left_i4[lane == 5 ? 0 : lane == 7 ? 1 : lane == 13 ? 2 : 3] = i48 ? s.i4c[sw_scan8(lane)] : (signed char)2;
         }
-        if (lane < 4) a.ref[(size_t)mb * 4 + lane] = (signed char)(is_p ? (intra ? -1 : ref) : -1);
+        if (lane < 4) {
+            const signed char rv = (signed char)(is_p ? (intra ? -1 : s.ref8[lane]) : -1);
+            a.ref[(size_t)mb * 4 + lane] = rv;
+            if (lane & 1) s.left_r8[lane >> 1] = rv;
+        }
         if (lane < 27) a.nnz[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
         if (lane == 0) {
             const int cbp_dc = a.cabac ? (s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2) : 0;
             a.mb_type[mb] = (signed char)type;
-            a.partition[mb] = 16;
+            a.partition[mb] = (signed char)(intra || type == T_P_SKIP ? 16 : part);
             a.i16mode[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
             a.chroma_mode[mb] = (signed char)(intra ? predc : 0);
             a.qp_out[mb] = (signed char)a.qp;
@@ -1315,7 +1530,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (lane < 16) a.luma_dc[(size_t)mb * 16 + lane] = (coded && type == T_I_16x16 && s.nnz[24]) ? s.lv_dc[lane] : (i16)0;
             if (lane < 8) a.chroma_dc[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
         }
-        left_type = type; left_ref = is_p ? (intra ? -1 : ref) : -1; left_mvx = intra ? 0 : mvx; left_mvy = intra ? 0 : mvy;
+        left_type = type;
+        left_ref = is_p ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);
         PROF(4);
         // ---- publish: everything this macroblock wrote is visible before the count moves ----
         __threadfence();
@@ -1400,7 +1616,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
     if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
     if (p->me_method < 0 || p->me_method > 1) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX)", p->me_method); return -1; }
-    if (p->analyse_inter & 0x30) { set_error("slice_sweep: sub-16x16 inter partitions (p8x8, p4x4) not built yet"); return -1; }
+    if (p->analyse_inter & 0x20) { set_error("slice_sweep: sub-8x8 inter partitions (X264_ANALYSE_PSUB8x8: p4x4 / p8x4 / p4x8) not built yet"); return -1; }
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
@@ -1429,6 +1645,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.q4mf = p->quant4_mf; a.q4bias = p->quant4_bias; a.dq4 = p->dequant4_mf;
     a.q8mf = p->quant8_mf; a.q8bias = p->quant8_bias; a.dq8 = p->dequant8_mf;
     a.transform8x8 = p->transform8x8 != 0;
+    a.flags_inter = is_p ? (p->analyse_inter & 0x10) : 0; a.mixed_refs = p->mixed_refs != 0;
     // x264_mb_analyse_intra takes its flags from param.analyse.intra in I slices and from .inter in P slices (analyse.c:614);
     // i8x8 needs the 8x8 transform (x264_validate_parameters, R/encoder/encoder.c:487-491)
     a.flags_intra = (is_p ? p->analyse_inter : p->analyse_intra) & (a.transform8x8 ? 3 : 1);

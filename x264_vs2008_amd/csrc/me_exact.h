@@ -57,6 +57,10 @@ struct MxCtx {
     const i16 *cost_l;        // LDS copy of cost_g[-MX_COST_LDS .. MX_COST_LDS], or nullptr
     int mvpx, mvpy;           // the predictor the costs are relative to
     int sy, sc, lane;
+    // the block searched: 16x16, 16x8, 8x16 or 8x8 at (bx, by) inside the macroblock.  pl / cu / cv point at the block
+    // (chroma at bx/2, by/2); fe_off = dword offset of the block in fe (by*4 + bx/4), cfe_off = byte offset in fe_u / fe_v
+    int bw, bh, fe_off, cfe_off;
+    __device__ __forceinline__ void set_block(int w, int h, int bx, int by) { bw = w; bh = h; fe_off = by * 4 + (bx >> 2); cfe_off = (by >> 1) * 8 + (bx >> 1); }
     __device__ __forceinline__ int cost1(int d) const
     {
         // d is wave-uniform: keep the looked-up cost in a scalar register
@@ -71,11 +75,22 @@ __device__ __forceinline__ void sad_fpel4(const MxCtx &c, const int fx[4], const
 {
     const int g = c.lane >> 4, row = c.lane & 15;
     const int mx = MX_PICK4(g, fx), my = MX_PICK4(g, fy);
-    u32 r[4];
-    load16u(c.pl[0] + (ptrdiff_t)(my + row) * c.sy + mx, r);
-    const u32 *f = c.fe + 4 * row;
-    u32 s = sad4(r[0], f[0], 0); s = sad4(r[1], f[1], s); s = sad4(r[2], f[2], s); s = sad4(r[3], f[3], s);
-    int v = (int)s;
+    int v = 0;
+    if (row < c.bh) {
+        const u8 *p = c.pl[0] + (ptrdiff_t)(my + row) * c.sy + mx;
+        const u32 *f = c.fe + c.fe_off + 4 * row;
+        u32 s;
+        if (c.bw == 16) {
+            u32 r[4];
+            load16u(p, r);
+            s = sad4(r[0], f[0], 0); s = sad4(r[1], f[1], s); s = sad4(r[2], f[2], s); s = sad4(r[3], f[3], s);
+        } else {
+            u32 r0, r1, t;
+            load9u(p, r0, r1, t);
+            s = sad4(r0, f[0], 0); s = sad4(r1, f[1], s);
+        }
+        v = (int)s;
+    }
     v = row_sum16(v);
     out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16); out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
 }
@@ -86,12 +101,24 @@ __device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const
     int mx = fx[0], my = fy[0];
 #pragma unroll
     for (int k = 1; k < 8; k++) if (g == k) { mx = fx[k]; my = fy[k]; }
-    u32 a[4], b[4];
-    load16u(c.pl[0] + (ptrdiff_t)(my + r) * c.sy + mx, a);
-    load16u(c.pl[0] + (ptrdiff_t)(my + r + 8) * c.sy + mx, b);
-    const u32 *f0 = c.fe + 4 * r, *f1 = c.fe + 4 * (r + 8);
-    u32 s = sad4(a[0], f0[0], 0); s = sad4(a[1], f0[1], s); s = sad4(a[2], f0[2], s); s = sad4(a[3], f0[3], s);
-    s = sad4(b[0], f1[0], s); s = sad4(b[1], f1[1], s); s = sad4(b[2], f1[2], s); s = sad4(b[3], f1[3], s);
+    u32 s = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int row = r + 8 * half;
+        if (row < c.bh) {
+            const u8 *p = c.pl[0] + (ptrdiff_t)(my + row) * c.sy + mx;
+            const u32 *f = c.fe + c.fe_off + 4 * row;
+            if (c.bw == 16) {
+                u32 a[4];
+                load16u(p, a);
+                s = sad4(a[0], f[0], s); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
+            } else {
+                u32 a0, a1, t;
+                load9u(p, a0, a1, t);
+                s = sad4(a0, f[0], s); s = sad4(a1, f[1], s);
+            }
+        }
+    }
     int v = (int)s;
     v = half_sum8(v);
 #pragma unroll
@@ -104,17 +131,29 @@ __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const
     const int mx = MX_PICK4(g, qx), my = MX_PICK4(g, qy);
     const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
     const ptrdiff_t base = (ptrdiff_t)((my >> 2) + row) * c.sy + (mx >> 2);
-    u32 a[4];
-    load16u(c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy, a);
-    if (idx & 5) {
-        u32 b[4];
-        load16u(c.pl[c_qpel_b[idx]] + base + (fx == 3), b);
+    int v = 0;
+    if (row < c.bh) {
+        const u8 *pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy, *pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+        const u32 *f = c.fe + c.fe_off + 4 * row;
+        u32 s;
+        if (c.bw == 16) {
+            u32 a[4];
+            load16u(pa, a);
+            if (idx & 5) {
+                u32 b[4];
+                load16u(pb, b);
 #pragma unroll
-        for (int k = 0; k < 4; k++) a[k] = avg4(a[k], b[k]);
+                for (int k = 0; k < 4; k++) a[k] = avg4(a[k], b[k]);
+            }
+            s = sad4(a[0], f[0], 0); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
+        } else {
+            u32 a0, a1, t;
+            load9u(pa, a0, a1, t);
+            if (idx & 5) { u32 b0, b1; load9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
+            s = sad4(a0, f[0], 0); s = sad4(a1, f[1], s);
+        }
+        v = (int)s;
     }
-    const u32 *f = c.fe + 4 * row;
-    u32 s = sad4(a[0], f[0], 0); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
-    int v = (int)s;
     v = row_sum16(v);
     out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16); out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
 }
@@ -172,8 +211,9 @@ __device__ __forceinline__ void me_subpel_costs4(const MxCtx &c, const int qx[4]
     const int g = c.lane >> 4, j = c.lane & 15;
     const int mx = MX_PICK4(g, qx), my = MX_PICK4(g, qy);
     int v = 0;
-    if (j < 8) {
-        const int bx = (j & 1) * 8, by = (j >> 1) * 4;
+    const int nbx = c.bw >> 3, n_luma = nbx * (c.bh >> 2), n_cunits = c.bh >> 3;      // 8x4 luma blocks; 4-row chroma units per plane
+    if (j < n_luma) {
+        const int bx = (nbx == 2 ? (j & 1) : 0) * 8, by = (nbx == 2 ? (j >> 1) : j) * 4;
         const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
         const ptrdiff_t base = (ptrdiff_t)((my >> 2) + by) * c.sy + (mx >> 2) + bx;
         const u8 *pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy, *pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
@@ -187,12 +227,13 @@ __device__ __forceinline__ void me_subpel_costs4(const MxCtx &c, const int qx[4]
                 load9u(pb + (ptrdiff_t)y * c.sy, b0, b1, t);
                 p[y][0] = avg4(p[y][0], b0); p[y][1] = avg4(p[y][1], b1);
             }
-            f[y][0] = c.fe[(by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[(by + y) * 4 + (bx >> 2) + 1];
+            f[y][0] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2) + 1];
         }
         v = blk8x4_cost(f, p, satd);
-    } else if (chroma && j < 12) {
-        const int by = ((j - 8) & 1) * 4;
-        const u8 *plane = j < 10 ? c.cu : c.cv, *fe = j < 10 ? c.fe_u : c.fe_v;
+    } else if (chroma && j >= 8 && j < 12 && ((j - 8) & 1) < n_cunits) {
+        // mbcmp[i_pixel + 3]: 8x8 / 8x4 chroma blocks are 8x4 units, 4x8 / 4x4 ones are 4x4 units (each halved on its own, pixel.c:235-253)
+        const int by = ((j - 8) & 1) * 4, wide = c.bw == 16;
+        const u8 *plane = j < 10 ? c.cu : c.cv, *fe = (j < 10 ? c.fe_u : c.fe_v) + c.cfe_off;
         const int dx = mx & 7, dy = my & 7;
         const int ca = (8 - dx) * (8 - dy), cb = dx * (8 - dy), cc = (8 - dx) * dy, cd = dx * dy;
         const u8 *s = plane + (ptrdiff_t)((my >> 3) + by) * c.sc + (mx >> 3);
@@ -210,9 +251,9 @@ __device__ __forceinline__ void me_subpel_costs4(const MxCtx &c, const int qx[4]
                 const u32 px = (u32)((ca * a0 + cb * a1 + cc * b0 + cd * b1 + 32) >> 6);
                 if (x < 4) w0 |= px << (8 * x); else w1 |= px << (8 * (x - 4));
             }
-            p[y][0] = w0; p[y][1] = w1;
             const u32 *fr = (const u32 *)(fe + (by + y) * 8);
-            f[y][0] = fr[0]; f[y][1] = fr[1];
+            p[y][0] = w0; f[y][0] = fr[0];
+            p[y][1] = wide ? w1 : 0u; f[y][1] = wide ? fr[1] : 0u;      // a 4-wide unit: the right half contributes nothing
         }
         v = blk8x4_cost(f, p, satd);
     }

@@ -38,7 +38,7 @@ class SliceParams(C.Structure):
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p), ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
                 ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
-                ("profile", C.c_void_p)]
+                ("mixed_refs", C.c_int), ("profile", C.c_void_p)]
 
 
 def iframe_qp(qp, ip_factor=1.4):
@@ -72,12 +72,12 @@ class ChainEncoder:
 
     def __init__(self, lib, width, height, cqm, batch=1, qp=26, me_method=0, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
-                 chroma_qp_offset=0, keyint=0):
+                 chroma_qp_offset=0, keyint=0, mixed_refs=0):
         self.lib = lib
         self.ctx = FrameCtx(lib, width, height, batch=batch)
         self.opt = dict(qp=qp, me_method=me_method, me_range=me_range, subme=subme, n_refs=n_refs, inter=inter, intra=intra,
                         transform8x8=transform8x8, fast_pskip=fast_pskip, dct_decimate=dct_decimate, chroma_me=chroma_me, cabac=cabac,
-                        deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint)
+                        deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint, mixed_refs=mixed_refs)
         self.cqm = CqmDevice(lib, cqm)
         self.cost = {}
         self.fenc = self.ctx.new_picture()
@@ -121,7 +121,7 @@ class ChainEncoder:
                         cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
                         quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
-                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc,
+                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
                         profile=self.profile.ptr if self.profile else None)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]

@@ -46,7 +46,8 @@ def load_cqm():
 
 def analysis_options(args):
     return dict(qp=args.qp, me_method=ME_HEX, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
-                chroma_me=1, cabac=1, deblock=1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8)
+                chroma_me=1, cabac=1, deblock=1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8,
+                mixed_refs=args.mixed_refs)
 
 
 def cpu_baseline(args):
@@ -85,7 +86,9 @@ def main():
     ap.add_argument("--refs", type=int, default=3)
     ap.add_argument("--subme", type=int, default=5)
     ap.add_argument("--keyint", type=int, default=24)
-    ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x3, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 (| PSUB16x16 0x10: not built)")
+    ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x13, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 | PSUB16x16 0x10 "
+                    "(PSUB8x8 0x20 is not built)")
+    ap.add_argument("--mixed-refs", type=int, default=1, help="param.analyse.b_mixed_references")
     ap.add_argument("--intra", type=lambda v: int(v, 0), default=0x3, help="param.analyse.intra")
     ap.add_argument("--dct8", type=int, default=1, help="param.analyse.b_transform_8x8")
     ap.add_argument("--cpu-frames", type=int, default=40)
@@ -177,10 +180,11 @@ def main():
             "config": {"workload": "%dx%d I/P chains through the reference's per-macroblock loop on the GPU (cache_load, "
                                    "x264_macroblock_analyse, x264_macroblock_encode, cache_save, deblock, borders, half-pel planes): "
                                    "hex ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; "
-                                   "analyse.inter 0x%x intra 0x%x 8x8dct %d; macroblock types built so far: I_16x16 / I_8x8 / I_4x4 / "
-                                   "P_L0 16x16 / P_SKIP (no sub-16x16 inter partitions, B-frames, RD or trellis yet -- the medium "
-                                   "preset minus those); entropy coding on the host, not timed"
-                                   % (args.width, args.height, args.subme, args.refs, args.qp, args.keyint, args.inter, args.intra, args.dct8),
+                                   "analyse.inter 0x%x intra 0x%x 8x8dct %d mixed-refs %d; macroblock types built so far: I_16x16 / "
+                                   "I_8x8 / I_4x4 / P_L0 16x16, 16x8, 8x16 / P_8x8 / P_SKIP (the medium preset minus B-frames, RD "
+                                   "(subme 7 -> 5) and trellis); entropy coding on the host, not timed"
+                                   % (args.width, args.height, args.subme, args.refs, args.qp, args.keyint, args.inter, args.intra, args.dct8,
+                                      args.mixed_refs),
                        "frames_per_step": B, "i_frames_in_timed_steps": n_i,
                        "parallelism": "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); "
                                       "chains shard across GPUs with no data-path collective"},

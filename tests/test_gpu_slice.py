@@ -82,3 +82,22 @@ def test_sweep_batched_chains_are_independent(hip_lib, cqm):
     for f in range(frames):
         for b in range(3):
             check_frame(out[f], gold, f, kw.get("n_refs", 1), b=b)
+
+
+def test_sweep_full_hd_matches_twin(hip_lib, oracle_lib, cqm):
+    """BASELINE's frame size: a 3-frame 1920x1080 chain (120x68 macroblocks, the medium-like option set) against the CPU
+    twin of the same loop (oracle/slice_oracle.c, itself pinned against the reference on the small chains)."""
+    from oracle import refslice as rs
+    w, h, n = 1920, 1080, 3
+    kw = dict(qp=28, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
+    y, u, v = rs.clip(w, h, n)
+    want = rs.run(oracle_lib, "x264o_encode_chain", rs.make_params(w, h, n, **kw), y, u, v)
+    out = run_chain(hip_lib, cqm, (w, h), n, y, u, v, kw)
+    for f in range(n):
+        for k in STATE:
+            got, ref = out[f][k][0], want[k][f]
+            assert np.array_equal(got.reshape(ref.shape), ref), "frame %d: %s differs first at %s" % (f, k, np.argwhere(got.reshape(ref.shape) != ref)[:3].tolist())
+        for nm in ("y", "u", "v"):
+            assert np.array_equal(out[f]["fin_" + nm][0], want["fin_" + nm][f]), "frame %d: filtered %s" % (f, nm)
+    t = want["mb_type"][1:]
+    assert (t == sl.P_8x8).any() and (t == sl.P_L0).any() and (want["mb_type"][0] == sl.I_4x4).any()

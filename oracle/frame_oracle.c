@@ -381,14 +381,89 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
             if (bmx == ox && bmy == oy) break;
             if (!INRANGE(bmx, bmy)) break;
         } while (++i < me_range);
-    } else {                                                     /* hexagon, me.c:246-305 */
+    }
+    int do_hex = method == 1, hex_range = me_range;
+    if (method == 2) {                                           /* uneven-cross multi-hexagon, me.c:306-447 */
+        static const int size_shift[7] = {0, 1, 1, 2, 3, 3, 4};
+        static const int range_mul[4][4] = {{3, 3, 4, 4}, {3, 4, 4, 4}, {4, 4, 4, 5}, {4, 4, 5, 6}};
+        static const int hex4[16][2] = {{-4, 2}, {-4, 1}, {-4, 0}, {-4, -1}, {-4, -2}, {4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2},
+                                        {2, 3}, {0, 4}, {-2, 3}, {-2, -3}, {0, -4}, {2, -3}};
+        int ucost1, ucost2, cross_start = 1, omx, omy, done = 0, j;
+#define SAD_THRESH(v) (bcost < ((v) >> size_shift[c->pix]))
+#define X4(ax, ay, bx_, by_, cx_, cy_, dx_, dy_) do { TRY(omx + (ax), omy + (ay)); TRY(omx + (bx_), omy + (by_)); TRY(omx + (cx_), omy + (cy_)); TRY(omx + (dx_), omy + (dy_)); } while (0)
+#define DIA1(mx_, my_) do { omx = (mx_); omy = (my_); X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(start, x_max, y_max) do { \
+        i = (start); \
+        if ((x_max) <= (c->fmax[0] - omx < omx - c->fmin[0] ? c->fmax[0] - omx : omx - c->fmin[0])) \
+            for (; i < (x_max) - 2; i += 4) X4(i, 0, -i, 0, i + 2, 0, -i - 2, 0); \
+        for (; i < (x_max); i += 2) { if (omx + i <= c->fmax[0]) TRY(omx + i, omy); if (omx - i >= c->fmin[0]) TRY(omx - i, omy); } \
+        i = (start); \
+        if ((y_max) <= (c->fmax[1] - omy < omy - c->fmin[1] ? c->fmax[1] - omy : omy - c->fmin[1])) \
+            for (; i < (y_max) - 2; i += 4) X4(0, i, 0, -i, 0, i + 2, 0, -i - 2); \
+        for (; i < (y_max); i += 2) { if (omy + i <= c->fmax[1]) TRY(omx, omy + i); if (omy - i >= c->fmin[1]) TRY(omx, omy - i); } } while (0)
+        ucost1 = bcost;
+        DIA1(pmx, pmy);
+        if (pmx | pmy) DIA1(0, 0);
+        ucost2 = bcost;
+        if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) { int tx = bmx, ty = bmy; DIA1(tx, ty); }
+        if (bcost == ucost2) cross_start = 3;
+        omx = bmx; omy = bmy;
+        if (bcost == ucost2 && SAD_THRESH(2000)) {               /* early termination */
+            X4(0, -2, -1, -1, 1, -1, -2, 0);
+            X4(2, 0, -1, 1, 1, 1, 0, 2);
+            if (bcost == ucost1 && SAD_THRESH(500)) done = 1;
+            else if (bcost == ucost2) {
+                int range = (hex_range >> 1) | 1;
+                CROSS(3, range, range);
+                X4(-1, -2, 1, -2, -2, -1, 2, -1);
+                X4(-2, 1, 2, 1, -1, 2, 1, 2);
+                if (bcost == ucost2) done = 1;
+                else cross_start = range + 2;
+            }
+        }
+        if (!done) {
+            if (n_mvc) {                                         /* adaptive search range */
+                int mvd, denom = 1, sad_ctx, mvd_ctx;
+                if (n_mvc == 1) mvd = c->pix == X264HIP_PIXEL_16x16 ? 25 : abs(mvp[0] - mvc[0][0]) + abs(mvp[1] - mvc[0][1]);
+                else {
+                    denom = n_mvc - 1; mvd = 0;
+                    if (c->pix != X264HIP_PIXEL_16x16) { mvd = abs(mvp[0] - mvc[0][0]) + abs(mvp[1] - mvc[0][1]); denom++; }
+                    for (j = 0; j < n_mvc - 1; j++) mvd += abs(mvc[j][0] - mvc[j + 1][0]) + abs(mvc[j][1] - mvc[j + 1][1]);   /* x264_predictor_difference */
+                }
+                sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+                mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                hex_range = hex_range * range_mul[mvd_ctx][sad_ctx] / 4;
+            }
+            CROSS(cross_start, hex_range, hex_range / 2);
+            X4(-2, -2, -2, 2, 2, -2, 2, 2);
+            omx = bmx; omy = bmy;                                /* hexagon grid */
+            i = 1;
+            do {
+                int lim = c->fmax[0] - omx;
+                if (omx - c->fmin[0] < lim) lim = omx - c->fmin[0];
+                if (c->fmax[1] - omy < lim) lim = c->fmax[1] - omy;
+                if (omy - c->fmin[1] < lim) lim = omy - c->fmin[1];
+                if (4 * i > lim) {
+                    for (j = 0; j < 16; j++) { int mx = omx + hex4[j][0] * i, my = omy + hex4[j][1] * i; if (INRANGE(mx, my)) TRY(mx, my); }
+                } else
+                    for (j = 0; j < 16; j++) TRY(omx + hex4[j][0] * i, omy + hex4[j][1] * i);
+            } while (++i <= hex_range / 4);
+            if (bmy <= c->fmax[1]) do_hex = 1;
+        }
+#undef SAD_THRESH
+#undef X4
+#undef DIA1
+#undef CROSS
+    }
+    if (do_hex) {                                                /* hexagon, me.c:246-305 */
+        const int me_range_h = hex_range;
         int dir = -2, costs[6], ox, oy;
         static const int first[6][2] = {{-2,0},{-1,2},{1,2},{2,0},{1,-2},{-1,-2}};
         for (i = 0; i < 6; i++) costs[i] = me_fpel_cost(c, bmx + first[i][0], bmy + first[i][1]);
         for (i = 0; i < 6; i++) if (costs[i] < bcost) { bcost = costs[i]; dir = i; }
         if (dir != -2) {
             bmx += me_hex2[dir + 1][0]; bmy += me_hex2[dir + 1][1];
-            for (i = 1; i < me_range / 2 && INRANGE(bmx, bmy); i++) {
+            for (i = 1; i < me_range_h / 2 && INRANGE(bmx, bmy); i++) {
                 int odir = me_mod6m1[dir + 1], k;
                 for (k = 0; k < 3; k++) costs[k] = me_fpel_cost(c, bmx + me_hex2[odir + k][0], bmy + me_hex2[odir + k][1]);
                 dir = -2;

@@ -36,7 +36,7 @@ from x264_vs2008_amd import lib as L, synth  # noqa: E402
 from x264_vs2008_amd import slice as sl  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ME_HEX = 1
+ME_NAMES = {0: "dia", 1: "hex", 2: "umh"}
 
 
 def load_cqm():
@@ -45,7 +45,7 @@ def load_cqm():
 
 
 def analysis_options(args):
-    return dict(qp=args.qp, me_method=ME_HEX, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
+    return dict(qp=args.qp, me_method=args.me, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
                 chroma_me=1, cabac=1, deblock=1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8,
                 mixed_refs=args.mixed_refs)
 
@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--refs", type=int, default=3)
     ap.add_argument("--subme", type=int, default=5)
+    ap.add_argument("--me", type=int, default=1, help="param.analyse.i_me_method: 0 dia, 1 hex (the medium preset), 2 umh")
     ap.add_argument("--keyint", type=int, default=24)
     ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x13, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 | PSUB16x16 0x10 "
                     "(PSUB8x8 0x20 is not built)")
@@ -179,11 +180,11 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d I/P chains through the reference's per-macroblock loop on the GPU (cache_load, "
                                    "x264_macroblock_analyse, x264_macroblock_encode, cache_save, deblock, borders, half-pel planes): "
-                                   "hex ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; "
+                                   "%s ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; "
                                    "analyse.inter 0x%x intra 0x%x 8x8dct %d mixed-refs %d; macroblock types built so far: I_16x16 / "
                                    "I_8x8 / I_4x4 / P_L0 16x16, 16x8, 8x16 / P_8x8 / P_SKIP (the medium preset minus B-frames, RD "
                                    "(subme 7 -> 5) and trellis); entropy coding on the host, not timed"
-                                   % (args.width, args.height, args.subme, args.refs, args.qp, args.keyint, args.inter, args.intra, args.dct8,
+                                   % (args.width, args.height, ME_NAMES[args.me], args.subme, args.refs, args.qp, args.keyint, args.inter, args.intra, args.dct8,
                                       args.mixed_refs),
                        "frames_per_step": B, "i_frames_in_timed_steps": n_i,
                        "parallelism": "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); "

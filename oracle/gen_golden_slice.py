@@ -6,6 +6,7 @@ oracle/_ref/libx264ref.so, built from the sources where they lie).  Runs only wh
     python -m oracle.gen_golden_slice
 """
 import os
+import sys
 
 import numpy as np
 
@@ -27,6 +28,9 @@ CASES = [
     ("parts", (200, 120), 4, "static", dict(qp=30, subme=2, me_method=rs.ME_HEX, inter=0x10, n_refs=2)),
     ("medium_ip", (208, 144), 5, "static", dict(qp=26, subme=5, me_method=rs.ME_HEX, n_refs=3, inter=0x13, intra=0x3, transform8x8=1,
                                                   mixed_refs=1, cabac=1, deblock=1)),
+    ("umh", (208, 144), 4, "static", dict(qp=28, subme=5, me_method=rs.ME_UMH, n_refs=2, inter=0x13, intra=0x3, transform8x8=1,
+                                            mixed_refs=1, cabac=1, deblock=1)),
+    ("umh_fpel", (200, 120), 4, "moving", dict(qp=32, subme=1, me_method=rs.ME_UMH, me_range=24, inter=0x10, n_refs=2, deblock=1)),
 ]
 
 
@@ -58,7 +62,10 @@ def masked(a):
 
 
 def main():
+    only = sys.argv[1:]                      # optional: regenerate just the named chains
     for name, size, frames, kind, kw in CASES:
+        if only and name not in only:
+            continue
         p = rs.make_params(size[0], size[1], frames, **kw)
         y, u, v = case_inputs(size, frames, kind)
         a = masked(rs.run_reference(p, y, u, v))

@@ -95,12 +95,9 @@ __device__ __forceinline__ void sad_fpel4(const MxCtx &c, const int fx[4], const
     out[0] = __builtin_amdgcn_readlane(v, 0); out[1] = __builtin_amdgcn_readlane(v, 16); out[2] = __builtin_amdgcn_readlane(v, 32); out[3] = __builtin_amdgcn_readlane(v, 48);
 }
 // the same for eight candidates: 8 lanes each, two picture rows per lane
-__device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const int fy[8], int out[8])
+__device__ __forceinline__ void sad_fpel8_at(const MxCtx &c, int mx, int my, int out[8])     // (mx, my): this lane group's candidate
 {
-    const int g = c.lane >> 3, r = c.lane & 7;
-    int mx = fx[0], my = fy[0];
-#pragma unroll
-    for (int k = 1; k < 8; k++) if (g == k) { mx = fx[k]; my = fy[k]; }
+    const int r = c.lane & 7;
     u32 s = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -123,6 +120,14 @@ __device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const
     v = half_sum8(v);
 #pragma unroll
     for (int k = 0; k < 8; k++) out[k] = __builtin_amdgcn_readlane(v, 8 * k);
+}
+__device__ __forceinline__ void sad_fpel8(const MxCtx &c, const int fx[8], const int fy[8], int out[8])
+{
+    const int g = c.lane >> 3;
+    int mx = fx[0], my = fy[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) if (g == k) { mx = fx[k]; my = fy[k]; }
+    sad_fpel8_at(c, mx, my, out);
 }
 // SAD 16x16 of up to four quarter-pel candidates through get_ref's blend (mc.c:181-202)
 __device__ __forceinline__ void sad_qpel4(const MxCtx &c, const int qx[4], const int qy[4], int out[4])
@@ -283,6 +288,54 @@ __device__ __forceinline__ MeLimits me_limits(int mbx, int mby, int mb_w, int mb
 }
 struct MeOpts { int method, me_range, subme, chroma_me; };
 
+// X264_ME_UMH (me.c:306-447): the offsets of its fixed candidate groups, in the reference's evaluation order
+static __constant__ signed char c_umh_tab[40][2] = {
+    {0,-1},{0,1},{-1,0},{1,0},                                                   //  0: DIA1
+    {0,-2},{-1,-1},{1,-1},{-2,0},{2,0},{-1,1},{1,1},{0,2},                       //  4: early-termination ring, me.c:340-343
+    {-1,-2},{1,-2},{-2,-1},{2,-1},{-2,1},{2,1},{-1,2},{1,2},                     // 12: second ring, me.c:353-356
+    {-2,-2},{-2,2},{2,-2},{2,2},                                                 // 20: 5x5 corners, me.c:401
+    {-4,2},{-4,1},{-4,0},{-4,-1},{-4,-2},{4,-2},{4,-1},{4,0},{4,1},{4,2},{2,3},{0,4},{-2,3},{-2,-3},{0,-4},{2,-3}};   // 24: hex4, me.c:409-414
+static __constant__ int c_umh_range_mul[4][4] = {{3, 3, 4, 4}, {3, 4, 4, 4}, {4, 4, 4, 5}, {4, 4, 5, 6}};
+// One candidate stream of the UMH search around (omx, omy): CROSS(start, x_max, y_max) -- horizontal arm, then vertical arm,
+// each "+i then -i" for i = start, start+2, .. with the reference's one-sided range tests -- followed by `rings` scaled
+// copies of a c_umh_tab group (grid = the hexagon grid, whose points are range-tested).  Candidate n of the stream is a pure
+// function of n, so every 8-lane group computes its own; a trip scores eight, and the reference's in-order strict '<'
+// comparisons are replayed on the scores.
+__device__ __forceinline__ void umh_stream(const MxCtx &c, const MeLimits &L, int omx, int omy, int start, int x_max, int y_max,
+                                           int toff, int tlog, int rings, bool grid, int &bcost, int &bmx, int &bmy)
+{
+    const int nh = x_max > start ? ((x_max - start + 1) >> 1) * 2 : 0, nv = y_max > start ? ((y_max - start + 1) >> 1) * 2 : 0;
+    const int total = nh + nv + (rings << tlog);
+    const int g = c.lane >> 3;
+    for (int base = 0; base < total; base += 8) {
+        const int n = base + g;
+        int dx = 0, dy = 0;
+        bool ok = n < total;
+        if (n < nh) {
+            const int i = start + (n >> 1) * 2;
+            if (n & 1) { dx = -i; ok = ok && omx - i >= L.fmin0; } else { dx = i; ok = ok && omx + i <= L.fmax0; }
+        } else if (n < nh + nv) {
+            const int m = n - nh, i = start + (m >> 1) * 2;
+            if (m & 1) { dy = -i; ok = ok && omy - i >= L.fmin1; } else { dy = i; ok = ok && omy + i <= L.fmax1; }
+        } else if (ok) {
+            const int t = n - nh - nv, ring = (t >> tlog) + 1, e = toff + (t & ((1 << tlog) - 1));
+            dx = (int)c_umh_tab[e][0] * ring; dy = (int)c_umh_tab[e][1] * ring;
+            if (grid) ok = omx + dx >= L.fmin0 && omx + dx <= L.fmax0 && omy + dy >= L.fmin1 && omy + dy <= L.fmax1;
+        }
+        const int x = ok ? omx + dx : omx, y = ok ? omy + dy : omy;
+        int er[8];
+        sad_fpel8_at(c, x, y, er);
+        const unsigned long long okm = __ballot(ok);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((okm >> (8 * k)) & 1) {
+                const int xs = __builtin_amdgcn_readlane(x, 8 * k), ys = __builtin_amdgcn_readlane(y, 8 * k);
+                const int cost = er[k] + c.cost(xs << 2, ys << 2);
+                if (cost < bcost) { bcost = cost; bmx = xs; bmy = ys; }
+            }
+    }
+}
+
 // x264_me_search_ref for PIXEL_16x16.  c.mvpx / c.mvpy = the predictor (m->mvp).
 // Returns m->cost (without the reference cost); thresh = p_halfpel_thresh or nullptr.
 __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &o, const i16 *mvc, int n_mvc,
@@ -364,7 +417,69 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
             if (bmx == ox && bmy == oyy) break;
             if (!INRANGE(bmx, bmy)) break;
         } while (++i < o.me_range);
-    } else {
+    }
+    bool do_hex = o.method == 1;
+    int hex_range = o.me_range;
+    if (o.method == 2) {
+        // uneven-cross multi-hexagon, me.c:306-447.  A small state machine so that the candidate scorer is instantiated once.
+        const int shift = (c.bw == 8) + (c.bh == 8);                      // x264_pixel_size_shift of the block
+#define SAD_THRESH(v_) (bcost < ((v_) >> shift))
+        const int ucost1 = bcost;
+        int ucost2 = 0, cross_start = 1, omx = pmx, omy = pmy, ph = 0, et_range = 0;
+        while (ph < 7) {
+            int start = 0, x_max = 0, y_max = 0, toff = 0, tlog = 2, rings = 1;
+            bool grid = false, run = true;
+            switch (ph) {
+            case 0: omx = pmx; omy = pmy; break;                            // DIA1 around the rounded predictor
+            case 1: omx = 0; omy = 0; run = (pmx | pmy) != 0; break;        // ... and around (0,0)
+            case 2: run = (bmx | bmy) && ((bmx - pmx) | (bmy - pmy)); omx = bmx; omy = bmy; break;
+            case 3: toff = 4; tlog = 3; break;                              // early-termination ring
+            case 4: et_range = (hex_range >> 1) | 1; start = 3; x_max = y_max = et_range; toff = 12; tlog = 3; break;
+            case 5: start = cross_start; x_max = hex_range; y_max = hex_range >> 1; toff = 20; break;
+            default: omx = bmx; omy = bmy; toff = 24; tlog = 4; rings = hex_range / 4 > 1 ? hex_range / 4 : 1; grid = true; break;
+            }
+            if (run) umh_stream(c, L, omx, omy, start, x_max, y_max, toff, tlog, rings, grid, bcost, bmx, bmy);
+            switch (ph) {
+            case 0: ph = 1; break;
+            case 1: ucost2 = bcost; ph = 2; break;
+            case 2:
+                if (bcost == ucost2) cross_start = 3;
+                omx = bmx; omy = bmy;
+                ph = (bcost == ucost2 && SAD_THRESH(2000)) ? 3 : 5;
+                break;
+            case 3:
+                if (bcost == ucost1 && SAD_THRESH(500)) ph = 8;
+                else ph = bcost == ucost2 ? 4 : 5;
+                break;
+            case 4:
+                if (bcost == ucost2) ph = 8;
+                else { cross_start = et_range + 2; ph = 5; }
+                break;
+            case 5: ph = 6; break;
+            default: ph = 7; break;
+            }
+            if (ph == 5 && n_mvc) {
+                // adaptive search range from the spread of the candidates, me.c:363-397
+                int mvd, denom = 1;
+                const int whole = c.bw == 16 && c.bh == 16;
+#define MVC_(k_, d_) __builtin_amdgcn_readfirstlane((int)mvc[2 * (k_) + (d_)])
+                const int d0 = abs(mvpx - MVC_(0, 0)) + abs(mvpy - MVC_(0, 1));
+                if (n_mvc == 1) mvd = whole ? 25 : d0;
+                else {
+                    denom = n_mvc - 1; mvd = 0;
+                    if (!whole) { mvd = d0; denom++; }
+                    for (int j = 0; j < n_mvc - 1; j++) mvd += abs(MVC_(j, 0) - MVC_(j + 1, 0)) + abs(MVC_(j, 1) - MVC_(j + 1, 1));
+                }
+#undef MVC_
+                const int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+                const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                hex_range = hex_range * c_umh_range_mul[mvd_ctx][sad_ctx] / 4;
+            }
+        }
+#undef SAD_THRESH
+        if (ph == 7 && bmy <= L.fmax1) do_hex = true;
+    }
+    if (do_hex) {
         int dir = -2, ex[8], ey[8], er[8];
         // the first ring in one trip: (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2), me.c:254-262
         ex[0] = bmx - 2; ey[0] = bmy; ex[1] = bmx - 1; ey[1] = bmy + 2; ex[2] = bmx + 1; ey[2] = bmy + 2; ex[3] = bmx + 2; ey[3] = bmy;
@@ -374,7 +489,7 @@ __device__ int me_search_ref16(const MxCtx &c, const MeLimits &L, const MeOpts &
         for (int k = 0; k < 6; k++) { const int cost = er[k] + c.cost(ex[k] << 2, ey[k] << 2); if (cost < bcost) { bcost = cost; dir = k; } }
         if (dir != -2) {
             bmx += c_hex2[dir + 1][0]; bmy += c_hex2[dir + 1][1];
-            for (int i = 1; i < o.me_range / 2 && INRANGE(bmx, bmy); i++) {
+            for (int i = 1; i < hex_range / 2 && INRANGE(bmx, bmy); i++) {
                 const int odir = c_mod6m1[dir + 1];
 #pragma unroll
                 for (int k = 0; k < 3; k++) { cx[k] = bmx + c_hex2[odir + k][0]; cy[k] = bmy + c_hex2[odir + k][1]; }

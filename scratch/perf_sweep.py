@@ -17,6 +17,8 @@ W, H = 1920, 1080
 frames = [synth.frame(W, H, t) for t in range(5)]
 cfgs = {"uf": dict(qp=26, subme=0), "hex5r3": dict(qp=26, subme=5, me_method=1, n_refs=3, cabac=1, deblock=1),
         "hex2r1": dict(qp=26, subme=2, me_method=1, n_refs=1),
+        "bench": dict(qp=26, subme=5, me_method=1, n_refs=3, cabac=1, deblock=1, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1),
+        "p16": dict(qp=26, subme=5, me_method=1, n_refs=3, cabac=1, deblock=1, inter=0x3, intra=0x3, transform8x8=1),
         "med": dict(qp=26, subme=5, me_method=1, n_refs=3, cabac=1, deblock=1, inter=0x3, intra=0x3, transform8x8=1)}
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else list(cfgs)
 batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 8]

@@ -67,13 +67,13 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
 
     for (int r = 0; r < g.n_refs; r++) {     // the loop of x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1090-1127
         MxCtx c;
-        c.fe = s_fe[wave]; c.fe_u = s_fc[wave]; c.fe_v = s_fc[wave] + 64; c.sy = g.sy; c.sc = g.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
+        c.fe = (MX_LDS(u32))s_fe[wave]; c.fe_u = (MX_LDS(u8))s_fc[wave]; c.fe_v = (MX_LDS(u8))(s_fc[wave] + 64); c.sy = g.sy; c.sc = g.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + g.bs_y * bz + oy;
-        c.cu = refs.u[r] + g.bs_c * bz + oc; c.cv = refs.v[r] + g.bs_c * bz + oc;
+        for (int k = 0; k < 4; k++) c.pl[k] = (MX_GLB(u8))(refs.y[r][k] + g.bs_y * bz + oy);
+        c.cu = (MX_GLB(u8))(refs.u[r] + g.bs_c * bz + oc); c.cv = (MX_GLB(u8))(refs.v[r] + g.bs_c * bz + oc);
         const i16 *mvp = mvp_in + ((size_t)mb * g.n_refs + r) * 2;
         const int mvpx = mvp[0], mvpy = mvp[1];
-        c.cost_g = cost_mv + g.cost_center; c.cost_l = nullptr; c.mvpx = mvpx; c.mvpy = mvpy;
+        c.cost_g = (MX_GLB(i16))(cost_mv + g.cost_center); c.cost_l = (MX_LDS(i16))s_fe[wave]; c.has_cost_l = false; c.mvpx = mvpx; c.mvpy = mvpy;
         thresh -= g.ref_cost[r];
         int mvx, mvy, cost_mv_out;
         int mcost = me_search_ref16(c, L, o, mvc_in + ((size_t)mb * g.n_refs + r) * 16, n_mvc_in[(size_t)mb * g.n_refs + r],

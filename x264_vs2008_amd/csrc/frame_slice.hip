@@ -1159,8 +1159,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 // ---- x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1077-1143 ----
                 const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
                 MxCtx c;
-                c.fe = (const u32 *)s.fe; c.fe_u = s.fe + 256; c.fe_v = s.fe + 320; c.sy = a.sy; c.sc = a.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
-                c.cost_g = a.cost_mv + a.cost_center; c.cost_l = s.costl;
+                c.fe = (MX_LDS(u32))s.fe; c.fe_u = (MX_LDS(u8))(s.fe + 256); c.fe_v = (MX_LDS(u8))(s.fe + 320); c.sy = a.sy; c.sc = a.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
+                c.cost_g = (MX_GLB(i16))(a.cost_mv + a.cost_center); c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
                 for (int r = 0; r < a.n_refs; r++) {
@@ -1194,8 +1194,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         WAVE_SYNC();
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + by_ + oy;
-                    c.cu = refs.u[r] + bc_ + oc; c.cv = refs.v[r] + bc_ + oc;
+                    for (int k = 0; k < 4; k++) c.pl[k] = (MX_GLB(u8))(refs.y[r][k] + by_ + oy);
+                    c.cu = (MX_GLB(u8))(refs.u[r] + bc_ + oc); c.cv = (MX_GLB(u8))(refs.v[r] + bc_ + oc);
                     c.mvpx = mvpx; c.mvpy = mvpy;
                     thresh -= a.ref_cost[r];
                     int smx, smy, cost_mv;
@@ -1218,8 +1218,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     // point the search context at a block of reference r (LOAD_HPELS, analyse.c:1065-1072)
                     auto aim = [&](int r, int w, int h, int bx, int by) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) c.pl[k] = refs.y[r][k] + by_ + oy + (ptrdiff_t)by * a.sy + bx;
-                        c.cu = refs.u[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1); c.cv = refs.v[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1);
+                        for (int k = 0; k < 4; k++) c.pl[k] = (MX_GLB(u8))(refs.y[r][k] + by_ + oy + (ptrdiff_t)by * a.sy + bx);
+                        c.cu = (MX_GLB(u8))(refs.u[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1)); c.cv = (MX_GLB(u8))(refs.v[r] + bc_ + oc + (ptrdiff_t)(by >> 1) * a.sc + (bx >> 1));
                         c.set_block(w, h, bx, by);
                     };
                     // candidate records of the partition analysis (x264_me_t's mv / cost / cost_mv / i_ref / i_ref_cost / mvp):
@@ -1676,8 +1676,6 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
     switch (wpe) {
     case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
-    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
-    case 4: hipLaunchKernelGGL(k_slice_sweep<4>, grid, block, 0, c->stream, a, t); break;
     default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
     }
     if (is_p && a.flags_intra)

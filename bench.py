@@ -77,9 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="independent GOP chains advanced per step on each GPU "
-                    "(128 x 68 macroblock rows = 8704 row waves for 2048 wave slots at 2 waves/SIMD: later rows take the "
-                    "slots of finished ones, so a slot is rarely held by a wave that is still waiting for its first neighbour)")
+    ap.add_argument("--batch", type=int, default=240, help="independent GOP chains advanced per step on each GPU "
+                    "(240 x 68 macroblock rows = 16320 row waves for 2048 wave slots at 2 waves/SIMD: 8.5 slots per chain, so the "
+                    "68 rows of a frame go through in 8 full generations; later rows take the slots of finished ones)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=26)

@@ -86,6 +86,9 @@ struct SwLds {
     // when i_skip_intra is set (the partly encoded macroblock of the analysis is the final one, macroblock.c:527-577)
     signed char i4c[48];
     u8 e4[16], edge8[40];
+    __attribute__((aligned(4))) u8 pt4[48];   // the current 4x4 / 8x8 block's prediction table (intra_pred.h: RAW | F1 | F2 | DC..)
+    __attribute__((aligned(4))) u8 pt8[80];
+    u32 p4lut[48], p8lut[192];  // c_plut4 / c_plut8
     u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     i16 lv_y8[256];             // levels of the 8x8 transform (h->dct.luma8x8), separate from the 4x4 ones like the reference's
     i16 t8[256];                // 8x8 transform: intermediate between the two 1-D passes
@@ -692,39 +695,53 @@ __device__ __forceinline__ void sw_encode_i8x8(SwLds &s, const SwArgs &a, int id
     WAVE_SYNC();
     if (nz) { cbp_luma |= 1 << idx; sw_luma8x8_add(s, 0, a.qp, 1 << idx, lane); }
 }
-// x264_mb_encode_i4x4 for block idx (prediction already in s.fd): one lane, a 4x4 block is 16 coefficients
+// x264_mb_encode_i4x4 for block idx (prediction already in s.fd): one lane per coefficient (the four 16-lane rows of the
+// wave run the same block; only the first stores).  The 1-D transforms work on the four values of a quad (DPP
+// broadcasts); between the passes the 4x4 is transposed with one ds_bpermute, so after the forward pair lane i holds
+// dct[i] in the reference's (transposed) storage order and the quantiser rows / zigzag are indexed by the lane.
+__device__ __forceinline__ void sw_quad4(int v, int &v0, int &v1, int &v2, int &v3)
+{
+    v0 = __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false); v1 = __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);
+    v2 = __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false); v3 = __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int sw_fwd4_quad(int v, int k)        // dct.c:122-145, one 1-D pass: output k of this quad's four inputs
+{
+    int v0, v1, v2, v3;
+    sw_quad4(v, v0, v1, v2, v3);
+    const int s03 = v0 + v3, s12 = v1 + v2, d03 = v0 - v3, d12 = v1 - v2;
+    return (int)(i16)(k == 0 ? s03 + s12 : k == 1 ? 2 * d03 + d12 : k == 2 ? s03 - s12 : d03 - 2 * d12);
+}
+__device__ __forceinline__ int sw_inv4_quad(int v, int k, int last)   // dct.c:174-206
+{
+    int d0, d1, d2, d3;
+    sw_quad4(v, d0, d1, d2, d3);
+    const int e = d0 + d2, f = d0 - d2, g = d1 + (d3 >> 1), h = (d1 >> 1) - d3;
+    const int r = k == 0 ? e + g : k == 1 ? f + h : k == 2 ? f - h : e - g;
+    return (int)(i16)(last ? (r + 32) >> 6 : r);
+}
 __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
 {
     int bx, by;
     sw_blk_xy(idx, bx, by);
-    if (lane == 0) {
-        int r[16], res[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
-        i16 c[16], lv[16];
-        fwd4x4(c, r);
-        int nz = 0;
-        const int bits = a.qp / 6 - 4;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], s.qmf[0][i], s.qbias[0][i]); c[i] = (i16)q; nz |= q; }
-        s.nnz[idx] = (u8)(nz != 0);
-        if (nz) {
-            SCAN4_FRAME(lv, c);
-#pragma unroll
-            for (int i = 0; i < 16; i++) { s.lv_y[16 * idx + i] = lv[i]; c[i] = (i16)dequant_one(c[i], s.qdq[0][i], bits); }
-            inv4x4(res, c);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) { u8 *p = s.fd + FDY + (by + j) * FD + bx + i; *p = (u8)clip_u8((int)*p + res[4 * j + i]); }
-        }
-        s.keep8 = nz != 0;
+    const int l16 = lane & 15, x = l16 & 3, y = l16 >> 2, tl = (lane & 48) | (x << 2) | y;
+    int v = (int)s.fe[(by + y) * 16 + bx + x] - (int)s.fd[FDY + (by + y) * FD + bx + x];
+    v = sw_fwd4_quad(v, x);
+    v = __shfl(v, tl, 64);
+    v = sw_fwd4_quad(v, x);                                        // dct[l16]
+    const int q = quant_one(v, s.qmf[0][l16], s.qbias[0][l16]);
+    const int nz = (__ballot(q != 0) & 0xffffull) != 0;
+    if (lane == 0) s.nnz[idx] = (u8)nz;
+    if (nz) {
+        if (lane < 16) s.lv_y[16 * idx + (int)((0xFDC6EB75A8419320ull >> (4 * l16)) & 15)] = (i16)q;      // zigzag position of dct[l16]
+        int d = dequant_one(q, s.qdq[0][l16], a.qp / 6 - 4);
+        d = __shfl(d, tl, 64);                                     // lane (c = l16 >> 2, p = l16 & 3) holds dct[4p + c]
+        d = sw_inv4_quad(d, x, 0);                                 // ... now mid[l16]
+        d = __shfl(d, tl, 64);
+        d = sw_inv4_quad(d, x, 1);                                 // ... now the residual of pixel (row x, column y)
+        if (lane < 16) { u8 *p = s.fd + FDY + (by + x) * FD + bx + y; *p = (u8)clip_u8((int)*p + d); }
+        cbp_luma |= 1 << (idx >> 2);
     }
     WAVE_SYNC();
-    if (__builtin_amdgcn_readfirstlane(s.keep8)) cbp_luma |= 1 << (idx >> 2);
 }
 
 // ---- intra 4x4 / 8x8 analysis helpers ------------------------------------------------------------
@@ -812,6 +829,82 @@ __device__ __forceinline__ int sw_sa8d_rows(const u8 *f, const u8 *p, int lane)
     return half_sum8((int)((acc & 0xffffu) + (acc >> 16)));
 }
 
+// the 4x4 block's prediction table (intra_pred.h) from the pixels around dst (stride FD): 13 edge samples, their two- and
+// three-tap filtered forms, the three DC values and 128
+__device__ __forceinline__ void sw_pred4_table(SwLds &s, const u8 *dst, int lane)
+{
+    const int k = lane < 13 ? lane : 12;
+    const int e = (int)(k < 4 ? dst[-1 + (3 - k) * FD] : k == 4 ? dst[-1 - FD] : dst[(k - 5) - FD]);
+    int prev = dpp_mov<0x111>(e), next = dpp_mov<0x101>(e);      // row_shr:1 / row_shl:1: lanes k - 1 / k + 1
+    if (lane == 0) prev = e;
+    if (lane >= 12) next = e;
+    if (lane < 13) { s.pt4[lane] = (u8)e; s.pt4[13 + lane] = (u8)((e + next + 1) >> 1); s.pt4[26 + lane] = (u8)((prev + 2 * e + next + 2) >> 2); }
+    int dv = 0;
+    if (lane >= 16 && lane < 20) dv = dst[(lane - 16) - FD];
+    else if (lane >= 20 && lane < 24) dv = dst[-1 + (lane - 20) * FD];
+    dv = quad_sum4(dv);
+    const int t = __builtin_amdgcn_readlane(dv, 16), l = __builtin_amdgcn_readlane(dv, 20);
+    if (lane >= 24 && lane < 28) s.pt4[39 + lane - 24] = (u8)(lane == 24 ? (t + l + 4) >> 3 : lane == 25 ? (l + 2) >> 2 : lane == 26 ? (t + 2) >> 2 : 128);
+}
+// x264_predict_8x8_filter with every filter on (R/common/predict.c:499-540): one lane per edge entry 7..32
+__device__ __forceinline__ void sw_pred8_filter_all(u8 *edge, const u8 *src, int neigh, int lane)
+{
+#define PX(xx, yy) ((int)src[(xx) + (yy) * FD])
+    const int have_tl = neigh & NB_TOPLEFT, have_tr = neigh & NB_TOPRIGHT;
+    if (lane < 26) {
+        const int i = 7 + lane;
+        int av, bv, cv;
+        if (i < 15) {                                    // left y = 14 - i
+            const int y = 14 - i;
+            av = y == 0 ? (have_tl ? PX(-1, -1) : PX(-1, 0)) : PX(-1, y - 1); bv = PX(-1, y); cv = y == 7 ? PX(-1, 7) : PX(-1, y + 1);
+        } else if (i == 15) { av = PX(0, -1); bv = PX(-1, -1); cv = PX(-1, 0); }
+        else if (i < 24) {                               // top x = i - 16
+            const int x = i - 16;
+            av = x == 0 ? (have_tl ? PX(-1, -1) : PX(0, -1)) : PX(x - 1, -1); bv = PX(x, -1); cv = x == 7 ? (have_tr ? PX(8, -1) : PX(7, -1)) : PX(x + 1, -1);
+        } else if (have_tr) {                            // top right x = 8 .. 15, edge[32] = edge[31]
+            const int x = i < 32 ? i - 16 : 15;
+            av = PX(x - 1, -1); bv = PX(x, -1); cv = x == 15 ? PX(15, -1) : PX(x + 1, -1);
+        } else av = bv = cv = PX(7, -1);
+        edge[i] = (u8)((av + 2 * bv + cv + 2) >> 2);
+    }
+#undef PX
+}
+// the 8x8 block's prediction table from the filtered edge array (e[j] = edge[7 + j], j = 0..24)
+__device__ __forceinline__ void sw_pred8_table(SwLds &s, int lane)
+{
+    if (lane < 25) {
+        const int e = s.edge8[7 + lane], prev = lane == 0 ? e : (int)s.edge8[6 + lane], next = lane == 24 ? e : (int)s.edge8[8 + lane];
+        s.pt8[lane] = (u8)e; s.pt8[25 + lane] = (u8)((e + next + 1) >> 1); s.pt8[50 + lane] = (u8)((prev + 2 * e + next + 2) >> 2);
+    }
+    int dv = 0;
+    if (lane >= 32 && lane < 40) dv = s.edge8[16 + lane - 32];
+    else if (lane >= 40 && lane < 48) dv = s.edge8[7 + lane - 40];
+    dv = half_sum8(dv);
+    const int t = __builtin_amdgcn_readlane(dv, 32), l = __builtin_amdgcn_readlane(dv, 40);
+    if (lane >= 48 && lane < 52) s.pt8[75 + lane - 48] = (u8)(lane == 48 ? (l + t + 8) >> 4 : lane == 49 ? (l + 4) >> 3 : lane == 50 ? (t + 4) >> 3 : 128);
+}
+// unnormalised 8x8 Hadamard SATD from one row of differences per lane (rows in 8 consecutive lanes); pixel.c:256-289
+__device__ __forceinline__ int sw_sa8d_rows_d(const int d[8], int lane)
+{
+    u32 e[4], t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = (u32)(d[2 * k] + d[2 * k + 1]) + ((u32)(d[2 * k] - d[2 * k + 1]) << 16);
+    wht4(t[0], t[1], t[2], t[3], e[0], e[1], e[2], e[3]);
+    u32 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 v = t[k], o = (u32)dpp_mov<DPP_XOR1>((int)v);
+        v = (lane & 1) ? o - v : v + o;
+        o = (u32)dpp_mov<DPP_XOR2>((int)v);
+        v = (lane & 2) ? o - v : v + o;
+        const u32 up = (u32)dpp_mov<0x104>((int)v), dn = (u32)dpp_mov<0x114>((int)v);     // row_shl:4 / row_shr:4: lanes + 4 / - 4 (both run in all lanes)
+        o = (lane & 4) ? dn : up;                                                          // = lane ^ 4
+        v = (lane & 4) ? o - v : v + o;
+        acc += lanes_abs(v);
+    }
+    return half_sum8((int)((acc & 0xffffu) + (acc >> 16)));
+}
+
 __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // WPE = waves per SIMD the register allocation is held to.  A row wave spends most of its time waiting
@@ -841,6 +934,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
         if (is_p)
             for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = a.cost_mv[a.cost_center - MX_COST_LDS + k];
+        if (lane < 48) s.p4lut[lane] = ((const u32 *)&c_plut4)[lane];
+        for (int k = lane; k < 192; k += 64) s.p8lut[k] = ((const u32 *)&c_plut8)[k];
         if (a.transform8x8)
             for (int c8 = 0; c8 < 2; c8++) {
                 s.q8mf[c8][lane] = a.q8mf[(c8 * 52 + a.qp) * 64 + lane]; s.q8bias[c8][lane] = a.q8bias[(c8 * 52 + a.qp) * 64 + lane];
@@ -992,44 +1087,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     const int bx = 8 * (idx & 1), by = 8 * (idx >> 1), pm = sw_pred_i4mode(s, 4 * idx), nb8 = sw_nb8(idx, nb);
                     int n;
                     const unsigned long long list = sw_modes4(nb8, n);
-                    if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + by * FD + bx, FD, nb8, 0xf);
+                    sw_pred8_filter_all(s.edge8, s.fd + FDY + by * FD + bx, nb8, lane);
                     WAVE_SYNC();
-                    int best = MX_COST_MAX, bmode = 0;
+                    sw_pred8_table(s, lane);
+                    WAVE_SYNC();
+                    u32 kb = 0xffffffffu;
 #pragma unroll
                     for (int pass = 0; pass < 2; pass++) {
                         const int g = (lane >> 3) + 8 * pass, r = lane & 7;
-                        int c = 0;
+                        u32 key = 0xffffffffu;
                         if (g < n) {
                             const int mode = (int)((list >> (4 * g)) & 15);
-                            u8 pr[8];
+                            const u32 o0 = s.p8lut[(mode * 8 + r) * 2], o1 = s.p8lut[(mode * 8 + r) * 2 + 1];
+                            const u32 f0 = *(const u32 *)(s.fe + (by + r) * 16 + bx), f1 = *(const u32 *)(s.fe + (by + r) * 16 + bx + 4);
+                            int d[8];
 #pragma unroll
-                            for (int x = 0; x < 8; x++) pr[x] = (u8)pred8_px(mode, s.edge8, x, r);
-                            const u8 *f = s.fe + (by + r) * 16 + bx;
-                            if (satd) c = sw_sa8d_rows(f, pr, lane);
+                            for (int x = 0; x < 4; x++) {
+                                d[x] = (int)((f0 >> (8 * x)) & 255) - (int)s.pt8[(o0 >> (8 * x)) & 255];
+                                d[4 + x] = (int)((f1 >> (8 * x)) & 255) - (int)s.pt8[(o1 >> (8 * x)) & 255];
+                            }
+                            int c;
+                            if (satd) c = (sw_sa8d_rows_d(d, lane) + 2) >> 2;
                             else {
                                 int sd = 0;
 #pragma unroll
-                                for (int x = 0; x < 8; x++) sd += iabs((int)f[x] - (int)pr[x]);
+                                for (int x = 0; x < 8; x++) sd += iabs(d[x]);
                                 c = half_sum8(sd);
                             }
+                            key = ((u32)(c + a.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
                         }
+                        // the reference's in-order strict '<' over the modes = the smallest (cost, slot) key
 #pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const int slot = k + 8 * pass;
-                            if (slot < n) {
-                                const int mode = (int)((list >> (4 * slot)) & 15);
-                                int ck = __builtin_amdgcn_readlane(c, 8 * k);
-                                if (satd) ck = (ck + 2) >> 2;
-                                ck += a.lambda * (pm == sw_fix4(mode) ? 1 : 4);
-                                if (ck < best) { best = ck; bmode = mode; }
-                            }
-                        }
+                        for (int k = 0; k < 8; k++) { const u32 t = (u32)__builtin_amdgcn_readlane((int)key, 8 * k); kb = t < kb ? t : kb; }
                     }
+                    const int best = (int)(kb >> 4), bmode = (int)((list >> (4 * (kb & 15))) & 15);
                     cost += best;
                     if (lane == 0) s.pred8[idx] = (signed char)bmode;
                     if (idx == 3 || cost > thresh) break;
                     {
-                        const int v = pred8_px(bmode, s.edge8, lane & 7, lane >> 3);
+                        const int v = s.pt8[(s.p8lut[(bmode * 8 + (lane >> 3)) * 2 + ((lane >> 2) & 1)] >> (8 * (lane & 3))) & 255];
                         WAVE_SYNC();
                         s.fd[FDY + (by + (lane >> 3)) * FD + bx + (lane & 7)] = (u8)v;
                         if (lane < 4) s.i4c[sw_scan8(4 * idx) + (lane & 1) + 8 * (lane >> 1)] = (signed char)bmode;
@@ -1059,31 +1155,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     u8 *dst = s.fd + FDY + by * FD + bx;
                     if ((nb4 & (NB_TOPRIGHT | NB_TOP)) == NB_TOP && lane < 4) dst[4 - FD + lane] = dst[3 - FD];    // emulate missing topright samples
                     WAVE_SYNC();
-                    if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
+                    sw_pred4_table(s, dst, lane);
                     WAVE_SYNC();
-                    int c = 0;
+                    u32 key = 0xffffffffu;
                     {
                         const int g = lane >> 2, r = lane & 3;
                         if (g < n) {
                             const int mode = (int)((list >> (4 * g)) & 15);
-                            const u8 *f = s.fe + (by + r) * 16 + bx;
-                            const int d0 = (int)f[0] - pred4_px(mode, s.e4, 0, r), d1 = (int)f[1] - pred4_px(mode, s.e4, 1, r);
-                            const int d2 = (int)f[2] - pred4_px(mode, s.e4, 2, r), d3 = (int)f[3] - pred4_px(mode, s.e4, 3, r);
-                            c = sw_cost4x4_rows(d0, d1, d2, d3, satd, lane);
+                            const u32 off = s.p4lut[mode * 4 + r], fw = *(const u32 *)(s.fe + (by + r) * 16 + bx);
+                            const int d0 = (int)(fw & 255) - (int)s.pt4[off & 255], d1 = (int)((fw >> 8) & 255) - (int)s.pt4[(off >> 8) & 255];
+                            const int d2 = (int)((fw >> 16) & 255) - (int)s.pt4[(off >> 16) & 255], d3 = (int)(fw >> 24) - (int)s.pt4[off >> 24];
+                            const int c = sw_cost4x4_rows(d0, d1, d2, d3, satd, lane);
+                            key = ((u32)(c + a.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
                         }
                     }
-                    int best = MX_COST_MAX, bmode = 0;
+                    u32 kb = (u32)__builtin_amdgcn_readlane((int)key, 0);
 #pragma unroll
-                    for (int k = 0; k < 9; k++)
-                        if (k < n) {
-                            const int mode = (int)((list >> (4 * k)) & 15);
-                            const int ck = __builtin_amdgcn_readlane(c, 4 * k) + a.lambda * (pm == sw_fix4(mode) ? 1 : 4);
-                            if (ck < best) { best = ck; bmode = mode; }
-                        }
+                    for (int k = 1; k < 9; k++) { const u32 t = (u32)__builtin_amdgcn_readlane((int)key, 4 * k); kb = t < kb ? t : kb; }
+                    const int best = (int)(kb >> 4), bmode = (int)((list >> (4 * (kb & 15))) & 15);
                     cost += best;
                     if (lane == 0) s.pred4[idx] = (signed char)bmode;
                     if (cost > thresh || idx == 15) break;
-                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)pred4_px(bmode, s.e4, lane & 3, lane >> 2);
+                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = s.pt4[(s.p4lut[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
                     if (lane == 0) s.i4c[sw_scan8(idx)] = (signed char)bmode;
                     WAVE_SYNC();
                     sw_encode_i4x4(s, a, idx, acbp, lane);

@@ -165,3 +165,76 @@ __device__ __forceinline__ void pred8_filter(u8 *edge, const u8 *s, int ls, int 
     }
 #undef PX
 }
+
+// ---- table-driven 4x4 / 8x8 prediction ---------------------------------------------------------
+// Every pixel of every 4x4 / 8x8 mode is one entry of a small per-block table built from the edge array
+// e[0..3n] (e[n-1-k] = left k, e[n] = top-left, e[n+1+k] = top k):
+//   RAW[j] = e[j];  F1[j] = (e[j] + e[j+1] + 1) >> 1;  F2[j] = (e[j-1] + 2 e[j] + e[j+1] + 2) >> 2 (ends repeated),
+// followed by DC, DC_LEFT, DC_TOP and 128.  Which entry pixel (x, y) of a mode reads is a compile-time
+// function (pt_off below restates dir_pred_px's index arithmetic), tabulated one byte per pixel, so a lane
+// predicts a row with one LUT read and n byte reads whatever its mode -- no divergent mode switch.
+constexpr int pt_entries(int n) { return 3 * n + 1; }
+constexpr int pt_size(int n) { return 3 * pt_entries(n) + 4; }
+constexpr int pt_off(int n, int mode, int x, int y)
+{
+    const int E = pt_entries(n), F1 = E, F2 = 2 * E, DC = 3 * E;
+    switch (mode) {
+    case 0: return n + 1 + x;
+    case 1: return n - 1 - y;
+    case 2: return DC;
+    case 9: return DC + 1;
+    case 10: return DC + 2;
+    case 11: return DC + 3;
+    case 3: return F2 + n + 2 + x + y;
+    case 4: return F2 + n + x - y;
+    case 5: {
+        const int z = 2 * x - y, i = x - (y >> 1);
+        if (z >= 0) return (z & 1) ? F2 + n + i : F1 + n + i;
+        if (z == -1) return F2 + n;
+        return F2 + n + 1 - y + 2 * x;
+    }
+    case 6: {
+        const int z = 2 * y - x, i = y - (x >> 1);
+        if (z >= 0) return (z & 1) ? F2 + n - i : F1 + n - i - 1;
+        if (z == -1) return F2 + n;
+        return F2 + n - 1 + x - 2 * y;
+    }
+    case 7: {
+        const int i = x + (y >> 1);
+        return (y & 1) ? F2 + n + 2 + i : F1 + n + 1 + i;
+    }
+    default: {
+        const int z = x + 2 * y, last = 2 * n - 3, i = y + (x >> 1);
+        if (z > last) return 0;
+        if (z == last) return F2;
+        return (z & 1) ? F2 + n - 2 - i : F1 + n - 2 - i;
+    }
+    }
+}
+struct PLut4 { u32 v[12][4]; };          // [mode][row]: four byte offsets
+struct PLut8 { u32 v[12][8][2]; };       // [mode][row][half]: eight byte offsets
+constexpr PLut4 make_plut4()
+{
+    PLut4 t{};
+    for (int m = 0; m < 12; m++)
+        for (int y = 0; y < 4; y++) {
+            u32 w = 0;
+            for (int x = 0; x < 4; x++) w |= (u32)pt_off(4, m, x, y) << (8 * x);
+            t.v[m][y] = w;
+        }
+    return t;
+}
+constexpr PLut8 make_plut8()
+{
+    PLut8 t{};
+    for (int m = 0; m < 12; m++)
+        for (int y = 0; y < 8; y++)
+            for (int h = 0; h < 2; h++) {
+                u32 w = 0;
+                for (int x = 0; x < 4; x++) w |= (u32)pt_off(8, m, 4 * h + x, y) << (8 * x);
+                t.v[m][y][h] = w;
+            }
+    return t;
+}
+static __constant__ PLut4 c_plut4 = make_plut4();
+static __constant__ PLut8 c_plut8 = make_plut8();

@@ -223,10 +223,34 @@ __device__ __forceinline__ int blk8x4_cost(const u32 f[4][2], const u32 p[4][2],
     return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
 }
 
+// Pixel x of a row's left half and pixel x of its right half side by side in 16-bit lanes (x264's SATD layout, pixel.c:175-181):
+// pair x of the eight pixels held in (w0 = px 0..3, w1 = px 4..7) = w0.byte[x] | w1.byte[x] << 16, one v_perm_b32
+__device__ __forceinline__ u32 mx_pair(u32 w1, u32 w0, int x) { return __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (u32)x | ((u32)(4 + x) << 16)); }
+// SATD of an 8x4 block from the packed differences d[y][x] = F - P (plain 32-bit subtraction of the pairs), pixel.c:214-233
+__device__ __forceinline__ int satd8x4_packed(const u32 d[4][4])
+{
+    u32 t[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) wht4(t[y][0], t[y][1], t[y][2], t[y][3], d[y][0], d[y][1], d[y][2], d[y][3]);
+    u32 acc = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        u32 v0, v1, v2, v3;
+        wht4(v0, v1, v2, v3, t[0][x], t[1][x], t[2][x], t[3][x]);
+        acc += lanes_abs(v0) + lanes_abs(v1) + lanes_abs(v2) + lanes_abs(v3);
+    }
+    return (int)(((acc & 0xffffu) + (acc >> 16)) >> 1);
+}
+typedef unsigned short mx_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mx_u16x2 mx_as_pk(u32 v) { return __builtin_bit_cast(mx_u16x2, v); }
+__device__ __forceinline__ u32 mx_as_u32(mx_u16x2 v) { return __builtin_bit_cast(u32, v); }
+
 // COST_MV_SATD's sum (me.c:654-677) for this lane group's quarter-pel candidate, 16 lanes per candidate:
 // mbcmp_unaligned[block] of the get_ref prediction + (chroma) mbcmp[chroma block] of mc_chroma for U and V.
 // Lane j of the group = one unit: 0-7 luma 8x4 blocks, 8-9 U, 10-11 V, each halved on its own as the
 // reference's composites do (pixel.c:235-253); the units add up to the whole sum.
+// With SATD the pixels go straight into the packed pair layout (v_perm_b32), mc_chroma's bilinear blend runs on
+// pairs (v_pk_mul / v_pk_mad: every term stays below 2^16) and a difference is one 32-bit subtraction.
 __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my, int satd, int chroma)
 {
     const int j = c.lane & 15;
@@ -249,7 +273,15 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
             }
             f[y][0] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2) + 1];
         }
-        v = blk8x4_cost(f, p, satd);
+        if (satd) {
+            u32 d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[y][x] = mx_pair(f[y][1], f[y][0], x) - mx_pair(p[y][1], p[y][0], x);
+            v = satd8x4_packed(d);
+        } else
+            v = blk8x4_cost(f, p, 0);
     } else if (chroma && j >= 8 && j < 12 && ((j - 8) & 1) < n_cunits) {
         // mbcmp[i_pixel + 3]: 8x8 / 8x4 chroma blocks are 8x4 units, 4x8 / 4x4 ones are 4x4 units
         const int by = ((j - 8) & 1) * 4, wide = c.bw == 16;
@@ -260,22 +292,48 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
         u32 r0[5], r1[5], r2[5];
 #pragma unroll
         for (int y = 0; y < 5; y++) load9u(s + (ptrdiff_t)y * c.sc, r0[y], r1[y], r2[y]);
-        u32 f[4][2], p[4][2];
+        if (satd) {
+            // pair x of a row = (px x, px x + 4); the row moved one sample right is pairs 1..3 and (px 4, px 8)
+            u32 a[5][5];
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            u32 w0 = 0, w1 = 0;
+            for (int y = 0; y < 5; y++) {
 #pragma unroll
-            for (int x = 0; x < 8; x++) {
-                const int a0 = x < 4 ? byte_of(r0[y], x) : byte_of(r1[y], x - 4), a1 = x < 3 ? byte_of(r0[y], x + 1) : x < 7 ? byte_of(r1[y], x - 3) : byte_of(r2[y], 0);
-                const int b0 = x < 4 ? byte_of(r0[y + 1], x) : byte_of(r1[y + 1], x - 4), b1 = x < 3 ? byte_of(r0[y + 1], x + 1) : x < 7 ? byte_of(r1[y + 1], x - 3) : byte_of(r2[y + 1], 0);
-                const u32 px = (u32)((ca * a0 + cb * a1 + cc * b0 + cd * b1 + 32) >> 6);
-                if (x < 4) w0 |= px << (8 * x); else w1 |= px << (8 * (x - 4));
+                for (int x = 0; x < 4; x++) a[y][x] = mx_pair(r1[y], r0[y], x);
+                a[y][4] = mx_pair(r2[y], r1[y], 0);
             }
-            MX_LDS(u32) fr = (MX_LDS(u32))(fe + (by + y) * 8);
-            p[y][0] = w0; f[y][0] = fr[0];
-            p[y][1] = wide ? w1 : 0u; f[y][1] = wide ? fr[1] : 0u;      // a 4-wide unit: the right half contributes nothing
+            const mx_u16x2 ka = {(unsigned short)ca, (unsigned short)ca}, kb = {(unsigned short)cb, (unsigned short)cb};
+            const mx_u16x2 kc = {(unsigned short)cc, (unsigned short)cc}, kd = {(unsigned short)cd, (unsigned short)cd}, k32 = {32, 32};
+            const u32 keep = wide ? 0xffffffffu : 0x0000ffffu;      // a 4-wide unit: the right half contributes nothing
+            u32 d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                MX_LDS(u32) fr = (MX_LDS(u32))(fe + (by + y) * 8);
+                const u32 f0 = fr[0], f1 = fr[1];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const mx_u16x2 pv = (mx_as_pk(a[y][x]) * ka + mx_as_pk(a[y][x + 1]) * kb + mx_as_pk(a[y + 1][x]) * kc + mx_as_pk(a[y + 1][x + 1]) * kd + k32) >> 6;
+                    d[y][x] = (mx_pair(f1, f0, x) & keep) - (mx_as_u32(pv) & keep);
+                }
+            }
+            v = satd8x4_packed(d);
+        } else {
+            u32 f[4][2], p[4][2];
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                u32 w0 = 0, w1 = 0;
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    const int a0 = x < 4 ? byte_of(r0[y], x) : byte_of(r1[y], x - 4), a1 = x < 3 ? byte_of(r0[y], x + 1) : x < 7 ? byte_of(r1[y], x - 3) : byte_of(r2[y], 0);
+                    const int b0 = x < 4 ? byte_of(r0[y + 1], x) : byte_of(r1[y + 1], x - 4), b1 = x < 3 ? byte_of(r0[y + 1], x + 1) : x < 7 ? byte_of(r1[y + 1], x - 3) : byte_of(r2[y + 1], 0);
+                    const u32 px = (u32)((ca * a0 + cb * a1 + cc * b0 + cd * b1 + 32) >> 6);
+                    if (x < 4) w0 |= px << (8 * x); else w1 |= px << (8 * (x - 4));
+                }
+                MX_LDS(u32) fr = (MX_LDS(u32))(fe + (by + y) * 8);
+                p[y][0] = w0; f[y][0] = fr[0];
+                p[y][1] = wide ? w1 : 0u; f[y][1] = wide ? fr[1] : 0u;
+            }
+            v = blk8x4_cost(f, p, 0);
         }
-        v = blk8x4_cost(f, p, satd);
     }
     return row_sum16(v);
 }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
         c.cu = (MX_GLB(u8))(refs.u[r] + g.bs_c * bz + oc); c.cv = (MX_GLB(u8))(refs.v[r] + g.bs_c * bz + oc);
         const i16 *mvp = mvp_in + ((size_t)mb * g.n_refs + r) * 2;
         const int mvpx = mvp[0], mvpy = mvp[1];
-        c.cost_g = (MX_GLB(i16))(cost_mv + g.cost_center); c.cost_l = (MX_LDS(i16))s_fe[wave]; c.has_cost_l = false; c.mvpx = mvpx; c.mvpy = mvpy;
+        c.cost_g = (MX_GLB(i16))(cost_mv + g.cost_center); c.cost_l = (MX_LDS(i16))s_fe[wave]; c.has_cost_l = false; c.patch = (MX_LDS(u8))s_fe[wave]; c.has_patch = false; c.patch_on = false; c.mvpx = mvpx; c.mvpy = mvpy;
         thresh -= g.ref_cost[r];
         int mvx, mvy, cost_mv_out;
         int mcost = me_search_ref16(c, L, o, mvc_in + ((size_t)mb * g.n_refs + r) * 16, n_mvc_in[(size_t)mb * g.n_refs + r],

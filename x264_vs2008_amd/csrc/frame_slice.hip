@@ -89,6 +89,7 @@ struct SwLds {
     __attribute__((aligned(4))) u8 pt4[48];   // the current 4x4 / 8x8 block's prediction table (intra_pred.h: RAW | F1 | F2 | DC..)
     __attribute__((aligned(4))) u8 pt8[80];
     u32 p4lut[48], p8lut[192];  // c_plut4 / c_plut8
+    __attribute__((aligned(16))) u8 patch[MX_PATCH_BYTES];   // the motion search's staged sub-pel neighbourhood (me_exact.h)
     u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     i16 lv_y8[256];             // levels of the 8x8 transform (h->dct.luma8x8), separate from the 4x4 ones like the reference's
     i16 t8[256];                // 8x8 transform: intermediate between the two 1-D passes
@@ -1253,7 +1254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
                 MxCtx c;
                 c.fe = (MX_LDS(u32))s.fe; c.fe_u = (MX_LDS(u8))(s.fe + 256); c.fe_v = (MX_LDS(u8))(s.fe + 320); c.sy = a.sy; c.sc = a.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
-                c.cost_g = (MX_GLB(i16))(a.cost_mv + a.cost_center); c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true;
+                c.cost_g = (MX_GLB(i16))(a.cost_mv + a.cost_center); c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true; c.patch = (MX_LDS(u8))s.patch; c.has_patch = true; c.patch_on = false;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
                 for (int r = 0; r < a.n_refs; r++) {

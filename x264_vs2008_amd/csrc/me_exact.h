@@ -77,6 +77,11 @@ struct MxCtx {
     MX_GLB(i16) cost_g;       // p_cost_mv, centred (global memory)
     MX_LDS(i16) cost_l;       // LDS copy of cost_g[-MX_COST_LDS .. MX_COST_LDS] (only read when has_cost_l)
     bool has_cost_l;
+    // optional LDS staging of the sub-pel neighbourhood (mx_load_patch): the four half-pel planes and both chroma planes
+    // around the refinement's start, so that its rounds read LDS instead of issuing dozens of scattered global loads each
+    MX_LDS(u8) patch;
+    bool has_patch, patch_on;
+    int px0, py0, cx0, cy0;   // top-left sample of the luma / chroma patch relative to the block's position
     int mvpx, mvpy;           // the predictor the costs are relative to
     int sy, sc, lane;
     // the block searched: 16x16, 16x8, 8x16 or 8x8 at (bx, by) inside the macroblock.  pl / cu / cv point at the block
@@ -99,6 +104,80 @@ struct MxCtx {
         return (int)cost_g[dx] + (int)cost_g[dy];
     }
 };
+
+// ---- LDS staging of the sub-pel neighbourhood ----------------------------------------------------
+#define MX_PS 28                       // luma patch row stride: bw + 5 samples wanted, dword reads may run 3 further
+#define MX_PROWS 21                    // bh + 5 rows
+#define MX_PPL (MX_PS * MX_PROWS)      // one luma plane
+#define MX_CS 16                       // chroma patch: bw/2 + 3 samples, bh/2 + 3 rows
+#define MX_CROWS 11
+#define MX_PATCH_BYTES (4 * MX_PPL + 2 * MX_CS * MX_CROWS + 16)
+// 16 / 8(+1) consecutive bytes at an arbitrary LDS address (aligned dword reads + v_alignbyte)
+__device__ __forceinline__ void lds16u(MX_LDS(u8) p, u32 o[4])
+{
+    const u32 a = (u32)(uintptr_t)p, s = a & 3;
+    MX_LDS(u32) q = (MX_LDS(u32))(uintptr_t)(a - s);
+    const u32 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+    o[0] = __builtin_amdgcn_alignbyte(w1, w0, s); o[1] = __builtin_amdgcn_alignbyte(w2, w1, s);
+    o[2] = __builtin_amdgcn_alignbyte(w3, w2, s); o[3] = __builtin_amdgcn_alignbyte(w4, w3, s);
+}
+__device__ __forceinline__ void lds9u(MX_LDS(u8) p, u32 &o0, u32 &o1, u32 &o2)
+{
+    const u32 a = (u32)(uintptr_t)p, s = a & 3;
+    MX_LDS(u32) q = (MX_LDS(u32))(uintptr_t)(a - s);
+    const u32 w0 = q[0], w1 = q[1], w2 = q[2];
+    o0 = __builtin_amdgcn_alignbyte(w1, w0, s); o1 = __builtin_amdgcn_alignbyte(w2, w1, s); o2 = __builtin_amdgcn_alignbyte(0u, w2, s);
+}
+// Stage what refine_subpel can reach from its start (qx, qy): +-6 quarter-pels, i.e. full-pel columns (qx >> 2) - 2 ..
+// (qx >> 2) + bw + 2 of each of the four planes (bw + 5 samples, bh + 5 rows) and the chroma samples (qx >> 3) - 1 ..
+// + bw/2 + 1 (bw/2 + 3 samples, bh/2 + 3 rows).  Lane = one row: 84 luma rows in two passes, the 22 chroma rows ride in
+// the second.  Only the samples the rounds can read are loaded (the same ones the global path would touch).
+__device__ __forceinline__ void mx_load_patch(MxCtx &c, int qx, int qy)
+{
+    typedef __attribute__((address_space(3))) u32 *lds_w;
+    c.px0 = (qx >> 2) - 2; c.py0 = (qy >> 2) - 2; c.cx0 = (qx >> 3) - 1; c.cy0 = (qy >> 3) - 1;
+    const int prow = c.bh + 5, crow = (c.bh >> 1) + 3, nl = 4 * prow;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int i = c.lane + 64 * pass;
+        if (i < nl) {
+            const int k = i / prow, r = i - k * prow;
+            MX_GLB(u8) src = c.pl[k] + (ptrdiff_t)(c.py0 + r) * c.sy + c.px0;
+            const uintptr_t a = (uintptr_t)src;
+            const u32 sft = (u32)(a & 3);
+            MX_GLB(u32) q = (MX_GLB(u32))(a - sft);
+            lds_w d = (lds_w)(uintptr_t)(u32)(uintptr_t)(c.patch + k * MX_PPL + r * MX_PS);
+            if (c.bw == 16) {
+                const u32 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], w6 = q[6];
+                d[0] = __builtin_amdgcn_alignbyte(w1, w0, sft); d[1] = __builtin_amdgcn_alignbyte(w2, w1, sft); d[2] = __builtin_amdgcn_alignbyte(w3, w2, sft);
+                d[3] = __builtin_amdgcn_alignbyte(w4, w3, sft); d[4] = __builtin_amdgcn_alignbyte(w5, w4, sft); d[5] = __builtin_amdgcn_alignbyte(w6, w5, sft);
+            } else {
+                const u32 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                d[0] = __builtin_amdgcn_alignbyte(w1, w0, sft); d[1] = __builtin_amdgcn_alignbyte(w2, w1, sft);
+                d[2] = __builtin_amdgcn_alignbyte(w3, w2, sft); d[3] = __builtin_amdgcn_alignbyte(w4, w3, sft);
+            }
+        } else if (i - nl < 2 * crow) {
+            const int j = i - nl, k = j >= crow, r = j - k * crow;
+            MX_GLB(u8) src = (k ? c.cv : c.cu) + (ptrdiff_t)(c.cy0 + r) * c.sc + c.cx0;
+            const uintptr_t a = (uintptr_t)src;
+            const u32 sft = (u32)(a & 3);
+            MX_GLB(u32) q = (MX_GLB(u32))(a - sft);
+            lds_w d = (lds_w)(uintptr_t)(u32)(uintptr_t)(c.patch + 4 * MX_PPL + (k * MX_CROWS + r) * MX_CS);
+            const u32 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+            d[0] = __builtin_amdgcn_alignbyte(w1, w0, sft); d[1] = __builtin_amdgcn_alignbyte(w2, w1, sft); d[2] = __builtin_amdgcn_alignbyte(w3, w2, sft);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    c.patch_on = true;
+}
+// true when every lane's quarter-pel candidate reads inside the staged neighbourhood
+__device__ __forceinline__ bool mx_in_patch(const MxCtx &c, int mx, int my)
+{
+    if (!c.has_patch || !c.patch_on) return false;
+    const int fx = (mx >> 2) - c.px0, fy = (my >> 2) - c.py0, gx = (mx >> 3) - c.cx0, gy = (my >> 3) - c.cy0;
+    const bool in = fx >= 0 && fx <= 4 && fy >= 0 && fy <= 4 && gx >= 0 && gx <= 2 && gy >= 0 && gy <= 2;
+    return __ballot(!in) == 0;
+}
 
 // ---- block sums for this lane group's candidate; the result is present in every lane of the group ----
 // SAD of the full-pel candidate (mx, my): 16 lanes per candidate, one picture row per lane
@@ -154,6 +233,32 @@ __device__ __forceinline__ int sad_qpel16_lane(const MxCtx &c, int mx, int my)
     const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
     const ptrdiff_t base = (ptrdiff_t)((my >> 2) + row) * c.sy + (mx >> 2);
     int v = 0;
+    if (mx_in_patch(c, mx, my)) {
+        if (row < c.bh) {
+            const int o = ((my >> 2) - c.py0 + row) * MX_PS + (mx >> 2) - c.px0;
+            MX_LDS(u8) pa = c.patch + c_qpel_a[idx] * MX_PPL + o + (fy == 3) * MX_PS; MX_LDS(u8) pb = c.patch + c_qpel_b[idx] * MX_PPL + o + (fx == 3);
+            MX_LDS(u32) f = c.fe + c.fe_off + 4 * row;
+            u32 s;
+            if (c.bw == 16) {
+                u32 a[4];
+                lds16u(pa, a);
+                if (idx & 5) {
+                    u32 b[4];
+                    lds16u(pb, b);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) a[k] = avg4(a[k], b[k]);
+                }
+                s = sad4(a[0], f[0], 0); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
+            } else {
+                u32 a0, a1, t;
+                lds9u(pa, a0, a1, t);
+                if (idx & 5) { u32 b0, b1; lds9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
+                s = sad4(a0, f[0], 0); s = sad4(a1, f[1], s);
+            }
+            v = (int)s;
+        }
+        return row_sum16(v);
+    }
     if (row < c.bh) {
         MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
         MX_LDS(u32) f = c.fe + c.fe_off + 4 * row;
@@ -256,23 +361,40 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
     const int j = c.lane & 15;
     int v = 0;
     const int nbx = c.bw >> 3, n_luma = nbx * (c.bh >> 2), n_cunits = c.bh >> 3;      // 8x4 luma blocks; 4-row chroma units per plane
+    const bool staged = mx_in_patch(c, mx, my);
     if (j < n_luma) {
         const int bx = (nbx == 2 ? (j & 1) : 0) * 8, by = (nbx == 2 ? (j >> 1) : j) * 4;
         const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
         const ptrdiff_t base = (ptrdiff_t)((my >> 2) + by) * c.sy + (mx >> 2) + bx;
         MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
         u32 f[4][2], p[4][2];
+        if (staged) {
+            const int o = ((my >> 2) - c.py0 + by) * MX_PS + (mx >> 2) - c.px0 + bx;
+            MX_LDS(u8) la = c.patch + c_qpel_a[idx] * MX_PPL + o + (fy == 3) * MX_PS; MX_LDS(u8) lb = c.patch + c_qpel_b[idx] * MX_PPL + o + (fx == 3);
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            u32 t;
-            load9u(pa + (ptrdiff_t)y * c.sy, p[y][0], p[y][1], t);
-            if (idx & 5) {
-                u32 b0, b1;
-                load9u(pb + (ptrdiff_t)y * c.sy, b0, b1, t);
-                p[y][0] = avg4(p[y][0], b0); p[y][1] = avg4(p[y][1], b1);
+            for (int y = 0; y < 4; y++) {
+                u32 t;
+                lds9u(la + y * MX_PS, p[y][0], p[y][1], t);
+                if (idx & 5) {
+                    u32 b0, b1;
+                    lds9u(lb + y * MX_PS, b0, b1, t);
+                    p[y][0] = avg4(p[y][0], b0); p[y][1] = avg4(p[y][1], b1);
+                }
             }
-            f[y][0] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2) + 1];
+        } else {
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                u32 t;
+                load9u(pa + (ptrdiff_t)y * c.sy, p[y][0], p[y][1], t);
+                if (idx & 5) {
+                    u32 b0, b1;
+                    load9u(pb + (ptrdiff_t)y * c.sy, b0, b1, t);
+                    p[y][0] = avg4(p[y][0], b0); p[y][1] = avg4(p[y][1], b1);
+                }
+            }
         }
+#pragma unroll
+        for (int y = 0; y < 4; y++) { f[y][0] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2) + 1]; }
         if (satd) {
             u32 d[4][4];
 #pragma unroll
@@ -290,8 +412,14 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
         const int ca = (8 - dx) * (8 - dy), cb = dx * (8 - dy), cc = (8 - dx) * dy, cd = dx * dy;
         MX_GLB(u8) s = plane + (ptrdiff_t)((my >> 3) + by) * c.sc + (mx >> 3);
         u32 r0[5], r1[5], r2[5];
+        if (staged) {
+            MX_LDS(u8) ls = c.patch + 4 * MX_PPL + ((j >= 10) * MX_CROWS + (my >> 3) - c.cy0 + by) * MX_CS + (mx >> 3) - c.cx0;
 #pragma unroll
-        for (int y = 0; y < 5; y++) load9u(s + (ptrdiff_t)y * c.sc, r0[y], r1[y], r2[y]);
+            for (int y = 0; y < 5; y++) lds9u(ls + y * MX_CS, r0[y], r1[y], r2[y]);
+        } else {
+#pragma unroll
+            for (int y = 0; y < 5; y++) load9u(s + (ptrdiff_t)y * c.sc, r0[y], r1[y], r2[y]);
+        }
         if (satd) {
             // pair x of a row = (px x, px x + 4); the row moved one sample right is pairs 1..3 and (px 4, px 8)
             u32 a[5][5];
@@ -443,7 +571,8 @@ __device__ __forceinline__ void umh_stream(const MxCtx &c, const MeLimits &L, in
 __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits &L_in, const MeOpts &o_in, const i16 *mvc, int n_mvc,
                                                int *thresh, int &out_mvx, int &out_mvy, int &out_cost_mv)
 {
-    const MxCtx c = mx_uniform(c_in);
+    MxCtx c = mx_uniform(c_in);
+    c.patch_on = false;
     const MeLimits L = mx_uniform(L_in);
     const MeOpts o = mx_uniform(o_in);
     n_mvc = MX_UNI(n_mvc);
@@ -606,6 +735,7 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
         const int hpel = c_subpel_iters[o.subme][2], qpel = c_subpel_iters[o.subme][3];
         int bx = mvx, by = mvy, bc = mcost, odir = -1, bdir;
         bool early = false;
+        if (c.has_patch) mx_load_patch(c, bx, by);
         if (hpel && o.subme < 3) {
             const int mx = clip3(mvpx, L.smin0, L.smax0), my = clip3(mvpy, L.smin1, L.smax1);
             if ((mx - bx) | (my - by)) {
@@ -657,12 +787,14 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
 // cost comes in without the reference cost; returns the refined cost.
 __device__ __forceinline__ int me_refine_qpel16(const MxCtx &c_in, const MeLimits &L_in, const MeOpts &o_in, int cost_in, int &mvx, int &mvy)
 {
-    const MxCtx c = mx_uniform(c_in);
+    MxCtx c = mx_uniform(c_in);
+    c.patch_on = false;
     const MeLimits L = mx_uniform(L_in);
     const MeOpts o = mx_uniform(o_in);
     const int lane = c.lane, g16 = lane >> 4;
     const int hpel = c_subpel_iters[o.subme][0], qpel = c_subpel_iters[o.subme][1], satd = o.subme > 1;
     int bx = MX_UNI(mvx), by = MX_UNI(mvy), bc = MX_UNI(cost_in);
+    if (c.has_patch) mx_load_patch(c, bx, by);
     if (hpel && o.subme < 3) {
         const int mx = clip3(c.mvpx, L.smin0, L.smax0), my = clip3(c.mvpy, L.smin1, L.smax1);
         if ((mx - bx) | (my - by)) {

@@ -101,3 +101,35 @@ def test_sweep_full_hd_matches_twin(hip_lib, oracle_lib, cqm):
             assert np.array_equal(out[f]["fin_" + nm][0], want["fin_" + nm][f]), "frame %d: filtered %s" % (f, nm)
     t = want["mb_type"][1:]
     assert (t == sl.P_8x8).any() and (t == sl.P_L0).any() and (want["mb_type"][0] == sl.I_4x4).any()
+
+
+def _against_twin(hip_lib, oracle_lib, cqm, w, h, n, kw, need_types=()):
+    from oracle import refslice as rs
+    y, u, v = rs.clip(w, h, n)
+    want = rs.run(oracle_lib, "x264o_encode_chain", rs.make_params(w, h, n, **kw), y, u, v)
+    out = run_chain(hip_lib, cqm, (w, h), n, y, u, v, kw)
+    for f in range(n):
+        for k in STATE:
+            got, ref = out[f][k][0], want[k][f]
+            assert np.array_equal(got.reshape(ref.shape), ref), "frame %d: %s differs first at %s" % (f, k, np.argwhere(got.reshape(ref.shape) != ref)[:3].tolist())
+        for nm in ("y", "u", "v"):
+            kind = "fin_" if kw.get("deblock") else "rec_"
+            assert np.array_equal(out[f][kind + nm][0], want[kind + nm][f]), "frame %d: reconstructed %s" % (f, nm)
+    for t in need_types:
+        assert (want["mb_type"] == t).any()
+
+
+def test_sweep_cif_ultrafast_matches_twin(hip_lib, oracle_lib, cqm):
+    """BASELINE configs[0]'s shape: 352x288, the ultrafast-like option set (dia, subme 0, one reference, 16x16 only, no
+    loop filter, CAVLC-side cbp), 10 frames of the synthetic clip against the CPU twin."""
+    from oracle import refslice as rs
+    _against_twin(hip_lib, oracle_lib, cqm, 352, 288, 10, dict(qp=26, subme=0, me_method=rs.ME_DIA, n_refs=1, cabac=0, deblock=0),
+                  need_types=(sl.P_L0, sl.I_16x16))
+
+
+def test_sweep_2160p_umh_matches_twin(hip_lib, oracle_lib, cqm):
+    """BASELINE configs[2]'s shape: 3840x2160 (240x135 macroblocks) with --me umh, the medium-like option set, 2 frames."""
+    from oracle import refslice as rs
+    _against_twin(hip_lib, oracle_lib, cqm, 3840, 2160, 2,
+                  dict(qp=28, subme=5, me_method=rs.ME_UMH, n_refs=1, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1),
+                  need_types=(sl.P_8x8, sl.P_L0))

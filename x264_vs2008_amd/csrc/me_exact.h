@@ -283,6 +283,40 @@ __device__ __forceinline__ int sad_qpel16_lane(const MxCtx &c, int mx, int my)
     }
     return row_sum16(v);
 }
+// the same with 8 lanes per candidate, two picture rows per lane (global memory only: the predictor stage, whose
+// candidates lie anywhere inside the mv limits)
+__device__ __forceinline__ int sad_qpel8_lane(const MxCtx &c, int mx, int my)
+{
+    const int r = c.lane & 7;
+    const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
+    u32 s = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int row = r + 8 * half;
+        if (row < c.bh) {
+            const ptrdiff_t base = (ptrdiff_t)((my >> 2) + row) * c.sy + (mx >> 2);
+            MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+            MX_LDS(u32) f = c.fe + c.fe_off + 4 * row;
+            if (c.bw == 16) {
+                u32 a[4];
+                load16u(pa, a);
+                if (idx & 5) {
+                    u32 b[4];
+                    load16u(pb, b);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) a[k] = avg4(a[k], b[k]);
+                }
+                s = sad4(a[0], f[0], s); s = sad4(a[1], f[1], s); s = sad4(a[2], f[2], s); s = sad4(a[3], f[3], s);
+            } else {
+                u32 a0, a1, t;
+                load9u(pa, a0, a1, t);
+                if (idx & 5) { u32 b0, b1; load9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
+                s = sad4(a0, f[0], s); s = sad4(a1, f[1], s);
+            }
+        }
+    }
+    return half_sum8((int)s);
+}
 // vertical half of the 8x4 SATD when the four rows of a block sit in lanes l, l^1, l^2, l^3
 __device__ __forceinline__ int satd_rows4(u32 t0, u32 t1, u32 t2, u32 t3, int lane)
 {
@@ -585,8 +619,8 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
     if (o.subme >= 3) {
         // me.c:188-210: the predictor and every distinct non-zero candidate at quarter-pel precision (SAD)
         const int px = bmx, py = bmy;
-        for (int base = 0; base < 1 + n_mvc; base += 4) {
-            const int k = base + g16;
+        for (int base = 0; base < 1 + n_mvc; base += 8) {      // eight per trip: one trip for all but the longest lists
+            const int k = base + g8;
             int x = px, y = py;
             bool ok = k == 0;
             if (k >= 1 && k <= n_mvc) {
@@ -595,9 +629,9 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
                     ok = true; x = clip3(vx, L.fmin0 * 4, L.fmax0 * 4); y = clip3(vy, L.fmin1 * 4, L.fmax1 * 4);
                 }
             }
-            const int cost = sad_qpel16_lane(c, x, y) + c.lane_cost(x, y);
-            const u32 key = mx_best_key<4>(cost, ok, lane);
-            MX_TAKE(4, key, bpcost, x, y, bpx, bpy);
+            const int cost = sad_qpel8_lane(c, x, y) + c.lane_cost(x, y);
+            const u32 key = mx_best_key<3>(cost, ok, lane);
+            MX_TAKE(3, key, bpcost, x, y, bpx, bpy);
         }
         bmx = (bpx + 2) >> 2; bmy = (bpy + 2) >> 2;
         // COST_MV(bmx, bmy); COST_MV(0, 0)

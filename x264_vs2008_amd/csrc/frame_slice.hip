@@ -915,7 +915,7 @@ template <int WPE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs)
 {
     __shared__ SwLds s;
-    const int lane = threadIdx.x;
+    const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
     if (bz >= a.batch) return;
     const size_t nmb = (size_t)a.mb_w * a.mb_h, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
@@ -959,6 +959,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
 
     for (int mbx = 0; mbx < a.mb_w; mbx++) {
+        // The lane id is laundered once per macroblock: otherwise every lane-derived address and index of the body is hoisted
+        // out of this loop, and, being live across all of it, spilled to scratch at the top and reloaded at its use (measured:
+        // ~160 scratch stores per macroblock).  Recomputing them from the lane id costs a few VALU operations each.
+        int lane = lane_id;
+#define LAUNDER() asm volatile("" : "+v"(lane))
+        LAUNDER();
         const int mb = mby * a.mb_w + mbx;
         // ---- wait for the row above: left-top, top and top-right neighbours finished ----
         if (mby > 0) {
@@ -1005,6 +1011,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         }
         WAVE_SYNC();
         PROF(1);
+        LAUNDER();
         // ---- neighbour availability and types ----
         int nb = 0, type_top = -1, type_topleft = -1, type_topright = -1;
 #define UNI(x_) __builtin_amdgcn_readfirstlane((int)(x_))      /* a wave-uniform load: keep the value in a scalar register */
@@ -1064,6 +1071,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         };
         // x264_mb_analyse_intra, R/encoder/analyse.c:612-843
         auto analyse_intra = [&](int satd_inter) {
+            LAUNDER();
             {
                 int m[4], n = sw_modes16(nb, m);
                 for (int i = 0; i < n; i++) {
@@ -1293,6 +1301,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     c.mvpx = mvpx; c.mvpy = mvpy;
                     thresh -= a.ref_cost[r];
                     int smx, smy, cost_mv;
+                    LAUNDER(); c.lane = lane;
                     int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], n_mvc, a.n_refs > 1 ? &thresh : nullptr, smx, smy, cost_mv);
                     if (r == 0 && try_pskip && cost - cost_mv < 300 * a.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
                         if (sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
@@ -1376,6 +1385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     predict_blk(13, 4 * i, 2, px, py);
                                     aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
                                     c.mvpx = px; c.mvpy = py;
+                                    LAUNDER(); c.lane = lane;
                                     int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + a.ref_cost[r];
                                     if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
                                     WAVE_SYNC();
@@ -1395,6 +1405,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 predict_blk(13, 4 * i, 2, px, py);
                                 aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
                                 c.mvpx = px; c.mvpy = py;
+                                LAUNDER(); c.lane = lane;
                                 const int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm);
                                 cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, r, vx, vy, 1);
                                 if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
@@ -1423,6 +1434,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                         predict_blk(dir ? 15 : 14, dir ? 4 * i : 8 * i, dir ? 2 : 4, px, py);
                                         aim(r, dir ? 8 : 16, dir ? 16 : 8, dir ? 8 * i : 0, dir ? 0 : 8 * i);
                                         c.mvpx = px; c.mvpy = py;
+                                        LAUNDER(); c.lane = lane;
                                         const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + a.ref_cost[r];
                                         if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
                                     }
@@ -1438,6 +1450,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         aim(ref, 16, 16, 0, 0);
                         c.mvpx = bmvpx; c.mvpy = bmvpy;
                         best -= a.ref_cost[ref];
+                        LAUNDER(); c.lane = lane;
                         best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
                         i_cost = best;
                         if (lane < 16) { s.mv4[lane][0] = (i16)mvx; s.mv4[lane][1] = (i16)mvy; }
@@ -1451,6 +1464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             int vx = pme(slot0 + i, 0), vy = pme(slot0 + i, 1);
                             aim(r, w, h, bx, by);
                             c.mvpx = pme(slot0 + i, 6); c.mvpy = pme(slot0 + i, 7);
+                            LAUNDER(); c.lane = lane;
                             i_cost += me_refine_qpel16(c, L, mo, pme(slot0 + i, 2) - pme(slot0 + i, 5), vx, vy);
                             WAVE_SYNC();
                             if (lane < 16) {
@@ -1465,6 +1479,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     }
                     WAVE_SYNC();
                     PROF(2);
+                    LAUNDER();
+        LAUNDER();
                     if (a.chroma_me) {
                         analyse_chroma();
                         analyse_intra(i_cost - satd_chroma);
@@ -1490,6 +1506,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         }
         (void)analysed;
         PROF(6);
+        LAUNDER();
 
         // ---- x264_analyse_update_cache + x264_macroblock_encode ----
         int cbp_luma = 0, cbp_chroma = 0;
@@ -1572,6 +1589,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         const int intra = IS_INTRA_T(type);
         if (cbp_luma == 0 && type != T_I_8x8) t8 = 0;           // x264_macroblock_cache_save, R/common/macroblock.c:1273-1275
         PROF(3);
+        LAUNDER();
 
         // ---- x264_macroblock_cache_save: reconstruction, per-macroblock state, levels ----
         {
@@ -1627,6 +1645,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         left_type = type;
         left_ref = is_p ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);
         PROF(4);
+        LAUNDER();
         // ---- publish: everything this macroblock wrote is visible before the count moves ----
         __threadfence();
         __builtin_amdgcn_wave_barrier();
@@ -1639,6 +1658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         a.prof[((size_t)bz * a.mb_h + mby) * 8 + lane] = v;
     }
 #undef PROF
+#undef LAUNDER
 }
 
 // b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
@@ -1770,6 +1790,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
     switch (wpe) {
     case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
+    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
+    case 4: hipLaunchKernelGGL(k_slice_sweep<4>, grid, block, 0, c->stream, a, t); break;
     default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
     }
     if (is_p && a.flags_intra)

@@ -1480,7 +1480,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     WAVE_SYNC();
                     PROF(2);
                     LAUNDER();
-        LAUNDER();
                     if (a.chroma_me) {
                         analyse_chroma();
                         analyse_intra(i_cost - satd_chroma);
@@ -1782,16 +1781,15 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     }
     HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
     static int wpe = 0;
-    if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..4
+    if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..3
         const char *e = getenv("X264HIP_SWEEP_WPE");
-        wpe = e ? atoi(e) : 2;
-        if (wpe < 1 || wpe > 4) wpe = 2;
+        wpe = e ? atoi(e) : 3;                                       // 3 waves/SIMD (168 VGPRs, 12 waves per CU with 13 KB of LDS each): measured best
+        if (wpe < 1 || wpe > 3) wpe = 3;
     }
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
     switch (wpe) {
     case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
     case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
-    case 4: hipLaunchKernelGGL(k_slice_sweep<4>, grid, block, 0, c->stream, a, t); break;
     default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
     }
     if (is_p && a.flags_intra)

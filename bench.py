@@ -12,8 +12,8 @@ x264_fdec_filter_row do for one frame (R/encoder/encoder.c:1141-1291, 983-1056):
   x264hip_expand_border, x264hip_hpel_filter_frame   the frame becomes a reference
 
 with the analysis options named in config.workload (the part of the medium preset built so far:
-hex ME, subme 5, 3 references, chroma ME, fast P-skip, decimation, CABAC-side cbp; every frame I or P;
-CQP).  Every decision, level and pixel of this loop is bit-exact against the reference's own
+hex ME (or --me 0/2: dia / umh), subme 5, 3 references, mixed refs, P 16x16/16x8/8x16/8x8, I 16x16/8x8/4x4, 8x8 transform,
+chroma ME, fast P-skip, decimation, CABAC-side cbp; every frame I or P; CQP).  Every decision, level and pixel of this loop is bit-exact against the reference's own
 functions (tests/test_gpu_slice.py); entropy coding stays on the host and is not timed.
 
 Chains shard across ranks with no data-path collective (closed GOPs); scaling is weak.
@@ -169,6 +169,21 @@ def main():
     sweep_bytes = int(B * px * (1.5 + 4.5 * args.refs + 1.5))
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
 
+    # HBM-side traffic of one P sweep launch: not measurable from inside this process (PMC counters need rocprofv3), so the
+    # figure is the committed rocprofv3 measurement of this very configuration, and null for any other configuration
+    traffic, traffic_note = None, "no rocprofv3 PMC measurement committed for this configuration"
+    tpath = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
+    defaults = (args.width, args.height, args.qp, args.subme, args.me, args.keyint, args.inter, args.intra, args.dct8, args.mixed_refs) == \
+               (1920, 1080, 26, 5, 1, 24, 0x13, 0x3, 1, 1)
+    if defaults and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        hit = [l for l in tj["launches"] if l["slice"] == "P" and l["refs"] == args.refs]
+        if hit and tj["batch"] == B:
+            traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE of one P launch with %d references, rocprofv3 --pmc, separate passes, raw request-granular "
+                            "counters (profiles/r01_sweep_traffic.json)" % args.refs)
+
     if rank == 0:
         fps = world * B * args.steps / dt
         frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)       # + deblock read/write + hpel planes
@@ -190,11 +205,11 @@ def main():
                        "parallelism": "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); "
                                       "chains shard across GPUs with no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "k_slice_sweep", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
-                         "note": "P-frame launches only; the sweep is bound by the macroblock dependency chain (mb_w + 2*mb_h = %d "
-                                 "serial macroblock steps per frame), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s "
-                                 "at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
+                         "note": "P-frame launches only; the sweep is bound by dependent memory round trips along the macroblock "
+                                 "dependency chain (mb_w + 2*mb_h = %d serial macroblock steps per frame; PMC: waves wait ~75%% of their "
+                                 "cycles), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(args)

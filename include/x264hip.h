@@ -177,7 +177,7 @@ int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, c
 
 /* The reference's own search, exactly: x264_me_search_ref + refine_subpel for the 16x16 block
  * (R/encoder/me.c:156-778) for every macroblock and every reference, inside the loop of
- * x264_mb_analyse_inter_p16x16 (R/encoder/analyse.c:1077-1127): predictor tests, DIA / HEX walk,
+ * x264_mb_analyse_inter_p16x16 (R/encoder/analyse.c:1077-1127): predictor tests, DIA / HEX / UMH walk,
  * square refine, half-pel + quarter-pel diamonds (SAD / SATD per subme, chroma ME), the half-pel
  * early-termination threshold carried across references, best reference = first minimum of
  * cost + ref_cost.  Predictors are inputs (the caller derives them from neighbours / lookahead).
@@ -186,7 +186,7 @@ int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, c
  *   out_mv   : [mb][n_refs][2] qpel;  out_cost : [mb][n_refs] (ref cost included)
  *   best     : [mb][4] = {ref, mvx, mvy, cost}                                             */
 typedef struct {
-    int me_method;             /* 0 = X264_ME_DIA, 1 = X264_ME_HEX */
+    int me_method;             /* 0 = X264_ME_DIA, 1 = X264_ME_HEX, 2 = X264_ME_UMH (ESA / TESA are refused) */
     int me_range, subme, chroma_me;
     int mv_range;              /* pixels; 0 = 512 */
     const int16_t *cost_mv;    /* device */

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             else if (lane < 32) s.fd[FDV + (lane - 24) * FD - 1] = s.fd[FDV + (lane - 24) * FD + 7];
         }
         {   // source pixels: fetched one macroblock ahead (they depend on nothing), parked in registers meanwhile
-            const int r = lane >> 2, x = (lane & 3) * 4, cx = lane & 7, cy = lane >> 3;
+            const int r = lane >> 2, x = (lane & 3) * 4;
             *(u32 *)(s.fe + r * 16 + x) = pre_y;
             s.fe[256 + lane] = pre_u;
             s.fe[320 + lane] = pre_v;

@@ -396,6 +396,8 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
     int v = 0;
     const int nbx = c.bw >> 3, n_luma = nbx * (c.bh >> 2), n_cunits = c.bh >> 3;      // 8x4 luma blocks; 4-row chroma units per plane
     const bool staged = mx_in_patch(c, mx, my);
+    u32 d[4][4];                 // packed differences of this lane's 8x4 unit (SATD): luma and chroma lanes share one transform below
+    bool have_d = false;
     if (j < n_luma) {
         const int bx = (nbx == 2 ? (j & 1) : 0) * 8, by = (nbx == 2 ? (j >> 1) : j) * 4;
         const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
@@ -430,12 +432,11 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
 #pragma unroll
         for (int y = 0; y < 4; y++) { f[y][0] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2)]; f[y][1] = c.fe[c.fe_off + (by + y) * 4 + (bx >> 2) + 1]; }
         if (satd) {
-            u32 d[4][4];
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
                 for (int x = 0; x < 4; x++) d[y][x] = mx_pair(f[y][1], f[y][0], x) - mx_pair(p[y][1], p[y][0], x);
-            v = satd8x4_packed(d);
+            have_d = true;
         } else
             v = blk8x4_cost(f, p, 0);
     } else if (chroma && j >= 8 && j < 12 && ((j - 8) & 1) < n_cunits) {
@@ -466,7 +467,6 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
             const mx_u16x2 ka = {(unsigned short)ca, (unsigned short)ca}, kb = {(unsigned short)cb, (unsigned short)cb};
             const mx_u16x2 kc = {(unsigned short)cc, (unsigned short)cc}, kd = {(unsigned short)cd, (unsigned short)cd}, k32 = {32, 32};
             const u32 keep = wide ? 0xffffffffu : 0x0000ffffu;      // a 4-wide unit: the right half contributes nothing
-            u32 d[4][4];
 #pragma unroll
             for (int y = 0; y < 4; y++) {
                 MX_LDS(u32) fr = (MX_LDS(u32))(fe + (by + y) * 8);
@@ -477,7 +477,7 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
                     d[y][x] = (mx_pair(f1, f0, x) & keep) - (mx_as_u32(pv) & keep);
                 }
             }
-            v = satd8x4_packed(d);
+            have_d = true;
         } else {
             u32 f[4][2], p[4][2];
 #pragma unroll
@@ -497,6 +497,7 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
             v = blk8x4_cost(f, p, 0);
         }
     }
+    if (have_d) v = satd8x4_packed(d);
     return row_sum16(v);
 }
 

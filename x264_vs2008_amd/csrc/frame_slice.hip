@@ -96,10 +96,7 @@ struct SwLds {
     signed char left_i4[4];     // the left macroblock's modes of blocks 5, 7, 13, 15
     signed char pred4[16], pred8[4];
     // P partitions: the motion cache (h->mb.cache.ref / mv, x264_scan8 layout), a->l0.mvc, candidate records, final vectors
-    signed char cref[48];
-    i16 cmv[48][2];
     i16 l0mvc[SW_MAX_REFS][5][2];
-    int pme[8][8];
     i16 mv4[16][2];
     signed char ref8[4];
     i16 left_mv4[4][2];         // the left macroblock's vectors of blocks 3, 7, 11, 15 and references of its 8x8 blocks 1, 3
@@ -1213,28 +1210,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = UNI(a.ref[o * 4 + 2]); bx = UNI(a.mv[(o * 16 + 12) * 2]); byv = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
             if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = UNI(a.ref[o * 4 + 2]); cx = UNI(a.mv[(o * 16 + 12) * 2]); cy = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
             else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = UNI(a.ref[o * 4 + 3]); cx = UNI(a.mv[(o * 16 + 15) * 2]); cy = UNI(a.mv[(o * 16 + 15) * 2 + 1]); }
+            // The motion cache (h->mb.cache.ref[0] / mv[0], x264_scan8 layout) and the partition analysis' candidate records live in
+            // the register file as lane-indexed arrays: entry k = lane k of a VGPR, read with v_readlane (uniform index), written
+            // by the lane itself or with v_writelane -- no LDS round trip, no barrier.
+            int cref_v = -2, cmvx_v = 0, cmvy_v = 0, pme_v = 0;
             if (a.flags_inter & 0x10) {
                 // the full motion cache for x264_mb_predict_mv on partitions: -2 = not available, neighbours as cache_load leaves them
-                if (lane < 48) { s.cref[lane] = -2; s.cmv[lane][0] = 0; s.cmv[lane][1] = 0; }
-                WAVE_SYNC();
-                if ((nb & NB_TOP) && lane < 4) {
-                    const int o = mb - a.mb_w;
-                    s.cref[4 + lane] = a.ref[o * 4 + 2 + (lane >> 1)];
-                    s.cmv[4 + lane][0] = a.mv[(o * 16 + 12 + lane) * 2]; s.cmv[4 + lane][1] = a.mv[(o * 16 + 12 + lane) * 2 + 1];
+                if ((nb & NB_TOP) && lane >= 4 && lane < 8) {
+                    const int o = mb - a.mb_w, k = lane - 4;
+                    cref_v = a.ref[o * 4 + 2 + (k >> 1)]; cmvx_v = a.mv[(o * 16 + 12 + k) * 2]; cmvy_v = a.mv[(o * 16 + 12 + k) * 2 + 1];
                 }
-                if ((nb & NB_TOPLEFT) && lane == 4) {
+                if ((nb & NB_TOPLEFT) && lane == 3) {
                     const int o = mb - a.mb_w - 1;
-                    s.cref[3] = a.ref[o * 4 + 3]; s.cmv[3][0] = a.mv[(o * 16 + 15) * 2]; s.cmv[3][1] = a.mv[(o * 16 + 15) * 2 + 1];
+                    cref_v = a.ref[o * 4 + 3]; cmvx_v = a.mv[(o * 16 + 15) * 2]; cmvy_v = a.mv[(o * 16 + 15) * 2 + 1];
                 }
-                if ((nb & NB_TOPRIGHT) && lane == 5) {
+                if ((nb & NB_TOPRIGHT) && lane == 8) {
                     const int o = mb - a.mb_w + 1;
-                    s.cref[8] = a.ref[o * 4 + 2]; s.cmv[8][0] = a.mv[(o * 16 + 12) * 2]; s.cmv[8][1] = a.mv[(o * 16 + 12) * 2 + 1];
+                    cref_v = a.ref[o * 4 + 2]; cmvx_v = a.mv[(o * 16 + 12) * 2]; cmvy_v = a.mv[(o * 16 + 12) * 2 + 1];
                 }
-                if ((nb & NB_LEFT) && lane >= 8 && lane < 12) {
-                    const int i = lane - 8;
-                    s.cref[11 + 8 * i] = s.left_r8[i >> 1]; s.cmv[11 + 8 * i][0] = s.left_mv4[i][0]; s.cmv[11 + 8 * i][1] = s.left_mv4[i][1];
+                if ((nb & NB_LEFT) && lane >= 11 && lane < 36 && ((lane - 11) & 7) == 0) {
+                    const int i = (lane - 11) >> 3;
+                    cref_v = s.left_r8[i >> 1]; cmvx_v = s.left_mv4[i][0]; cmvy_v = s.left_mv4[i][1];
                 }
-                WAVE_SYNC();
             }
             // x264_mb_predict_mv_16x16, :90-128
             auto predict16 = [&](int i_ref, int &px, int &py) {
@@ -1328,28 +1325,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     // candidate records of the partition analysis (x264_me_t's mv / cost / cost_mv / i_ref / i_ref_cost / mvp):
                     // slots 0-3 me8x8, 4-5 me16x8, 6-7 me8x16.  Wave-uniform values, parked in LDS because they are indexed.
                     auto pme_put = [&](int slot, int vx, int vy, int cost, int cost_mv, int r, int ref_cost, int px, int py) {
-                        if (lane == 0) { int *d = s.pme[slot]; d[0] = vx; d[1] = vy; d[2] = cost; d[3] = cost_mv; d[4] = r; d[5] = ref_cost; d[6] = px; d[7] = py; }
-                        WAVE_SYNC();
+                        const int f = lane - slot * 8;                          // this lane's field of that record, if 0..7
+                        pme_v = f == 0 ? vx : f == 1 ? vy : f == 2 ? cost : f == 3 ? cost_mv : f == 4 ? r : f == 5 ? ref_cost : f == 6 ? px : f == 7 ? py : pme_v;
                     };
-                    auto pme = [&](int slot, int f) -> int { return UNI(s.pme[slot][f]); };
+                    auto pme = [&](int slot, int f) -> int { return __builtin_amdgcn_readlane(pme_v, slot * 8 + f); };
                     // x264_macroblock_cache_ref / _mv on a run of 4x4 blocks of the motion cache
                     auto cache_set = [&](int x, int y, int w, int h, int r, int vx, int vy, int set_mv) {
-                        if (lane < 16) {
-                            const int i = lane & 3, j = lane >> 2, k = 12 + i + 8 * j;
-                            if (i >= x && i < x + w && j >= y && j < y + h) {
-                                s.cref[k] = (signed char)r;
-                                if (set_mv) { s.cmv[k][0] = (i16)vx; s.cmv[k][1] = (i16)vy; }
-                            }
+                        const int k = lane - 12, i = k & 7, j = k >> 3;          // cache entry 12 + i + 8 j = 4x4 block (i, j)
+                        if (k >= 0 && i < 4 && j < 4 && i >= x && i < x + w && j >= y && j < y + h) {
+                            cref_v = r;
+                            if (set_mv) { cmvx_v = vx; cmvy_v = vy; }
                         }
-                        WAVE_SYNC();
                     };
                     // x264_mb_predict_mv (R/common/macroblock.c:28-88) from the cache; cur_part = h->mb.i_partition
                     auto predict_blk = [&](int cur_part, int idx, int width, int &px, int &py) {
-                        const int i8 = sw_scan8(idx), i_ref = UNI(s.cref[i8]);
-                        int ra = UNI(s.cref[i8 - 1]), rb = UNI(s.cref[i8 - 8]), rc = UNI(s.cref[i8 - 8 + width]), kc = i8 - 8 + width;
-                        if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { kc = i8 - 8 - 1; rc = UNI(s.cref[kc]); }
-                        const int ax = UNI(s.cmv[i8 - 1][0]), ay = UNI(s.cmv[i8 - 1][1]), bx = UNI(s.cmv[i8 - 8][0]), byv = UNI(s.cmv[i8 - 8][1]);
-                        const int cx = UNI(s.cmv[kc][0]), cy = UNI(s.cmv[kc][1]);
+                        const int i8 = sw_scan8(idx), i_ref = __builtin_amdgcn_readlane(cref_v, i8);
+                        int ra = __builtin_amdgcn_readlane(cref_v, i8 - 1), rb = __builtin_amdgcn_readlane(cref_v, i8 - 8), rc = __builtin_amdgcn_readlane(cref_v, i8 - 8 + width), kc = i8 - 8 + width;
+                        if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { kc = i8 - 8 - 1; rc = __builtin_amdgcn_readlane(cref_v, kc); }
+                        const int ax = __builtin_amdgcn_readlane(cmvx_v, i8 - 1), ay = __builtin_amdgcn_readlane(cmvy_v, i8 - 1), bx = __builtin_amdgcn_readlane(cmvx_v, i8 - 8), byv = __builtin_amdgcn_readlane(cmvy_v, i8 - 8);
+                        const int cx = __builtin_amdgcn_readlane(cmvx_v, kc), cy = __builtin_amdgcn_readlane(cmvy_v, kc);
                         if (cur_part == 14) {                       // D_16x8
                             if (idx == 0 && rb == i_ref) { px = bx; py = byv; return; }
                             if (idx != 0 && ra == i_ref) { px = ax; py = ay; return; }
@@ -1374,8 +1368,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             const int tt = type_top == T_I_8x8 ? 0 : type_top, tl = left_type == T_I_8x8 ? 0 : left_type;   // as cache_save stores them
                             if (maxref > 0 && ref == 0 && tt && tl) {
                                 maxref = 0;
-                                maxref = max(maxref, UNI(s.cref[3])); maxref = max(maxref, UNI(s.cref[4])); maxref = max(maxref, UNI(s.cref[6]));
-                                maxref = max(maxref, UNI(s.cref[8])); maxref = max(maxref, UNI(s.cref[11])); maxref = max(maxref, UNI(s.cref[27]));
+                                maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 3)); maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 4)); maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 6));
+                                maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 8)); maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 11)); maxref = max(maxref, __builtin_amdgcn_readlane(cref_v, 27));
                             }
                             for (int i = 0; i < 4; i++) {
                                 int bcost = 0x7fffffff, bvx = 0, bvy = 0, bcm = 0, br = 0, bpx = 0, bpy = 0;

@@ -17,10 +17,15 @@
 // cross-row traffic stays inside one L2.  Every wait is bounded: a wave that spins too long raises
 // the abort flag and every wave leaves, so the grid always drains.
 //
-// Inside a macroblock all 64 lanes work on the same block: 4 luma pixels per lane for prediction and
-// SAD, 32 lanes x 8 pixels for SATD, 16 lanes x one 4x4 block for the transforms; every decision is
-// wave-uniform scalar state.  Built so far: I_16x16 + chroma modes, P_SKIP (fast and early), P 16x16
-// over several references (DIA / HEX, subme 0..5, chroma ME), CQP.
+// Inside a macroblock all 64 lanes work on the same block and every decision is wave-uniform scalar state: 4 luma pixels
+// per lane for prediction and SAD, one lane per 8x4 block for SATD, one lane per coefficient for the 4x4 transform, a lane
+// per column / row for the 8x8 one; the motion search scores one candidate per lane group and ranks a trip's candidates
+// with one packed key (me_exact.h); intra 4x4 / 8x8 modes are read out of a per-block table through a compile-time LUT
+// (intra_pred.h); the motion cache and the partition candidates live in lane-indexed registers.
+// Built: I_16x16 / I_8x8 / I_4x4 + chroma modes, P_SKIP (fast and early), P 16x16 / 16x8 / 8x16 / 8x8 over several
+// references with or without mixed references (DIA / HEX / UMH, subme 0..5, chroma ME), 4x4 / 8x8 transform choice, CQP.
+// The lane id is laundered once per macroblock and at phase boundaries (LAUNDER): otherwise every lane-derived address of the
+// 60k-instruction body is hoisted out of the macroblock loop and spilled.
 #include <cstring>
 #include "me_exact.h"
 #include "intra_pred.h"

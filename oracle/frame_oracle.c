@@ -404,6 +404,7 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
         ucost1 = bcost;
         DIA1(pmx, pmy);
         if (pmx | pmy) DIA1(0, 0);
+        if (c->pix == X264HIP_PIXEL_4x4) { do_hex = 1; goto umh_end; }   /* "if(i_pixel == PIXEL_4x4) goto me_hex2", me.c:323 */
         ucost2 = bcost;
         if ((bmx | bmy) && ((bmx - pmx) | (bmy - pmy))) { int tx = bmx, ty = bmy; DIA1(tx, ty); }
         if (bcost == ucost2) cross_start = 3;
@@ -450,6 +451,7 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
             } while (++i <= hex_range / 4);
             if (bmy <= c->fmax[1]) do_hex = 1;
         }
+umh_end:;
 #undef SAD_THRESH
 #undef X4
 #undef DIA1
@@ -845,6 +847,8 @@ static void db_edge_intra(u8 *p1, u8 *p2, int stride, int qp, int chroma, int a_
     if (chroma) f(p2, stride, alpha, beta);
 }
 
+/* mb_type: 0 inter, 1 intra, 2 P_SKIP, 3 P_8x8 while X264_ANALYSE_PSUB8x8 is on (frame.c:645: only then no_sub8x8 = 0, every
+ * 4-pixel edge segment of that macroblock compares vectors; otherwise only the 8x8 grid does and an odd segment copies its neighbour) */
 void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int sc,
                          const u8 *mb_type, const u8 *qp, const u8 *nnz, const u8 *t8x8, const i16 *mv, const int8_t *ref,
                          int a_off, int b_off, int cqp_off)
@@ -854,7 +858,7 @@ void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int
     const u8 *cqt = db_chroma_qp + 12 + cqp_off;
     for (int mby = 0; mby < mb_h; mby++)
         for (int mbx = 0; mbx < mb_w; mbx++) {
-            int mb = mby * mb_w + mbx, t8 = t8x8[mb], q = qp[mb];
+            int mb = mby * mb_w + mbx, t8 = t8x8[mb], q = qp[mb], no_sub8x8 = mb_type[mb] != 3;
             int edge_end = (mb_type[mb] == 2 || q <= qp_thresh) ? 1 : 4;
             u8 *piy = py + 16 * mby * sy + 16 * mbx, *piu = pu + 8 * mby * sc + 8 * mbx, *piv = pv + 8 * mby * sc + 8 * mbx;
             for (int dir = 0; dir < 2; dir++) {
@@ -880,8 +884,8 @@ void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int
                                 int x = dir == 0 ? edge : i, y = dir == 0 ? i : edge;
                                 int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
                                 if (nnz[mb * 26 + z_of(x, y)] || nnz[mbn * 26 + z_of(xn, yn)]) bS[i] = 2;
-                                else if (!(edge & 1)) {
-                                    if ((i & 1) && bS[i - 1] != 2) bS[i] = bS[i - 1];
+                                else if (!(edge & no_sub8x8)) {
+                                    if ((i & no_sub8x8) && bS[i - 1] != 2) bS[i] = bS[i - 1];
                                     else {
                                         const i16 *mp = mv + (mb * 16 + x + 4 * y) * 2, *mq = mv + (mbn * 16 + xn + 4 * yn) * 2;
                                         int rp = ref[mb * 4 + (x >> 1) + (y >> 1) * 2], rq = ref[mbn * 4 + (xn >> 1) + (yn >> 1) * 2];

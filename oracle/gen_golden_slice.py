@@ -30,6 +30,9 @@ CASES = [
                                                   mixed_refs=1, cabac=1, deblock=1)),
     ("umh", (208, 144), 4, "static", dict(qp=28, subme=5, me_method=rs.ME_UMH, n_refs=2, inter=0x13, intra=0x3, transform8x8=1,
                                             mixed_refs=1, cabac=1, deblock=1)),
+    ("sub8x8", (208, 144), 4, "moving", dict(qp=22, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x33, intra=0x3, transform8x8=1,
+                                               mixed_refs=1, cabac=1, deblock=1)),
+    ("sub8x8_umh", (200, 120), 4, "static", dict(qp=24, subme=3, me_method=rs.ME_UMH, inter=0x30, n_refs=2, deblock=1, chroma_me=0)),
     ("umh_fpel", (200, 120), 4, "moving", dict(qp=32, subme=1, me_method=rs.ME_UMH, me_range=24, inter=0x10, n_refs=2, deblock=1)),
 ]
 

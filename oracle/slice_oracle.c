@@ -39,7 +39,7 @@ typedef struct {
 
 /* mb types / partitions / slice types with the reference's numbering (R/common/macroblock.h:55-102, R/common/common.h:128-134) */
 enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6 };
-enum { S_D_L0_8x8 = 3, S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
+enum { S_D_L0_4x4 = 0, S_D_L0_8x4 = 1, S_D_L0_4x8 = 2, S_D_L0_8x8 = 3, S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
 enum { S_SLICE_P = 0, S_SLICE_I = 2 };
 enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
 #define S_COST_MAX (1 << 28)
@@ -139,7 +139,7 @@ typedef struct {
     int mvx, mvy, ref;                   /* the 16x16 vector */
     int partition;                       /* D_16x16 / D_16x8 / D_8x16 / D_8x8 */
     i16 mv4[16][2];                      /* final vectors per 4x4 block (raster inside the macroblock) and references per 8x8 */
-    int8_t ref8[4];
+    int8_t ref8[4], sub[4];
     int8_t cref[48];                     /* h->mb.cache.ref / mv for list 0, x264_scan8 layout */
     i16 cmv[48][2];
     i16 l0mvc[16][5][2];                 /* a->l0.mvc[ref][0 = 16x16, 1..4 = 8x8 blocks] */
@@ -674,7 +674,7 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
 
 static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by)
 {
-    static const u8 bw[4] = {16, 16, 8, 8}, bh[4] = {16, 8, 16, 8};
+    static const u8 bw[7] = {16, 16, 8, 8, 8, 4, 4}, bh[7] = {16, 8, 16, 8, 4, 8, 4};
     int oy = (16 * m->mby + by) * S->sy + 16 * m->mbx + bx, oc = (8 * m->mby + by / 2) * S->sc + 8 * m->mbx + bx / 2, sp[4], fp[4];
     const sframe *r = S->fref[ref];
     mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, 512, sp, fp);
@@ -722,7 +722,7 @@ static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
 static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
 {
     int subme = S->p->subme, hpel = me_subpel_iters[subme][0], qpel = me_subpel_iters[subme][1];
-    int satd = subme > 1, chroma_me = S->p->chroma_me && subme >= 5;
+    int satd = subme > 1, chroma_me = S->p->chroma_me && subme >= 5 && c->pix <= X264HIP_PIXEL_8x8;   /* b_chroma_me && i_pixel <= PIXEL_8x8, me.c:654 */
     int bx = *pmx, by = *pmy, bc = cost, i, cst;
     if (hpel && subme < 3) {
         int mx = clip3i(mvp[0], c->smin[0], c->smax[0]), my = clip3i(mvp[1], c->smin[1], c->smax[1]);
@@ -753,6 +753,22 @@ static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int 
     }
     *pmx = bx; *pmy = by;
     return bc;
+}
+
+/* x264_mb_analyse_inter_p4x4_chroma, R/encoder/analyse.c:1373-1405: mc_chroma of every sub-block into a 4x4, then mbcmp 4x4 on U and V */
+typedef struct { int mvx, mvy, cost; i16 mvp[2]; } sub_me;
+static int p4x4_chroma(const ssl *S, const smb *m, int ref, int i8, int sub, const sub_me *me)
+{
+    u8 pix1[16 * 8], *pix2 = pix1 + 8;
+    const sframe *r = S->fref[ref];
+    const int oc = (8 * m->mby + 4 * (i8 >> 1)) * S->sc + 8 * m->mbx + 4 * (i8 & 1), oe = 4 * (i8 >> 1) * FENC + 4 * (i8 & 1);
+    const int n = sub == S_D_L0_4x4 ? 4 : 2, w = sub == S_D_L0_8x4 ? 4 : 2, h = sub == S_D_L0_4x8 ? 4 : 2;
+    for (int k = 0; k < n; k++) {
+        const int x = sub == S_D_L0_4x4 ? 2 * (k & 1) : sub == S_D_L0_4x8 ? 2 * k : 0, y = sub == S_D_L0_4x4 ? 2 * (k >> 1) : sub == S_D_L0_8x4 ? 2 * k : 0;
+        mcf.mc_chroma(&pix1[x + y * 16], 16, r->plane[1] + oc + x + y * S->sc, S->sc, me[k].mvx, me[k].mvy, w, h);
+        mcf.mc_chroma(&pix2[x + y * 16], 16, r->plane[2] + oc + x + y * S->sc, S->sc, me[k].mvx, me[k].mvy, w, h);
+    }
+    return (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[1] + oe, FENC, pix1, 16) + (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[2] + oe, FENC, pix2, 16);
 }
 
 static void analyse_mb(ssl *S, smb *m)
@@ -809,6 +825,8 @@ static void analyse_mb(ssl *S, smb *m)
             /* ---- sub-16x16 partitions (X264_ANALYSE_PSUB16x16), R/encoder/analyse.c:2222-2265 ---- */
             struct { int mvx, mvy, cost, cost_mv, ref, ref_cost; i16 mvp[2]; } me8[4], me16x8[2], me8x16[2];
             int cost8x8 = S_COST_MAX, cost16x8 = S_COST_MAX, cost8x16 = S_COST_MAX, part = S_D_16x16;
+            sub_me me4[4][4], me84[4][2], me48[4][2];
+            int sub[4] = {S_D_L0_8x8, S_D_L0_8x8, S_D_L0_8x8, S_D_L0_8x8};
             i_cost = best;
             if (p->inter & 0x10) {
                 m->partition = S_D_8x8;
@@ -855,6 +873,45 @@ static void analyse_mb(ssl *S, smb *m)
                     if (p->cabac) cost8x8 -= ref_cost;
                 }
                 if (cost8x8 < best) { m->type = S_P_8x8; part = S_D_8x8; i_cost = cost8x8; }
+                if ((p->inter & 0x20) && m->type == S_P_8x8) {       /* X264_ANALYSE_PSUB8x8, :2252-2277 with _p4x4 / _p8x4 / _p4x8 (:1407-1519) */
+                    static const int subw[3] = {1, 2, 1}, subh[3] = {1, 1, 2}, subn[3] = {4, 2, 2}, subpix[3] = {6, 4, 5}, subbits[3] = {5, 3, 3};
+                    m->partition = S_D_8x8;
+                    for (int i = 0; i < 4; i++) {
+                        const int r = me8[i].ref, x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
+                        int c8 = 0, costs[3];
+                        for (int t = 0; t < 3; t++) {                /* D_L0_4x4, then (only if that beats the 8x8) D_L0_8x4 and D_L0_4x8 */
+                            sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                            int sum = 0;
+                            for (int k = 0; k < subn[t]; k++) {
+                                const int x4 = x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y4 = y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0), idx = 4 * i + (y4 - y0) * 2 + (x4 - x0);
+                                me_ctx c; i16 mvp[2], mvc1[1][2]; int mx, my, cmv = 0;
+                                mvc1[0][0] = t == 0 ? me8[i].mvx : me4[i][0].mvx; mvc1[0][1] = t == 0 ? me8[i].mvy : me4[i][0].mvy;
+                                predict_mv_blk(m, idx, subw[t], mvp);
+                                set_me_ctx_blk(S, m, r, mvp, &c, subpix[t], 4 * x4, 4 * y4);
+                                me[k].cost = me_search16(&c, mvp, (const i16 (*)[2])mvc1, k == 0, p->me_method, p->me_range, p->subme, 0, 0, &mx, &my, &cmv);
+                                me[k].mvx = mx; me[k].mvy = my; me[k].mvp[0] = mvp[0]; me[k].mvp[1] = mvp[1];
+                                cache_set(m, x4, y4, subw[t], subh[t], r, mx, my, 1);
+                                sum += me[k].cost;
+                            }
+                            costs[t] = sum + S->ref_cost[r] + S->lambda * subbits[t];
+                            if (p->chroma_me && p->subme >= 5) costs[t] += p4x4_chroma(S, m, r, i, t, me);
+                            if (t == 0) {
+                                if (!(costs[0] < me8[i].cost)) break;
+                                c8 = costs[0]; sub[i] = S_D_L0_4x4;
+                            } else if (costs[t] < c8) { c8 = costs[t]; sub[i] = t; }
+                        }
+                        if (sub[i] != S_D_L0_8x8) i_cost += c8 - me8[i].cost;
+                        /* x264_mb_cache_mv_p8x8 */
+                        if (sub[i] == S_D_L0_8x8) cache_set(m, x0, y0, 2, 2, r, me8[i].mvx, me8[i].mvy, 1);
+                        else {
+                            const int t = sub[i];
+                            const sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                            for (int k = 0; k < subn[t]; k++)
+                                cache_set(m, x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0), subw[t], subh[t], r, me[k].mvx, me[k].mvy, 1);
+                        }
+                    }
+                    cost8x8 = i_cost;
+                }
                 const int thresh16x8 = me8[1].cost_mv + me8[2].cost_mv;
                 if (cost8x8 < best + thresh16x8) {
                     for (int dir = 0; dir < 2; dir++) {              /* 0: x264_mb_analyse_inter_p16x8 (:1274), 1: _p8x16 (:1324) */
@@ -901,6 +958,22 @@ static void analyse_mb(ssl *S, smb *m)
             } else {
                 i_cost = 0;
                 for (int i = 0; i < (part == S_D_8x8 ? 4 : 2); i++) {
+                    if (part == S_D_8x8 && sub[i] != S_D_L0_8x8) {   /* the sub-8x8 blocks: no reference cost in their sums, no chroma (me.c:639, :654) */
+                        static const int subw[3] = {1, 2, 1}, subh[3] = {1, 1, 2}, subn[3] = {4, 2, 2}, subpix[3] = {6, 4, 5};
+                        const int t = sub[i], x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
+                        sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                        for (int k = 0; k < subn[t]; k++) {
+                            const int x4 = x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y4 = y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0);
+                            me_ctx c;
+                            set_me_ctx_blk(S, m, me8[i].ref, me[k].mvp, &c, subpix[t], 4 * x4, 4 * y4);
+                            me[k].cost = refine_qpel16(S, &c, me[k].cost, &me[k].mvx, &me[k].mvy, me[k].mvp);
+                            i_cost += me[k].cost;
+                            for (int y = 0; y < subh[t]; y++)
+                                for (int x = 0; x < subw[t]; x++) { m->mv4[(y4 + y) * 4 + x4 + x][0] = me[k].mvx; m->mv4[(y4 + y) * 4 + x4 + x][1] = me[k].mvy; }
+                        }
+                        m->ref8[i] = me8[i].ref;
+                        continue;
+                    }
                     typeof(me8[0]) *d = part == S_D_8x8 ? &me8[i] : part == S_D_16x8 ? &me16x8[i] : &me8x16[i];
                     const int pix = part == S_D_8x8 ? X264HIP_PIXEL_8x8 : part == S_D_16x8 ? X264HIP_PIXEL_16x8 : X264HIP_PIXEL_8x16;
                     const int bx = part == S_D_8x8 ? 8 * (i & 1) : part == S_D_8x16 ? 8 * i : 0, by = part == S_D_8x8 ? 8 * (i >> 1) : part == S_D_16x8 ? 8 * i : 0;
@@ -916,6 +989,7 @@ static void analyse_mb(ssl *S, smb *m)
                 }
             }
             m->mvx = bmx; m->mvy = bmy; m->ref = bref;
+            for (int i = 0; i < 4; i++) m->sub[i] = part == S_D_8x8 ? sub[i] : S_D_L0_8x8;
             (void)cost16x8; (void)cost8x16;
             if (chroma_me) {
                 analyse_intra_chroma(S, m);
@@ -959,7 +1033,9 @@ static void update_mb(ssl *S, smb *m)
     default:
         break;
     }
-    if ((m->type == S_P_L0 || m->type == S_P_8x8) && S->p->transform8x8) {
+    /* x264_mb_transform_8x8_allowed (R/common/macroblock.h): a P_8x8 macroblock only with four 8x8 sub-partitions */
+    if ((m->type == S_P_L0 || (m->type == S_P_8x8 && m->sub[0] == S_D_L0_8x8 && m->sub[1] == S_D_L0_8x8 && m->sub[2] == S_D_L0_8x8 && m->sub[3] == S_D_L0_8x8))
+        && S->p->transform8x8) {
         mc_parts(S, m);
         int c8 = pixf.sa8d[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
         int c4 = pixf.satd[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
@@ -1045,7 +1121,7 @@ static void save_mb(ssl *S, smb *m)
     if (intra) S->intra_count++;
 
     o->mb_type[M] = m->type; o->partition[M] = intra || m->type == S_P_SKIP ? S_D_16x16 : m->partition;
-    memset(o->sub_partition + M * 4, m->type == S_P_8x8 ? S_D_L0_8x8 : 0, 4);
+    for (int i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = m->type == S_P_8x8 ? m->sub[i] : 0;
     memcpy(o->nnz + M * 27, m->nnz, 27);
     o->qp[M] = S->qp;
     o->cbp[M] = m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
@@ -1082,7 +1158,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     sframe *refs[16] = {0};
     int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
     s_setup();
-    if ((p->inter & 0x20) || p->subme > 5 || p->me_method > 2) return -3;
+    if (p->subme > 5 || p->me_method > 2) return -3;
     memset(&S, 0, sizeof(S));
     S.p = p; S.o = o;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;
@@ -1141,7 +1217,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
             u8 *t = malloc(S.n), *q = malloc(S.n), *t8 = malloc(S.n), *nz = malloc(S.n * 26);
             for (int mb = 0; mb < S.n; mb++) {
                 int ty = o->mb_type[F * S.n + mb];
-                t[mb] = S_IS_INTRA(ty) ? 1 : ty == S_P_SKIP ? 2 : 0;
+                t[mb] = S_IS_INTRA(ty) ? 1 : ty == S_P_SKIP ? 2 : ty == S_P_8x8 && (p->inter & 0x20) ? 3 : 0;
                 q[mb] = (u8)o->qp[F * S.n + mb]; t8[mb] = (u8)S.t8[mb];
                 memcpy(nz + mb * 26, S.nnz + mb * 27, 24); nz[mb * 26 + 24] = S.nnz[mb * 27 + 25]; nz[mb * 26 + 25] = S.nnz[mb * 27 + 26];
             }

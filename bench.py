@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--subme", type=int, default=5)
     ap.add_argument("--me", type=int, default=1, help="param.analyse.i_me_method: 0 dia, 1 hex (the medium preset), 2 umh")
     ap.add_argument("--keyint", type=int, default=24)
-    ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x13, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 | PSUB16x16 0x10 "
-                    "(PSUB8x8 0x20 is not built)")
+    ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x13, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 | PSUB16x16 0x10 | "
+                    "PSUB8x8 0x20 (the medium preset's p8x8 = 0x10; 0x33 adds p4x4 / p8x4 / p4x8)")
     ap.add_argument("--mixed-refs", type=int, default=1, help="param.analyse.b_mixed_references")
     ap.add_argument("--intra", type=lambda v: int(v, 0), default=0x3, help="param.analyse.intra")
     ap.add_argument("--dct8", type=int, default=1, help="param.analyse.b_transform_8x8")

@@ -214,7 +214,7 @@ int x264hip_me_search16_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc,
  * R/common/predict.h:31-107, nnz index = block index of x264_scan8 (0-15 luma, 16-23 chroma AC,
  * 24 luma DC, 25/26 chroma DC).  Levels are in scan order and zero wherever cbp / nnz say "not coded". */
 typedef struct {
-    int8_t  *mb_type, *partition;
+    int8_t  *mb_type, *partition, *sub_partition;   /* sub_partition [mb][4]: D_L0_4x4 0, 8x4 1, 4x8 2, 8x8 3 of each 8x8 block of a P_8x8 macroblock */
     int8_t  *ref;          /* [n][4] per 8x8; -1 intra */
     int8_t  *i4mode;       /* [n][16] intra 4x4 / 8x8 modes by block index; I_PRED_4x4_DC elsewhere */
     int8_t  *i16mode, *chroma_mode, *qp, *t8;
@@ -317,7 +317,7 @@ int x264hip_probe_skip_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, 
  * Macroblocks are filtered in the standard's order (raster; vertical then
  * horizontal edges): the frame is swept in 2:1 anti-diagonals, one launch per
  * diagonal, because MB (x,y) needs (x-1,y) and (x+1,y-1) finished.
- *   mb_type : [mb] u8, 0 inter, 1 intra, 2 P_SKIP ; qp : [mb] u8 ;
+ *   mb_type : [mb] u8, 0 inter, 1 intra, 2 P_SKIP, 3 P_8x8 with sub-8x8 analysis on ; qp : [mb] u8 ;
  *   nnz : [mb][26] as x264hip_inter_residual_frame writes it ;
  *   mv : [mb][16][2] int16 qpel per 4x4 block in raster order ;
  *   ref : [mb][4] int8 per 8x8 ; transform8x8 : [mb] u8 (all device) */
@@ -327,6 +327,8 @@ typedef struct {
     const int8_t  *ref;
     int alpha_c0_offset, beta_offset, chroma_qp_offset;
     int state_layout;      /* 0: compact codes above, nnz [mb][26]; 1: the arrays of an x264hip_mb_state (reference type numbers, nnz [mb][27]) */
+    int sub8x8;            /* param.analyse.inter & X264_ANALYSE_PSUB8x8: P_8x8 macroblocks (layout 1: type 5; layout 0: code 3) compare vectors
+                            * on every 4-pixel edge segment (no_sub8x8 = 0, R/common/frame.c:645) */
 } x264hip_deblock_params;
 int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x264hip_deblock_params *p);
 

@@ -12,7 +12,7 @@ from oracle import refslice as rs
 from oracle.gen_golden_slice import case_inputs
 from x264_vs2008_amd import lib as L, slice as sl
 
-STATE = ["mb_type", "partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc", "chroma_dc", "chroma_ac"]
+STATE = ["mb_type", "partition", "sub_partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc", "chroma_dc", "chroma_ac"]
 
 
 def run_gpu(hip, cqm, size, frames, y, u, v, kw):
@@ -47,7 +47,7 @@ def main():
         w, h = int(r.integers(5, 16)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(5, 11)) * 16 - int(r.integers(0, 2)) * 8
         frames = int(r.integers(3, 6))
         kw = dict(qp=int(r.integers(18, 42)), subme=int(r.integers(0, 6)), me_method=int(r.integers(0, 3)), me_range=int(r.choice([8, 16, 24])),
-                  n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),
+                  n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13, 0x30, 0x33])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),
                   transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=int(r.integers(0, 2)), deblock=int(r.integers(0, 2)),
                   fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])))
         if not kw["transform8x8"]:

@@ -14,8 +14,8 @@ from x264_vs2008_amd import slice as sl
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [c for c in CASES if not (c[4].get("inter", 0) & 0x20)]        # everything but sub-8x8 inter partitions
-STATE = ["mb_type", "partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc",
+SUPPORTED = list(CASES)
+STATE = ["mb_type", "partition", "sub_partition", "ref", "i4mode", "i16mode", "chroma_mode", "qp", "t8", "mv", "cbp", "nnz", "luma", "luma_dc",
          "chroma_dc", "chroma_ac"]
 
 
@@ -141,7 +141,7 @@ def _random_case(seed):
     w, h = int(r.integers(5, 16)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(5, 11)) * 16 - int(r.integers(0, 2)) * 8
     frames = int(r.integers(3, 6))
     kw = dict(qp=int(r.integers(18, 42)), subme=int(r.integers(0, 6)), me_method=int(r.integers(0, 3)), me_range=int(r.choice([8, 16, 24])),
-              n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),
+              n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13, 0x30, 0x33])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),
               transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=int(r.integers(0, 2)), deblock=int(r.integers(0, 2)),
               fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])))
     if not kw["transform8x8"]:

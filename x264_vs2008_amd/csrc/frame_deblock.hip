@@ -43,7 +43,8 @@ static __constant__ u8 c_chroma_qp[76] = {
 struct DbGeom {
     int mb_w, mb_h, sy, sc, a_off, b_off, cqp_off, diag, y_min, count;
     size_t bs_y, bs_c;  // bytes between batch elements
-    int layout;         // 0: compact type codes (0 inter 1 intra 2 skip), nnz[26]; 1: x264hip_mb_state (reference numbering, nnz[27])
+    int layout;         // 0: compact type codes (0 inter 1 intra 2 skip 3 P_8x8 with sub-8x8 on), nnz[26]; 1: x264hip_mb_state (reference numbering, nnz[27])
+    int sub8x8;         // X264_ANALYSE_PSUB8x8 is on
 };
 
 __device__ __forceinline__ int z_of(int x, int y) { return (y >> 1) * 8 + (x >> 1) * 4 + (y & 1) * 2 + (x & 1); }
@@ -120,8 +121,10 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0); \
                          __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
     const int ns = g.layout ? 27 : 26;
-#define DB_TYPE(t_) (g.layout ? ((t_) <= 3 ? 1 : (t_) == 6 ? 2 : 0) : (int)(t_))
+#define DB_TYPE(t_) (g.layout ? ((t_) <= 3 ? 1 : (t_) == 6 ? 2 : 0) : (int)(t_) == 3 ? 0 : (int)(t_))
     const int q = qp[mb], t8 = t8x8[mb], type = DB_TYPE(mb_type[mb]);
+    // no_sub8x8 (frame.c:645): 0 only for a P_8x8 macroblock while sub-8x8 partitions are analysed
+    const int no_sub = g.layout ? !(g.sub8x8 && mb_type[mb] == 5) : mb_type[mb] != 3;
     const int qp_thresh = 15 - (g.a_off < g.b_off ? g.a_off : g.b_off) - (g.cqp_off > 0 ? g.cqp_off : 0);
     const int edge_end = (type == 2 || q <= qp_thresh) ? 1 : 4;
 
@@ -144,8 +147,8 @@ __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__
                     int xn = dir == 0 ? (x - 1) & 3 : x, yn = dir == 0 ? y : (y - 1) & 3;
                     int b = 0;
                     if (nnz[mb * ns + z_of(x, y)] || nnz[mbn * ns + z_of(xn, yn)]) b = 2;
-                    else if (!(edge & 1)) {
-                        if ((j & 1) && prev != 2) b = prev;
+                    else if (!(edge & no_sub)) {
+                        if ((j & no_sub) && prev != 2) b = prev;
                         else {
                             const i16 *mp = mv + ((size_t)mb * 16 + x + 4 * y) * 2, *mq = mv + ((size_t)mbn * 16 + xn + 4 * yn) * 2;
                             int rp = ref[mb * 4 + (x >> 1) + (y >> 1) * 2], rq = ref[mbn * 4 + (xn >> 1) + (yn >> 1) * 2];
@@ -232,7 +235,7 @@ extern "C" int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *reco
     DbGeom g;
     g.mb_w = c->d.mb_w; g.mb_h = c->d.mb_h; g.sy = c->d.stride_y; g.sc = c->d.stride_c;
     g.bs_y = c->bs_y; g.bs_c = c->bs_c;
-    g.a_off = p->alpha_c0_offset; g.b_off = p->beta_offset; g.cqp_off = p->chroma_qp_offset; g.layout = p->state_layout ? 1 : 0;
+    g.a_off = p->alpha_c0_offset; g.b_off = p->beta_offset; g.cqp_off = p->chroma_qp_offset; g.layout = p->state_layout ? 1 : 0; g.sub8x8 = p->sub8x8 != 0;
     if (g.a_off < -12 || g.a_off > 12 || g.b_off < -12 || g.b_off > 12 || g.cqp_off < -12 || g.cqp_off > 12) {
         set_error("deblock: offsets out of range");
         return -1;

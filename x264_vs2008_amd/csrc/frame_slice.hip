@@ -55,7 +55,7 @@ struct SwArgs {
     int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS];
     int l0_n_ref0, l0_inv_ref_poc[SW_MAX_REFS];
     int me_method, me_range, subme, chroma_me, fast_pskip, dct_decimate, cabac, mv_range;
-    int flags_inter, mixed_refs; // X264_ANALYSE_PSUB16x16 (0x10) of param.analyse.inter; param.analyse.b_mixed_references
+    int flags_inter, mixed_refs; // X264_ANALYSE_PSUB16x16 (0x10) / PSUB8x8 (0x20) of param.analyse.inter; param.analyse.b_mixed_references
     int flags_intra;            // X264_ANALYSE_I4x4 | I8x8 bits that apply to this slice type (param.analyse.intra / .inter)
     int transform8x8;
     const u16 *q4mf, *q4bias, *q8mf, *q8bias;
@@ -66,7 +66,7 @@ struct SwArgs {
     u8 *dy, *du, *dv;
     const signed char *l0_type, *l0_ref;
     const i16 *l0_mv;
-    signed char *mb_type, *partition, *ref, *i4mode, *i16mode, *chroma_mode, *qp_out, *t8;
+    signed char *mb_type, *partition, *sub_partition, *ref, *i4mode, *i16mode, *chroma_mode, *qp_out, *t8;
     i16 *mv, *mvr, *cbp;
     u8 *nnz;
     i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
@@ -908,6 +908,29 @@ __device__ __forceinline__ int sw_sa8d_rows_d(const int d[8], int lane)
     return half_sum8((int)((acc & 0xffffu) + (acc >> 16)));
 }
 
+// x264_mb_analyse_inter_p4x4_chroma (R/encoder/analyse.c:1373-1405): mc_chroma of the 8x8 block's sub-partitions into one 4x4 per
+// plane, then mbcmp 4x4 against the source.  Lane = plane * 4 + row (lanes 8.. repeat the work); every pixel takes the vector
+// of the sub-block that covers it (sub = 0 four 2x2, 1 two 4x2, 2 two 2x4), read from the lane-indexed records at rec0 + k.
+__device__ __forceinline__ int sw_sub_chroma(const SwLds &s, const SwRefs &refs, const SwArgs &a, int r, int i8, int sub, int rec0, int sub_mx, int sub_my,
+                                             int satd, ptrdiff_t oc, size_t bc, int lane)
+{
+    const int pl = (lane >> 2) & 1, y = lane & 3;
+    const u8 *plane = (pl ? refs.v[r] : refs.u[r]) + bc + oc + 4 * (i8 & 1) + (ptrdiff_t)(4 * (i8 >> 1)) * a.sc;
+    const u8 *src = s.fe + 256 + 64 * pl + (4 * (i8 >> 1) + y) * 8 + 4 * (i8 & 1);
+    int d[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const int k = sub == 0 ? (y >> 1) * 2 + (x >> 1) : sub == 1 ? (y >> 1) : (x >> 1);
+        const int mvx = __shfl(sub_mx, rec0 + k, 64), mvy = __shfl(sub_my, rec0 + k, 64);
+        const int dx = mvx & 7, dy = mvy & 7;
+        const u8 *p = plane + (ptrdiff_t)(y + (mvy >> 3)) * a.sc + x + (mvx >> 3);
+        const int v = ((8 - dx) * (8 - dy) * p[0] + dx * (8 - dy) * p[1] + (8 - dx) * dy * p[a.sc] + dx * dy * p[a.sc + 1] + 32) >> 6;
+        d[x] = (int)src[x] - v;
+    }
+    const int c4 = sw_cost4x4_rows(d[0], d[1], d[2], d[3], satd, lane);
+    return __builtin_amdgcn_readlane(c4, 0) + __builtin_amdgcn_readlane(c4, 4);
+}
+
 __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // WPE = waves per SIMD the register allocation is held to.  A row wave spends most of its time waiting
@@ -923,7 +946,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     const size_t nmb = (size_t)a.mb_w * a.mb_h, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
     // batch element
     a.fy += by_; a.fu += bc_; a.fv += bc_; a.dy += by_; a.du += bc_; a.dv += bc_;
-    a.mb_type += nmb * bz; a.partition += nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz; a.i16mode += nmb * bz;
+    a.mb_type += nmb * bz; a.partition += nmb * bz; a.sub_partition += 4 * nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz; a.i16mode += nmb * bz;
     a.chroma_mode += nmb * bz; a.qp_out += nmb * bz; a.t8 += nmb * bz; a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
     a.cbp += nmb * bz; a.nnz += 27 * nmb * bz; a.luma += 256 * nmb * bz; a.luma_dc += 16 * nmb * bz; a.chroma_dc += 8 * nmb * bz;
     a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz; a.cost_alt += nmb * bz;
@@ -1023,6 +1046,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = UNI(a.mb_type[mb - a.mb_w - 1]); }
 
         int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0, part = 16;
+        int sub_t_mb = 3;                    // lanes 0..3: h->mb.i_sub_partition[] (D_L0_4x4 0, 8x4 1, 4x8 2, 8x8 3)
         int satd_i16 = MX_COST_MAX, satd_chroma = MX_COST_MAX, pskx = 0, psky = 0;
         int satd_i8 = MX_COST_MAX, satd_i4 = MX_COST_MAX, i8_cbp = 0, i4_cbp = 0, t8 = 0, fi_open = 0, stat_alt = -1;
         if (a.flags_intra & 3) {
@@ -1219,6 +1243,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             // the register file as lane-indexed arrays: entry k = lane k of a VGPR, read with v_readlane (uniform index), written
             // by the lane itself or with v_writelane -- no LDS round trip, no barrier.
             int cref_v = -2, cmvx_v = 0, cmvy_v = 0, pme_v = 0;
+            int sub_mx = 0, sub_my = 0, sub_cost = 0, sub_px = 0, sub_py = 0, sub_t = 3;      // sub-8x8 records (lanes 0..31) and chosen type (lanes 0..3)
             if (a.flags_inter & 0x10) {
                 // the full motion cache for x264_mb_predict_mv on partitions: -2 = not available, neighbours as cache_load leaves them
                 if ((nb & NB_TOP) && lane >= 4 && lane < 8) {
@@ -1414,6 +1439,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             if (a.cabac) cost8x8 -= ref_cost;
                         }
                         if (cost8x8 < best) { type = T_P_8x8; part = 13; i_cost = cost8x8; }
+                        if ((a.flags_inter & 0x20) && type == T_P_8x8) {
+                            // ---- X264_ANALYSE_PSUB8x8 (R/encoder/analyse.c:2252-2277): p4x4, and only if that beats the 8x8 block, p8x4 and p4x8
+                            // (:1407-1519).  Records (mv, cost, mvp) of me4x4[i][k] / me8x4[i][k] / me4x8[i][k] sit in lanes 4i+k / 16+2i+k / 24+2i+k.
+                            MeOpts mo_sub = mo;
+                            mo_sub.chroma_me = 0;                        // b_chroma_me && i_pixel <= PIXEL_8x8, me.c:654
+                            for (int i = 0; i < 4; i++) {
+                                const int r = pme(i, 4), x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
+                                int c8 = 0, subt = 3;
+                                for (int t = 0; t < 3; t++) {
+                                    const int sw = t == 1 ? 2 : 1, sh = t == 2 ? 2 : 1, sn = t == 0 ? 4 : 2, rec0 = t == 0 ? 4 * i : t == 1 ? 16 + 2 * i : 24 + 2 * i;
+                                    const int cvx = t == 0 ? pme(i, 0) : __builtin_amdgcn_readlane(sub_mx, 4 * i), cvy = t == 0 ? pme(i, 1) : __builtin_amdgcn_readlane(sub_my, 4 * i);
+                                    int sum = 0;
+                                    for (int k = 0; k < sn; k++) {
+                                        const int x4 = x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y4 = y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0);
+                                        const int idx = 4 * i + (y4 - y0) * 2 + (x4 - x0);
+                                        int px, py, vx, vy, cm;
+                                        predict_blk(13, idx, sw, px, py);
+                                        aim(r, 4 * sw, 4 * sh, 4 * x4, 4 * y4);
+                                        c.mvpx = px; c.mvpy = py;
+                                        WAVE_SYNC();
+                                        if (lane < 2) s.mvc[0][lane] = (i16)(lane ? cvy : cvx);
+                                        WAVE_SYNC();
+                                        LAUNDER(); c.lane = lane;
+                                        const int cost = me_search_ref16(c, L, mo_sub, &s.mvc[0][0], k == 0 ? 1 : 0, nullptr, vx, vy, cm);
+                                        if (lane == rec0 + k) { sub_mx = vx; sub_my = vy; sub_cost = cost; sub_px = px; sub_py = py; }
+                                        cache_set(x4, y4, sw, sh, r, vx, vy, 1);
+                                        sum += cost;
+                                    }
+                                    int cst = sum + a.ref_cost[r] + a.lambda * (t == 0 ? 5 : 3);          // i_sub_mb_p_cost_table
+                                    if (a.chroma_me && a.subme >= 5) cst += sw_sub_chroma(s, refs, a, r, i, t, rec0, sub_mx, sub_my, satd, oc, bc_, lane);
+                                    if (t == 0) {
+                                        if (!(cst < pme(i, 2))) break;
+                                        c8 = cst; subt = 0;
+                                    } else if (cst < c8) { c8 = cst; subt = t; }
+                                }
+                                if (subt != 3) i_cost += c8 - pme(i, 2);
+                                // x264_mb_cache_mv_p8x8
+                                if (subt == 3) cache_set(x0, y0, 2, 2, r, pme(i, 0), pme(i, 1), 1);
+                                else {
+                                    const int sw = subt == 1 ? 2 : 1, sh = subt == 2 ? 2 : 1, sn = subt == 0 ? 4 : 2, rec0 = subt == 0 ? 4 * i : subt == 1 ? 16 + 2 * i : 24 + 2 * i;
+                                    for (int k = 0; k < sn; k++)
+                                        cache_set(x0 + (subt == 0 ? (k & 1) : subt == 2 ? k : 0), y0 + (subt == 0 ? (k >> 1) : subt == 1 ? k : 0), sw, sh, r,
+                                                  __builtin_amdgcn_readlane(sub_mx, rec0 + k), __builtin_amdgcn_readlane(sub_my, rec0 + k), 1);
+                                }
+                                if (lane == i) sub_t = subt;
+                            }
+                            cost8x8 = i_cost;
+                        }
                         const int thresh16x8 = pme(1, 3) + pme(2, 3);
                         if (cost8x8 < best + thresh16x8)
                             for (int dir = 0; dir < 2; dir++) {      // 0: x264_mb_analyse_inter_p16x8 (:1274), 1: _p8x16 (:1324)
@@ -1458,25 +1531,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         i_cost = 0;
                         const int nblk = part == 13 ? 4 : 2, slot0 = part == 13 ? 0 : part == 14 ? 4 : 6;
                         for (int i = 0; i < nblk; i++) {
-                            const int bx = part == 13 ? 8 * (i & 1) : part == 15 ? 8 * i : 0, by = part == 13 ? 8 * (i >> 1) : part == 14 ? 8 * i : 0;
-                            const int w = part == 14 ? 16 : 8, h = part == 15 ? 16 : 8, r = pme(slot0 + i, 4);
-                            int vx = pme(slot0 + i, 0), vy = pme(slot0 + i, 1);
-                            aim(r, w, h, bx, by);
-                            c.mvpx = pme(slot0 + i, 6); c.mvpy = pme(slot0 + i, 7);
-                            LAUNDER(); c.lane = lane;
-                            i_cost += me_refine_qpel16(c, L, mo, pme(slot0 + i, 2) - pme(slot0 + i, 5), vx, vy);
-                            WAVE_SYNC();
-                            if (lane < 16) {
-                                const int x4 = (lane & 3) * 4, y4 = (lane >> 2) * 4;
-                                if (x4 >= bx && x4 < bx + w && y4 >= by && y4 < by + h) { s.mv4[lane][0] = (i16)vx; s.mv4[lane][1] = (i16)vy; }
-                            }
-                            if (lane < 4) {
-                                const int x8 = (lane & 1) * 8, y8 = (lane >> 1) * 8;
-                                if (x8 >= bx && x8 < bx + w && y8 >= by && y8 < by + h) s.ref8[lane] = (signed char)r;
+                            // an 8x8 block of a P_8x8 macroblock refines its sub-partitions (analyse.c:2317-2352): no reference cost in their
+                            // sums and no chroma (me.c:639, :654)
+                            const int subt = part == 13 ? __builtin_amdgcn_readlane(sub_t, i) : 3, nj = subt == 3 ? 1 : subt == 0 ? 4 : 2;
+                            for (int k = 0; k < nj; k++) {
+                                int bx = part == 13 ? 8 * (i & 1) : part == 15 ? 8 * i : 0, by = part == 13 ? 8 * (i >> 1) : part == 14 ? 8 * i : 0;
+                                int w = part == 14 ? 16 : 8, h = part == 15 ? 16 : 8;
+                                const int r = pme(slot0 + i, 4);
+                                int vx = pme(slot0 + i, 0), vy = pme(slot0 + i, 1), cin = pme(slot0 + i, 2) - pme(slot0 + i, 5);
+                                MeOpts mo_r = mo;
+                                c.mvpx = pme(slot0 + i, 6); c.mvpy = pme(slot0 + i, 7);
+                                if (subt != 3) {
+                                    const int rec = (subt == 0 ? 4 * i : subt == 1 ? 16 + 2 * i : 24 + 2 * i) + k;
+                                    bx += 4 * (subt == 0 ? (k & 1) : subt == 2 ? k : 0); by += 4 * (subt == 0 ? (k >> 1) : subt == 1 ? k : 0);
+                                    w = subt == 1 ? 8 : 4; h = subt == 2 ? 8 : 4;
+                                    vx = __builtin_amdgcn_readlane(sub_mx, rec); vy = __builtin_amdgcn_readlane(sub_my, rec); cin = __builtin_amdgcn_readlane(sub_cost, rec);
+                                    c.mvpx = __builtin_amdgcn_readlane(sub_px, rec); c.mvpy = __builtin_amdgcn_readlane(sub_py, rec);
+                                    mo_r.chroma_me = 0;
+                                }
+                                aim(r, w, h, bx, by);
+                                LAUNDER(); c.lane = lane;
+                                i_cost += me_refine_qpel16(c, L, mo_r, cin, vx, vy);
+                                WAVE_SYNC();
+                                if (lane < 16) {
+                                    const int x4 = (lane & 3) * 4, y4 = (lane >> 2) * 4;
+                                    if (x4 >= bx && x4 < bx + w && y4 >= by && y4 < by + h) { s.mv4[lane][0] = (i16)vx; s.mv4[lane][1] = (i16)vy; }
+                                }
+                                if (lane < 4) {
+                                    const int x8 = (lane & 1) * 8, y8 = (lane >> 1) * 8;
+                                    if (x8 >= (bx & ~7) && x8 < (bx & ~7) + (w < 8 ? 8 : w) && y8 >= (by & ~7) && y8 < (by & ~7) + (h < 8 ? 8 : h)) s.ref8[lane] = (signed char)r;
+                                }
                             }
                         }
                     }
                     WAVE_SYNC();
+                    if (part == 13) sub_t_mb = sub_t;
                     PROF(2);
                     LAUNDER();
                     if (a.chroma_me) {
@@ -1567,7 +1656,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             } else {
                 sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
                 WAVE_SYNC();
-                if (a.transform8x8) {
+                // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
+                if (a.transform8x8 && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
                     // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
                     int raw = 0;
                     if (lane < 32) {
@@ -1613,6 +1703,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (lane & 1) s.left_r8[lane >> 1] = rv;
         }
         if (lane < 27) a.nnz[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
+        if (lane < 4) a.sub_partition[(size_t)mb * 4 + lane] = (signed char)(type == T_P_8x8 ? sub_t_mb : 0);
         if (lane == 0) {
             const int cbp_dc = a.cabac ? (s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2) : 0;
             a.mb_type[mb] = (signed char)type;
@@ -1697,7 +1788,7 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
     const size_t n = (size_t)c->d.mb_w * c->d.mb_h * c->batch;
     memset(st, 0, sizeof(*st));
     struct { void **p; size_t bytes; } items[] = {
-        {(void **)&st->mb_type, n}, {(void **)&st->partition, n}, {(void **)&st->ref, 4 * n}, {(void **)&st->i4mode, 16 * n},
+        {(void **)&st->mb_type, n}, {(void **)&st->partition, n}, {(void **)&st->sub_partition, 4 * n}, {(void **)&st->ref, 4 * n}, {(void **)&st->i4mode, 16 * n},
         {(void **)&st->i16mode, n}, {(void **)&st->chroma_mode, n}, {(void **)&st->qp, n}, {(void **)&st->t8, n},
         {(void **)&st->mv, 64 * n}, {(void **)&st->mvr, 4 * SW_MAX_REFS * n}, {(void **)&st->cbp, 2 * n}, {(void **)&st->nnz, 27 * n},
         {(void **)&st->luma, 512 * n}, {(void **)&st->luma_dc, 32 * n}, {(void **)&st->chroma_dc, 16 * n}, {(void **)&st->chroma_ac, 256 * n},
@@ -1712,7 +1803,7 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
 extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st)
 {
     (void)c;
-    void *ps[] = {st->mb_type, st->partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
+    void *ps[] = {st->mb_type, st->partition, st->sub_partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
                   st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress};
     for (void *p : ps) if (p) (void)hipFree(p);
     memset(st, 0, sizeof(*st));
@@ -1728,7 +1819,6 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
     if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
     if (p->me_method < 0 || p->me_method > 2) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX, 2 UMH)", p->me_method); return -1; }
-    if (p->analyse_inter & 0x20) { set_error("slice_sweep: sub-8x8 inter partitions (X264_ANALYSE_PSUB8x8: p4x4 / p8x4 / p4x8) not built yet"); return -1; }
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
@@ -1757,7 +1847,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.q4mf = p->quant4_mf; a.q4bias = p->quant4_bias; a.dq4 = p->dequant4_mf;
     a.q8mf = p->quant8_mf; a.q8bias = p->quant8_bias; a.dq8 = p->dequant8_mf;
     a.transform8x8 = p->transform8x8 != 0;
-    a.flags_inter = is_p ? (p->analyse_inter & 0x10) : 0; a.mixed_refs = p->mixed_refs != 0;
+    a.flags_inter = is_p ? (p->analyse_inter & 0x30) : 0; a.mixed_refs = p->mixed_refs != 0;
     // x264_mb_analyse_intra takes its flags from param.analyse.intra in I slices and from .inter in P slices (analyse.c:614);
     // i8x8 needs the 8x8 transform (x264_validate_parameters, R/encoder/encoder.c:487-491)
     a.flags_intra = (is_p ? p->analyse_inter : p->analyse_intra) & (a.transform8x8 ? 3 : 1);
@@ -1765,7 +1855,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.fy = fenc->plane[0]; a.fu = fenc->plane[1]; a.fv = fenc->plane[2];
     a.dy = recon->plane[0]; a.du = recon->plane[1]; a.dv = recon->plane[2];
     if (l0) { a.l0_type = (const signed char *)l0->mb_type; a.l0_ref = (const signed char *)l0->ref; a.l0_mv = l0->mv; }
-    a.mb_type = (signed char *)out->mb_type; a.partition = (signed char *)out->partition; a.ref = (signed char *)out->ref;
+    a.mb_type = (signed char *)out->mb_type; a.partition = (signed char *)out->partition; a.sub_partition = (signed char *)out->sub_partition;
+    a.ref = (signed char *)out->ref;
     a.i4mode = (signed char *)out->i4mode; a.i16mode = (signed char *)out->i16mode; a.chroma_mode = (signed char *)out->chroma_mode;
     a.qp_out = (signed char *)out->qp; a.t8 = (signed char *)out->t8; a.mv = out->mv; a.mvr = out->mvr; a.cbp = out->cbp; a.nnz = out->nnz;
     a.luma = out->luma; a.luma_dc = out->luma_dc; a.chroma_dc = out->chroma_dc; a.chroma_ac = out->chroma_ac;

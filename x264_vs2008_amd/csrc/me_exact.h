@@ -196,7 +196,8 @@ __device__ __forceinline__ int sad_fpel16_lane(const MxCtx &c, int mx, int my)
         } else {
             u32 r0, r1, t;
             load9u(p, r0, r1, t);
-            s = sad4(r0, f[0], 0); s = sad4(r1, f[1], s);
+            s = sad4(r0, f[0], 0);
+            if (c.bw == 8) s = sad4(r1, f[1], s);
         }
         v = (int)s;
     }
@@ -220,7 +221,8 @@ __device__ __forceinline__ int sad_fpel8_lane(const MxCtx &c, int mx, int my)
             } else {
                 u32 a0, a1, t;
                 load9u(p, a0, a1, t);
-                s = sad4(a0, f[0], s); s = sad4(a1, f[1], s);
+                s = sad4(a0, f[0], s);
+                if (c.bw == 8) s = sad4(a1, f[1], s);
             }
         }
     }
@@ -253,7 +255,7 @@ __device__ __forceinline__ int sad_qpel16_lane(const MxCtx &c, int mx, int my)
                 u32 a0, a1, t;
                 lds9u(pa, a0, a1, t);
                 if (idx & 5) { u32 b0, b1; lds9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
-                s = sad4(a0, f[0], 0); s = sad4(a1, f[1], s);
+                s = sad4(a0, f[0], 0); if (c.bw == 8) s = sad4(a1, f[1], s);
             }
             v = (int)s;
         }
@@ -277,7 +279,7 @@ __device__ __forceinline__ int sad_qpel16_lane(const MxCtx &c, int mx, int my)
             u32 a0, a1, t;
             load9u(pa, a0, a1, t);
             if (idx & 5) { u32 b0, b1; load9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
-            s = sad4(a0, f[0], 0); s = sad4(a1, f[1], s);
+            s = sad4(a0, f[0], 0); if (c.bw == 8) s = sad4(a1, f[1], s);
         }
         v = (int)s;
     }
@@ -311,7 +313,7 @@ __device__ __forceinline__ int sad_qpel8_lane(const MxCtx &c, int mx, int my)
                 u32 a0, a1, t;
                 load9u(pa, a0, a1, t);
                 if (idx & 5) { u32 b0, b1; load9u(pb, b0, b1, t); a0 = avg4(a0, b0); a1 = avg4(a1, b1); }
-                s = sad4(a0, f[0], s); s = sad4(a1, f[1], s);
+                s = sad4(a0, f[0], s); if (c.bw == 8) s = sad4(a1, f[1], s);
             }
         }
     }
@@ -394,7 +396,8 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
 {
     const int j = c.lane & 15;
     int v = 0;
-    const int nbx = c.bw >> 3, n_luma = nbx * (c.bh >> 2), n_cunits = c.bh >> 3;      // 8x4 luma blocks; 4-row chroma units per plane
+    const int nbx = c.bw == 16 ? 2 : 1, n_luma = nbx * (c.bh >> 2), n_cunits = c.bh >> 3;   // 8x4 (4x4 when bw = 4) luma blocks; 4-row chroma units per plane
+    const u32 lkeep = c.bw == 4 ? 0x0000ffffu : 0xffffffffu;                          // a 4-wide block: the right half of the unit contributes nothing
     const bool staged = mx_in_patch(c, mx, my);
     u32 d[4][4];                 // packed differences of this lane's 8x4 unit (SATD): luma and chroma lanes share one transform below
     bool have_d = false;
@@ -435,10 +438,15 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
 #pragma unroll
             for (int y = 0; y < 4; y++)
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[y][x] = mx_pair(f[y][1], f[y][0], x) - mx_pair(p[y][1], p[y][0], x);
+                for (int x = 0; x < 4; x++) d[y][x] = (mx_pair(f[y][1], f[y][0], x) & lkeep) - (mx_pair(p[y][1], p[y][0], x) & lkeep);
             have_d = true;
-        } else
+        } else {
+            if (c.bw == 4) {
+#pragma unroll
+                for (int y = 0; y < 4; y++) { f[y][1] = 0; p[y][1] = 0; }
+            }
             v = blk8x4_cost(f, p, 0);
+        }
     } else if (chroma && j >= 8 && j < 12 && ((j - 8) & 1) < n_cunits) {
         // mbcmp[i_pixel + 3]: 8x8 / 8x4 chroma blocks are 8x4 units, 4x8 / 4x4 ones are 4x4 units
         const int by = ((j - 8) & 1) * 4, wide = c.bw == 16;
@@ -674,7 +682,8 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
         } while (++i < o.me_range);
     } else if (o.method == 2) {
         // uneven-cross multi-hexagon, me.c:306-447.  A small state machine so that the candidate scorer is instantiated once.
-        const int shift = (c.bw == 8) + (c.bh == 8);                      // x264_pixel_size_shift of the block
+        const int shift = (c.bw == 8) + (c.bh == 8) + 2 * ((c.bw == 4) + (c.bh == 4));   // x264_pixel_size_shift of the block: 0 1 1 2 3 3 4
+        const bool tiny = c.bw == 4 && c.bh == 4;                         // "if(i_pixel == PIXEL_4x4) goto me_hex2", me.c:323
 #define SAD_THRESH(v_) (bcost < ((v_) >> shift))
         const int ucost1 = bcost;
         int ucost2 = 0, cross_start = 1, omx = pmx, omy = pmy, ph = 0, et_range = 0;
@@ -693,7 +702,7 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
             if (run) umh_stream(c, L, omx, omy, start, x_max, y_max, toff, tlog, rings, grid, bcost, bmx, bmy);
             switch (ph) {
             case 0: ph = 1; break;
-            case 1: ucost2 = bcost; ph = 2; break;
+            case 1: ucost2 = bcost; ph = tiny ? 9 : 2; break;
             case 2:
                 if (bcost == ucost2) cross_start = 3;
                 omx = bmx; omy = bmy;
@@ -729,7 +738,7 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
             }
         }
 #undef SAD_THRESH
-        if (ph == 7 && bmy <= L.fmax1) do_hex = true;
+        if ((ph == 7 && bmy <= L.fmax1) || ph == 9) do_hex = true;
     }
     if (do_hex) {
         // hexagon, me.c:246-305.  The first ring in one trip: (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2) = hex2[1..6]

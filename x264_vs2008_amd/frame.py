@@ -48,7 +48,7 @@ class DeblockParams(C.Structure):
     _fields_ = [("mb_type", C.c_void_p), ("qp", C.c_void_p), ("nnz", C.c_void_p), ("transform8x8", C.c_void_p),
                 ("mv", C.c_void_p), ("ref", C.c_void_p),
                 ("alpha_c0_offset", C.c_int), ("beta_offset", C.c_int), ("chroma_qp_offset", C.c_int),
-                ("state_layout", C.c_int)]
+                ("state_layout", C.c_int), ("sub8x8", C.c_int)]
 
 
 class DeviceArray:

@@ -18,7 +18,7 @@ LAMBDA_TAB = (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 
               6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91)   # R/encoder/analyse.c:140-149
 COST_SPAN = 2 * 4 * 2048      # p_cost_mv reaches +-2*4*2048 quarter-pels (R/encoder/analyse.c:191-198)
 
-STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("ref", np.int8, (4,)), ("i4mode", np.int8, (16,)),
+STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("sub_partition", np.int8, (4,)), ("ref", np.int8, (4,)), ("i4mode", np.int8, (16,)),
                 ("i16mode", np.int8, ()), ("chroma_mode", np.int8, ()), ("qp", np.int8, ()), ("t8", np.int8, ()),
                 ("mv", np.int16, (16, 2)), ("mvr", np.int16, None), ("cbp", np.int16, ()), ("nnz", np.uint8, (27,)),
                 ("luma", np.int16, (256,)), ("luma_dc", np.int16, (16,)), ("chroma_dc", np.int16, (8,)), ("chroma_ac", np.int16, (128,)),
@@ -146,7 +146,8 @@ class ChainEncoder:
         if o["deblock"]:
             s = state.st
             dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
-                               alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1)
+                               alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1,
+                               sub8x8=1 if o["inter"] & 0x20 else 0)
             c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
         c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
         c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")

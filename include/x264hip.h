@@ -186,7 +186,7 @@ int x264hip_me_subpel_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, c
  *   out_mv   : [mb][n_refs][2] qpel;  out_cost : [mb][n_refs] (ref cost included)
  *   best     : [mb][4] = {ref, mvx, mvy, cost}                                             */
 typedef struct {
-    int me_method;             /* 0 = X264_ME_DIA, 1 = X264_ME_HEX, 2 = X264_ME_UMH (ESA / TESA are refused) */
+    int me_method;             /* 0 = X264_ME_DIA, 1 = X264_ME_HEX, 2 = X264_ME_UMH, 3 = X264_ME_ESA (subme >= 1); TESA is refused */
     int me_range, subme, chroma_me;
     int mv_range;              /* pixels; 0 = 512 */
     const int16_t *cost_mv;    /* device */

@@ -382,6 +382,17 @@ static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], i
             if (!INRANGE(bmx, bmy)) break;
         } while (++i < me_range);
     }
+    if (method == 3) {
+        /* X264_ME_ESA, me.c:449-600.  The reference drops, row by row, every position whose ADS bound (sum of |differences of block
+         * sums| + mv cost <= SAD + mv cost) is not below the best cost so far; such a position could not have passed COST_MV's strict
+         * '<' either, so the walk equals the plain raster scan of its own "#if 0" branch -- over min_x .. min_x + width - 1 with the
+         * width rounded up to a multiple of 4 (:456), which can stop one column short of max_x or run up to three past it. */
+        const int min_x = bmx - me_range > c->fmin[0] ? bmx - me_range : c->fmin[0], min_y = bmy - me_range > c->fmin[1] ? bmy - me_range : c->fmin[1];
+        const int max_x = bmx + me_range < c->fmax[0] ? bmx + me_range : c->fmax[0], max_y = bmy + me_range < c->fmax[1] ? bmy + me_range : c->fmax[1];
+        const int width = (max_x - min_x + 3) & ~3;
+        for (int my = min_y; my <= max_y; my++)
+            for (int mx = min_x; mx < min_x + width; mx++) TRY(mx, my);
+    }
     int do_hex = method == 1, hex_range = me_range;
     if (method == 2) {                                           /* uneven-cross multi-hexagon, me.c:306-447 */
         static const int size_shift[7] = {0, 1, 1, 2, 3, 3, 4};

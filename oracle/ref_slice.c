@@ -110,6 +110,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     x264_predict_8x8_init(0, h->predict_8x8, &h->predict_8x8_filter); x264_predict_4x4_init(0, h->predict_4x4);
     sel_cmp(h);
     h->frames.b_have_lowres = 0;
+    h->frames.b_have_sub8x8_esa = !!(h->param.analyse.inter & X264_ANALYSE_PSUB8x8);   /* encoder.c:717: the 4x4 integral plane of ESA */
     h->fenc = x264_frame_new(h);
     h->fdec = x264_frame_new(h);
     if (x264_macroblock_cache_init(h) < 0 || x264_ratecontrol_new(h) < 0) return -2;

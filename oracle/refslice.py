@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 # R/x264.h:190-199
 ANALYSE_I4x4, ANALYSE_I8x8, ANALYSE_PSUB16x16, ANALYSE_PSUB8x8 = 0x0001, 0x0002, 0x0010, 0x0020
-ME_DIA, ME_HEX, ME_UMH = 0, 1, 2
+ME_DIA, ME_HEX, ME_UMH, ME_ESA = 0, 1, 2, 3
 # R/common/macroblock.h:78-102 (mb types), :55-76 (partitions)
 I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = 0, 1, 2, 3, 4, 5, 6
 SLICE_P, SLICE_B, SLICE_I = 0, 1, 2

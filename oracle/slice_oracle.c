@@ -1158,7 +1158,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     sframe *refs[16] = {0};
     int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
     s_setup();
-    if (p->subme > 5 || p->me_method > 2) return -3;
+    if (p->subme > 5 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
     memset(&S, 0, sizeof(S));
     S.p = p; S.o = o;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;

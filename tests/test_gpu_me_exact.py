@@ -76,7 +76,7 @@ def test_me_search16_matches_reference_golden(hip_lib, oracle_lib, size, method,
     assert len(np.unique(best[:, 0])) > 1, "every reference index should win somewhere"
 
 
-@pytest.mark.parametrize("method,subme,chroma_me,n_refs", [(1, 6, 1, 3), (0, 4, 0, 1), (1, 9, 1, 2), (2, 5, 1, 2), (2, 1, 0, 1)])
+@pytest.mark.parametrize("method,subme,chroma_me,n_refs", [(1, 6, 1, 3), (0, 4, 0, 1), (1, 9, 1, 2), (2, 5, 1, 2), (2, 1, 0, 1), (3, 5, 1, 2), (3, 1, 0, 1)])
 def test_me_search16_matches_twin_on_wild_predictors(hip_lib, oracle_lib, method, subme, chroma_me, n_refs):
     """Predictors up to the vector limits (clipped starts, border reads), 0..8 candidates, one to three references."""
     size, qp, me_range = (208, 144), 30, 16

@@ -98,7 +98,7 @@ extern "C" int x264hip_me_search16_frame(x264hip_frame_ctx *c, const x264hip_pic
                                          int32_t *best_dev)
 {
     if (n_refs < 1 || n_refs > MX_MAX_REFS) { set_error("me_search16: %d references (1..%d)", n_refs, MX_MAX_REFS); return -1; }
-    if (p->me_method < 0 || p->me_method > 2) { set_error("me_search16: method %d not built (0 DIA, 1 HEX, 2 UMH)", p->me_method); return -1; }
+    if (p->me_method < 0 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) { set_error("me_search16: method %d not built (0 DIA, 1 HEX, 2 UMH, 3 ESA with subme >= 1)", p->me_method); return -1; }
     if (p->subme < 0 || p->subme > 9 || !p->cost_mv || !p->mvp || !p->mvc || !p->n_mvc) { set_error("me_search16: bad parameters"); return -1; }
     MxRefs t;
     for (int i = 0; i < MX_MAX_REFS; i++) {

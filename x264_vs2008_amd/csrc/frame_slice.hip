@@ -1818,7 +1818,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (is_p && (n_refs < 1 || n_refs > SW_MAX_REFS)) { set_error("slice_sweep: %d references (1..%d)", n_refs, SW_MAX_REFS); return -1; }
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
     if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
-    if (p->me_method < 0 || p->me_method > 2) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX, 2 UMH)", p->me_method); return -1; }
+    if (p->me_method < 0 || p->me_method > 3) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX, 2 UMH, 3 ESA)", p->me_method); return -1; }
+    if (p->me_method == 3 && p->subme < 1) { set_error("slice_sweep: ESA at subme 0 is undefined in the reference (it never fills the integral plane there, encoder.c:1009 / mc.c:431)"); return -1; }
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }

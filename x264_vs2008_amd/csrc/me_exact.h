@@ -680,6 +680,26 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
             if (bmx == ox && bmy == oyy) break;
             if (!INRANGE(bmx, bmy)) break;
         } while (++i < o.me_range);
+    } else if (o.method == 3) {
+        // X264_ME_ESA, me.c:449-600.  The reference drops, row by row, every position whose ADS bound (sum of |differences of block
+        // sums| + mv cost, which never exceeds SAD + mv cost) is not below the best cost so far; such a position could not have passed
+        // COST_MV's strict '<' either, so its walk equals the plain raster scan of its own "#if 0" branch (pinned: scratch/cmp_esa.py) --
+        // over min_x .. min_x + width - 1 with the width rounded up to a multiple of 4 (:456), which can stop one column short of max_x
+        // or run up to three past it.  Eight positions of a row per trip; a row whose vertical mv cost alone reaches the best is skipped.
+        const int min_x = max(bmx - o.me_range, L.fmin0), min_y = max(bmy - o.me_range, L.fmin1);
+        const int max_x = min(bmx + o.me_range, L.fmax0), max_y = min(bmy + o.me_range, L.fmax1);
+        const int width = (max_x - min_x + 3) & ~3;
+        for (int my = min_y; my <= max_y; my++) {
+            if (bcost <= c.cost1((my << 2) - mvpy)) continue;
+            for (int x0 = 0; x0 < width; x0 += 8) {
+                const int n = x0 + g8;
+                const bool ok = n < width;
+                const int x = min_x + (ok ? n : 0), y = my;
+                const int cost = sad_fpel8_lane(c, x, y) + c.lane_cost(x << 2, y << 2);
+                const u32 key = mx_best_key<3>(cost, ok, lane);
+                MX_TAKE(3, key, bcost, x, y, bmx, bmy);
+            }
+        }
     } else if (o.method == 2) {
         // uneven-cross multi-hexagon, me.c:306-447.  A small state machine so that the candidate scorer is instantiated once.
         const int shift = (c.bw == 8) + (c.bh == 8) + 2 * ((c.bw == 4) + (c.bh == 4));   // x264_pixel_size_shift of the block: 0 1 1 2 3 3 4

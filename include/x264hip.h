@@ -243,7 +243,22 @@ typedef struct {
     int mixed_refs;                    /* param.analyse.b_mixed_references (p8x8 blocks search every reference) */
     int64_t *profile;                  /* NULL, or device [batch][mb_h][8]: 100 MHz ticks each row wave spent
                                           0 waiting 1 loading 2 inter search 3 encode 4 stores 5 publish 6 intra analysis */
+    /* param.analyse.i_noise_reduction (R/encoder/macroblock.c:632-637,682-695): when non-zero, inter luma coefficients go through
+     * x264_denoise_dct with nr->offset before quantisation and their magnitudes / block counts are added to nr->sum / nr->count */
+    int noise_reduction;
+    const struct x264hip_nr_state *nr;
 } x264hip_slice_params;
+
+/* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:
+ * sum [batch][2][64] uint32 (cat 0: 4x4, first 16 used; cat 1: 8x8), count [batch][2] uint32, offset [batch][2][64] uint16 */
+typedef struct x264hip_nr_state {
+    uint32_t *sum, *count;
+    uint16_t *offset;
+} x264hip_nr_state;
+int  x264hip_nr_state_alloc(x264hip_frame_ctx *c, x264hip_nr_state *nr);
+void x264hip_nr_state_free(x264hip_frame_ctx *c, x264hip_nr_state *nr);
+/* x264_noise_reduction_update (R/encoder/macroblock.c:890-911) for every chain: call once after each frame's sweep */
+int  x264hip_noise_reduction_update(x264hip_frame_ctx *c, const x264hip_nr_state *nr, int noise_reduction);
 
 int  x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st);
 void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st);

@@ -35,6 +35,8 @@ CASES = [
     ("sub8x8_umh", (200, 120), 4, "static", dict(qp=24, subme=3, me_method=rs.ME_UMH, inter=0x30, n_refs=2, deblock=1, chroma_me=0)),
     ("esa", (208, 144), 3, "moving", dict(qp=26, subme=5, me_method=rs.ME_ESA, me_range=12, n_refs=2, inter=0x33, intra=0x1, mixed_refs=1, cabac=1, deblock=1)),
     ("esa_fpel", (200, 120), 3, "static", dict(qp=30, subme=1, me_method=rs.ME_ESA, me_range=16, inter=0x10)),
+    ("nr", (208, 144), 6, "moving", dict(qp=28, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1,
+                                         cabac=1, deblock=1, noise_reduction=300)),
     ("umh_fpel", (200, 120), 4, "moving", dict(qp=32, subme=1, me_method=rs.ME_UMH, me_range=24, inter=0x10, n_refs=2, deblock=1)),
 ]
 

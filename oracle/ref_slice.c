@@ -22,6 +22,7 @@ typedef struct {
     int inter, intra;                        /* X264_ANALYSE_* */
     int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
+    int noise_reduction;                     /* param.analyse.i_noise_reduction */
 } refslice_params;
 
 typedef struct {
@@ -91,7 +92,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->param.analyse.b_chroma_me = p->chroma_me; h->param.analyse.b_mixed_references = p->mixed_refs;
     h->param.analyse.b_fast_pskip = p->fast_pskip; h->param.analyse.b_dct_decimate = p->dct_decimate;
     h->param.analyse.b_transform_8x8 = p->transform8x8; h->param.analyse.i_trellis = 0;
-    h->param.analyse.i_noise_reduction = 0; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
+    h->param.analyse.i_noise_reduction = p->noise_reduction; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
     h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
     h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
     h->param.rc.i_qp_min = 0; h->param.rc.i_qp_max = 51;
@@ -210,6 +211,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
             }
         }
         filter_row(h, mb_h);
+        x264_noise_reduction_update(h);                      /* x264_encoder_frame_end, R/encoder/encoder.c:1755 */
         o->stat[4 * F] = h->stat.frame.i_intra_cost; o->stat[4 * F + 1] = h->stat.frame.i_inter_cost;
         o->stat[4 * F + 2] = h->stat.frame.i_mbs_analysed; o->stat[4 * F + 3] = 0;
         for (y = 0; y < 16 * mb_h; y++)

@@ -20,6 +20,7 @@ typedef struct {
     int inter, intra;
     int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
+    int noise_reduction;
 } slice_params;
 
 typedef struct {
@@ -125,6 +126,9 @@ typedef struct {
     int dq4[4][6][16], dq8[2][6][64];
     slice_out *o;
     int f;
+    /* --nr: h->nr_residual_sum / nr_count / nr_offset, [0] 4x4, [1] 8x8 (R/common/common.h:308-310) */
+    uint32_t nr_sum[2][64], nr_count[2];
+    uint16_t nr_offset[2][64];
 } ssl;
 
 typedef struct {
@@ -368,7 +372,9 @@ static void enc_inter_luma(ssl *S, smb *m)
     if (m->t8) {
         i16 d8[4][8][8];
         dctf.sub16x16_dct8(d8, m->fe[0], m->fd[0]);
+        if (S->p->noise_reduction) S->nr_count[1] += 4;
         for (int idx = 0; idx < 4; idx++) {
+            if (S->p->noise_reduction) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
             int nz = quantf.quant_8x8(d8[idx], S->mf8[1], S->b8[1]);
             if (nz) {
                 zigf[0].scan_8x8(m->luma8[idx], d8[idx]);
@@ -393,9 +399,11 @@ static void enc_inter_luma(ssl *S, smb *m)
     } else {
         i16 d4[16][4][4];
         dctf.sub16x16_dct(d4, m->fe[0], m->fd[0]);
+        if (S->p->noise_reduction) S->nr_count[0] += 16;
         for (int i8 = 0; i8 < 4; i8++) {
             int dec8 = 0, cbp = 0;
             for (int i4 = 0; i4 < 4; i4++) {
+                if (S->p->noise_reduction) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
                 int idx = 4 * i8 + i4, nz = quantf.quant_4x4(d4[idx], S->mf4[1], S->b4[1]);
                 m->nnz[idx] = nz;
                 if (nz) {
@@ -769,6 +777,26 @@ static int p4x4_chroma(const ssl *S, const smb *m, int ref, int i8, int sub, con
         mcf.mc_chroma(&pix2[x + y * 16], 16, r->plane[2] + oc + x + y * S->sc, S->sc, me[k].mvx, me[k].mvy, w, h);
     }
     return (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[1] + oe, FENC, pix1, 16) + (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[2] + oe, FENC, pix2, 16);
+}
+
+/* x264_noise_reduction_update, R/encoder/macroblock.c:890-911 (weights: x264_dct4_weight2_tab / x264_dct8_weight2_tab, dct.h:56-83) */
+static void nr_update(ssl *S)
+{
+    static const uint16_t w4[3] = {800, 320, 128}, w8[6] = {256, 201, 656, 227, 410, 363};
+    static const u8 k4[16] = {0, 1, 0, 1, 1, 2, 1, 2, 0, 1, 0, 1, 1, 2, 1, 2};
+    static const u8 k8[32] = {0, 3, 4, 3, 0, 3, 4, 3, 3, 1, 5, 1, 3, 1, 5, 1, 4, 5, 2, 5, 4, 5, 2, 5, 3, 1, 5, 1, 3, 1, 5, 1};
+    for (int cat = 0; cat < 2; cat++) {
+        const int size = cat ? 64 : 16;
+        if (S->nr_count[cat] > (cat ? (1u << 16) : (1u << 18))) {
+            for (int i = 0; i < size; i++) S->nr_sum[cat][i] >>= 1;
+            S->nr_count[cat] >>= 1;
+        }
+        for (int i = 0; i < size; i++) {
+            const unsigned long long w = cat ? w8[k8[i & 31]] : w4[k4[i]];
+            S->nr_offset[cat][i] = (uint16_t)(((unsigned long long)S->p->noise_reduction * S->nr_count[cat] + S->nr_sum[cat][i] / 2)
+                                         / ((unsigned long long)S->nr_sum[cat][i] * w / 256 + 1));
+        }
+    }
 }
 
 static void analyse_mb(ssl *S, smb *m)
@@ -1211,6 +1239,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
             encode_mb(&S, &m);
             save_mb(&S, &m);
         }
+        if (p->noise_reduction) nr_update(&S);
         o->stat[4 * F] = S.stat_intra; o->stat[4 * F + 1] = S.stat_inter; o->stat[4 * F + 2] = S.stat_n; o->stat[4 * F + 3] = 0;
         /* x264_fdec_filter_row over the finished frame: loop filter, borders, half-pel planes */
         if (p->deblock) {

@@ -143,7 +143,8 @@ def _random_case(seed):
     kw = dict(qp=int(r.integers(18, 42)), subme=int(r.integers(0, 6)), me_method=int(r.choice([0, 1, 1, 2, 2, 3])), me_range=int(r.choice([8, 16, 24])),
               n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13, 0x30, 0x33])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),
               transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=int(r.integers(0, 2)), deblock=int(r.integers(0, 2)),
-              fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])))
+              fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])),
+              noise_reduction=int(r.choice([0, 0, 0, 60, 400])))
     if kw["me_method"] == 3:
         kw["subme"] = max(kw["subme"], 1); kw["me_range"] = min(kw["me_range"], 16)       # ESA: undefined at subme 0 in the reference; keep the scan small
     if not kw["transform8x8"]:

@@ -73,6 +73,9 @@ struct SwArgs {
     int *cost_intra, *cost_inter, *cost_alt;
     int *progress, *abort_flag;
     long long *prof;            // optional [batch][mb_h][8] accumulated wall-clock ticks per phase (developer aid)
+    int nr;                     // param.analyse.i_noise_reduction != 0
+    u32 *nr_sum, *nr_count;     // [batch][2][64], [batch][2]
+    const u16 *nr_offset;       // [batch][2][64]
 };
 
 struct SwLds {
@@ -94,6 +97,7 @@ struct SwLds {
     __attribute__((aligned(4))) u8 pt4[48];   // the current 4x4 / 8x8 block's prediction table (intra_pred.h: RAW | F1 | F2 | DC..)
     __attribute__((aligned(4))) u8 pt8[80];
     u32 p4lut[48], p8lut[192];  // c_plut4 / c_plut8
+    u16 nr_off4[16], nr_off8[64];   // h->nr_offset[0] / [1] of this chain (--nr)
     __attribute__((aligned(16))) u8 patch[MX_PATCH_BYTES];   // the motion search's staged sub-pel neighbourhood (me_exact.h)
     u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     i16 lv_y8[256];             // levels of the 8x8 transform (h->dct.luma8x8), separate from the 4x4 ones like the reference's
@@ -298,7 +302,16 @@ __device__ __forceinline__ int sw_fix8c(int m) { return m < 4 ? m : 0; }      //
 // ---- encode pieces (R/encoder/macroblock.c:116-363, 596-768; no trellis, not lossless) ------------
 // luma 4x4 transform + quant + scan + dequant of the 16 blocks, lanes 0-15.  cat: 0 intra, 1 inter.
 // i16 mode takes the DC out first (s.dc16 in raster order) and scores with decimate_score15.
-__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane)
+// x264_denoise_dct (R/common/quant.c:180-192) on coefficient v with offset off: returns the new coefficient, la = |v|
+__device__ __forceinline__ int sw_denoise(int v, int off, int &la)
+{
+    const int sign = v >> 15;
+    int level = (v + sign) ^ sign;
+    la = level;
+    level -= off;
+    return level < 0 ? 0 : (level ^ sign) - sign;
+}
+__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr)
 {
     if (lane < 16) {
         int bx, by, r[16];
@@ -310,6 +323,17 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int ca
                 r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
         i16 c[16], lv[16];
         fwd4x4(c, r);
+        if (nr_acc4) {
+            // --nr: every coefficient but the first of every block, and the sum of magnitudes per coefficient index over the 16
+            // blocks (lane i keeps index i's running sum for the whole row; added to the chain's totals at the end of the row)
+#pragma unroll
+            for (int i = 1; i < 16; i++) {
+                int la;
+                c[i] = (i16)sw_denoise(c[i], s.nr_off4[i], la);
+                const int t = row_sum16(la);
+                if (lane == i) *nr_acc4 += t;
+            }
+        }
         if (dc_out) { s.dc16[(by >> 2) * 4 + (bx >> 2)] = c[0]; c[0] = 0; }
         const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
         const int *dq = s.qdq[cat];
@@ -342,9 +366,9 @@ __device__ __forceinline__ void sw_luma4x4_add(SwLds &s, int lane, int keep8)
     WAVE_SYNC();
 }
 // x264_macroblock_encode's inter 4x4-transform branch; returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane)
+__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane, int *nr_acc4 = nullptr)
 {
-    sw_luma4x4_fwd(s, a, 1, false, lane);
+    sw_luma4x4_fwd(s, a, 1, false, lane, nr_acc4);
     if (lane == 0) {
         int cbp = 0, dec_mb = 0;
         for (int i8 = 0; i8 < 4; i8++) {
@@ -576,7 +600,7 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
 // for the two 1-D passes (32 lanes), then 64 lanes x one coefficient per block.  Leaves the quantised
 // coefficients (transposed storage) in s.coef[4*b..][..] = [4][64], levels in s.lv_y8, per block
 // s.score[b] = decimate_score64 | nz << 8.  cat: 0 intra, 1 inter.
-__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane)
+__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane, int *nr_acc8 = nullptr)
 {
     i16 *tmp = s.t8, *coef = &s.coef[0][0];
     const int b = lane >> 3, k8 = lane & 7;
@@ -605,6 +629,11 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int 
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((mask >> j) & 1) {
+            if (nr_acc8 && lane) {      // --nr: lane = coefficient index, the first one is left alone
+                int la;
+                coef[64 * j + lane] = (i16)sw_denoise(coef[64 * j + lane], s.nr_off8[lane], la);
+                *nr_acc8 += la;
+            }
             int q = quant_one(coef[64 * j + lane], mfl, bsl);
             coef[64 * j + lane] = (i16)q;
             nzmask[j] = __ballot(q != 0);
@@ -671,9 +700,9 @@ __device__ __forceinline__ void sw_luma8x8_add(SwLds &s, int cat, int qp, int ke
     WAVE_SYNC();
 }
 // inter, 8x8 transform (R/encoder/macroblock.c:627-669); returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane)
+__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane, int *nr_acc8 = nullptr)
 {
-    sw_luma8x8_fwd(s, 1, 0xf, lane);
+    sw_luma8x8_fwd(s, 1, 0xf, lane, nr_acc8);
     int cbp = 0, dec_mb = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -960,6 +989,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
         if (is_p)
             for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = a.cost_mv[a.cost_center - MX_COST_LDS + k];
+        if (a.nr) { s.nr_off8[lane] = a.nr_offset[(size_t)bz * 128 + 64 + lane]; if (lane < 16) s.nr_off4[lane] = a.nr_offset[(size_t)bz * 128 + lane]; }
         if (lane < 48) s.p4lut[lane] = ((const u32 *)&c_plut4)[lane];
         for (int k = lane; k < 192; k += 64) s.p8lut[k] = ((const u32 *)&c_plut8)[k];
         if (a.transform8x8)
@@ -970,6 +1000,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
     WAVE_SYNC();
 
+    int nr_acc4 = 0, nr_acc8 = 0, nr_n4 = 0, nr_n8 = 0;      // --nr: this row's additions to nr_residual_sum (lane = coefficient index) / nr_count
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptime = a.prof ? (long long)wall_clock64() : 0;
 #define PROF(k_) do { if (a.prof) { long long now_ = (long long)wall_clock64(); pacc[k_] += now_ - ptime; ptime = now_; } } while (0)
     // the left neighbour = this wave's previous macroblock
@@ -1669,7 +1700,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     const int c4 = sw_cmp_luma16(s, 1, lane);
                     t8 = c8 < c4;
                 }
-                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane) : sw_encode_inter_luma(s, a, lane);
+                if (a.nr) { if (t8) nr_n8 += 4; else nr_n4 += 16; }
+                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane, a.nr ? &nr_acc8 : nullptr) : sw_encode_inter_luma(s, a, lane, a.nr ? &nr_acc4 : nullptr);
                 cbp_chroma = sw_encode_chroma(s, a, 1, lane);
                 if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
             }
@@ -1742,6 +1774,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (lane == 0) __hip_atomic_store(prog + mby, (mbx + 1) | (row_intra << 16), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         PROF(5);
     }
+    if (a.nr) {
+        if (lane >= 1 && lane < 16 && nr_acc4) atomicAdd(a.nr_sum + (size_t)bz * 128 + lane, (u32)nr_acc4);
+        if (lane >= 1 && nr_acc8) atomicAdd(a.nr_sum + (size_t)bz * 128 + 64 + lane, (u32)nr_acc8);
+        if (lane == 0 && (nr_n4 | nr_n8)) { atomicAdd(a.nr_count + (size_t)bz * 2, (u32)nr_n4); atomicAdd(a.nr_count + (size_t)bz * 2 + 1, (u32)nr_n8); }
+    }
     if (a.prof && lane < 8) {
         long long v = lane == 0 ? pacc[0] : lane == 1 ? pacc[1] : lane == 2 ? pacc[2] : lane == 3 ? pacc[3] : lane == 4 ? pacc[4] : lane == 5 ? pacc[5] : lane == 6 ? pacc[6] : pacc[7];
         a.prof[((size_t)bz * a.mb_h + mby) * 8 + lane] = v;
@@ -1809,6 +1846,48 @@ extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st
     memset(st, 0, sizeof(*st));
 }
 
+// x264_noise_reduction_update, R/encoder/macroblock.c:890-911: one block per chain, thread = cat * 64 + coefficient
+static __constant__ u16 c_nr_w4[16] = {800, 320, 800, 320, 320, 128, 320, 128, 800, 320, 800, 320, 320, 128, 320, 128};        // x264_dct4_weight2_tab
+static __constant__ u16 c_nr_w8k[6] = {256, 201, 656, 227, 410, 363};                                                     // x264_dct8_weight2_tab's W(i)
+static __constant__ u8 c_nr_k8[32] = {0, 3, 4, 3, 0, 3, 4, 3, 3, 1, 5, 1, 3, 1, 5, 1, 4, 5, 2, 5, 4, 5, 2, 5, 3, 1, 5, 1, 3, 1, 5, 1};
+__global__ __launch_bounds__(128) void k_nr_update(u32 *sum, u32 *count, u16 *offset, int strength)
+{
+    const int cat = threadIdx.x >> 6, i = threadIdx.x & 63, size = cat ? 64 : 16;
+    sum += (size_t)blockIdx.x * 128; count += (size_t)blockIdx.x * 2; offset += (size_t)blockIdx.x * 128;
+    u32 cnt = count[cat], sv = i < size ? sum[cat * 64 + i] : 0;
+    const bool halve = cnt > (cat ? (1u << 16) : (1u << 18));
+    __syncthreads();                                   // everyone has read the count before it is rewritten
+    if (halve) { sv >>= 1; cnt >>= 1; if (i < size) sum[cat * 64 + i] = sv; if (i == 0) count[cat] = cnt; }
+    if (i < size) {
+        const unsigned long long w = cat ? c_nr_w8k[c_nr_k8[i & 31]] : c_nr_w4[i];
+        offset[cat * 64 + i] = (u16)(((unsigned long long)strength * cnt + sv / 2) / ((unsigned long long)sv * w / 256 + 1));
+    }
+}
+extern "C" int x264hip_nr_state_alloc(x264hip_frame_ctx *c, x264hip_nr_state *nr)
+{
+    memset(nr, 0, sizeof(*nr));
+    const size_t B = (size_t)c->batch;
+    HIPCHK(hipMalloc((void **)&nr->sum, B * 128 * 4)); HIPCHK(hipMalloc((void **)&nr->count, B * 2 * 4)); HIPCHK(hipMalloc((void **)&nr->offset, B * 128 * 2));
+    HIPCHK(hipMemsetAsync(nr->sum, 0, B * 128 * 4, c->stream)); HIPCHK(hipMemsetAsync(nr->count, 0, B * 2 * 4, c->stream));
+    HIPCHK(hipMemsetAsync(nr->offset, 0, B * 128 * 2, c->stream));
+    return 0;
+}
+extern "C" void x264hip_nr_state_free(x264hip_frame_ctx *c, x264hip_nr_state *nr)
+{
+    (void)c;
+    if (nr->sum) (void)hipFree(nr->sum);
+    if (nr->count) (void)hipFree(nr->count);
+    if (nr->offset) (void)hipFree(nr->offset);
+    memset(nr, 0, sizeof(*nr));
+}
+extern "C" int x264hip_noise_reduction_update(x264hip_frame_ctx *c, const x264hip_nr_state *nr, int noise_reduction)
+{
+    if (!nr || !nr->sum || !nr->count || !nr->offset) { set_error("noise_reduction_update: no state"); return -1; }
+    hipLaunchKernelGGL(k_nr_update, dim3((unsigned)c->batch), dim3(128), 0, c->stream, nr->sum, nr->count, nr->offset, noise_reduction);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs, int n_refs,
                                          x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
                                          x264hip_mb_state *out)
@@ -1864,6 +1943,9 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter; a.cost_alt = out->cost_intra_alt;
     a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
     a.prof = (long long *)p->profile;
+    a.nr = p->noise_reduction != 0;
+    if (a.nr && (!p->nr || !p->nr->sum || !p->nr->count || !p->nr->offset)) { set_error("slice_sweep: noise_reduction without an x264hip_nr_state"); return -1; }
+    a.nr_sum = a.nr ? p->nr->sum : nullptr; a.nr_count = a.nr ? p->nr->count : nullptr; a.nr_offset = a.nr ? p->nr->offset : nullptr;
     SwRefs t;
     for (int i = 0; i < SW_MAX_REFS; i++) {
         const x264hip_picture *r = (is_p && n_refs > 0) ? refs[i < n_refs ? i : 0] : fenc;

@@ -38,7 +38,12 @@ class SliceParams(C.Structure):
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p), ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
                 ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
-                ("mixed_refs", C.c_int), ("profile", C.c_void_p)]
+                ("mixed_refs", C.c_int), ("profile", C.c_void_p), ("noise_reduction", C.c_int), ("nr", C.c_void_p)]
+
+
+class NrState(C.Structure):
+    """x264hip_nr_state: h->nr_residual_sum / nr_count / nr_offset of every chain (device)."""
+    _fields_ = [("sum", C.c_void_p), ("count", C.c_void_p), ("offset", C.c_void_p)]
 
 
 def iframe_qp(qp, ip_factor=1.4):
@@ -72,12 +77,13 @@ class ChainEncoder:
 
     def __init__(self, lib, width, height, cqm, batch=1, qp=26, me_method=0, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
-                 chroma_qp_offset=0, keyint=0, mixed_refs=0):
+                 chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0):
         self.lib = lib
         self.ctx = FrameCtx(lib, width, height, batch=batch)
         self.opt = dict(qp=qp, me_method=me_method, me_range=me_range, subme=subme, n_refs=n_refs, inter=inter, intra=intra,
                         transform8x8=transform8x8, fast_pskip=fast_pskip, dct_decimate=dct_decimate, chroma_me=chroma_me, cabac=cabac,
-                        deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint, mixed_refs=mixed_refs)
+                        deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint, mixed_refs=mixed_refs,
+                        noise_reduction=noise_reduction)
         self.cqm = CqmDevice(lib, cqm)
         self.cost = {}
         self.fenc = self.ctx.new_picture()
@@ -88,6 +94,10 @@ class ChainEncoder:
         self.last_idr = 0
         self.profile = None            # DeviceArray [batch][mb_h][8] int64 when phase timing is wanted
         self.events = None             # set to [] to collect (start, stop, slice_type, n_refs) HIP events per sweep launch
+        self.nr = None
+        if noise_reduction:
+            self.nr = NrState()
+            self.ctx.check(lib.x264hip_nr_state_alloc(self.ctx.h, C.byref(self.nr)), "nr_state_alloc")
         lib.x264hip_event_create.restype = C.c_void_p
         lib.x264hip_event_elapsed_ms.restype = C.c_float
 
@@ -122,7 +132,8 @@ class ChainEncoder:
                         quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
                         cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
-                        profile=self.profile.ptr if self.profile else None)
+                        profile=self.profile.ptr if self.profile else None,
+                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]
         arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None
@@ -136,6 +147,8 @@ class ChainEncoder:
         if ev:
             L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
             self.events.append((ev[0], ev[1], stype, len(refs)))
+        if self.nr:                            # x264_noise_reduction_update at the end of every frame (R/encoder/encoder.c:1755)
+            c.check(L.x264hip_noise_reduction_update(c.h, C.byref(self.nr), o["noise_reduction"]), "noise_reduction_update")
         self.last = (recon, state)
         return stype, qp, state
 
@@ -160,6 +173,9 @@ class ChainEncoder:
         c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(self.last[1].st)), "slice_sweep_status")
 
     def close(self):
+        if self.nr:
+            self.lib.x264hip_nr_state_free(self.ctx.h, C.byref(self.nr))
+            self.nr = None
         for s in self.states:
             s.free()
         for d in self.cost.values():

@@ -169,3 +169,28 @@ def test_sweep_random_options_match_twin(hip_lib, oracle_lib, cqm, seed):
             assert np.array_equal(got.reshape(ref.shape), ref), "frame %d: %s (%s %s)" % (f, k, size, kw)
         for nm in ("y", "u", "v"):
             assert np.array_equal(out[f]["fin_" + nm][0], want[("fin_" if kw["deblock"] else "rec_") + nm][f]), "frame %d: %s (%s %s)" % (f, nm, size, kw)
+
+
+@pytest.mark.parametrize("size", [(16, 16), (32, 16), (16, 48), (48, 32), (24, 40)])
+def test_sweep_tiny_frames_match_twin(hip_lib, oracle_lib, cqm, size):
+    """The smallest pictures: one macroblock, one row, one column, ragged 24x40 (mv limits, neighbour availability and the row
+    hand-off degenerate here); smooth random content, the medium-like option set with every partition size."""
+    from oracle import refslice as rs
+    w, h = size
+    frames = 4
+    rng = np.random.default_rng(w * 131 + h)
+    base = rng.integers(0, 256, (h + 16, w + 16)).astype(np.float32)
+    for _ in range(3):                                   # blur: textures that motion search can follow
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(np.roll(base, 1, 0), 1, 1)) / 4
+    y = np.stack([np.clip(base[2 * t:2 * t + h, t:t + w] + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8) for t in range(frames)])
+    u = np.stack([np.clip(base[t:t + h // 2, 2 * t:2 * t + w // 2] * 0.5 + 64, 0, 255).astype(np.uint8) for t in range(frames)])
+    v = np.stack([np.clip(255 - base[t:t + h // 2, t:t + w // 2] * 0.5, 0, 255).astype(np.uint8) for t in range(frames)])
+    kw = dict(qp=24, subme=5, me_method=rs.ME_UMH, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
+    want = rs.run(oracle_lib, "x264o_encode_chain", rs.make_params(w, h, frames, **kw), y, u, v)
+    out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw)
+    for f in range(frames):
+        for k in STATE:
+            got, ref = out[f][k][0], want[k][f]
+            assert np.array_equal(got.reshape(ref.shape), ref), "frame %d: %s" % (f, k)
+        for nm in ("y", "u", "v"):
+            assert np.array_equal(out[f]["fin_" + nm][0], want["fin_" + nm][f]), "frame %d: %s" % (f, nm)

@@ -23,6 +23,7 @@ typedef struct {
     int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
     int noise_reduction;                     /* param.analyse.i_noise_reduction */
+    int mv_range;                            /* param.analyse.i_mv_range (0 = 512) */
 } refslice_params;
 
 typedef struct {
@@ -88,7 +89,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->param.i_log_level = X264_LOG_NONE;
     h->param.analyse.inter = p->inter; h->param.analyse.intra = p->intra;
     h->param.analyse.i_me_method = p->me_method; h->param.analyse.i_me_range = p->me_range;
-    h->param.analyse.i_mv_range = 512; h->param.analyse.i_subpel_refine = p->subme;
+    h->param.analyse.i_mv_range = p->mv_range > 0 ? p->mv_range : 512; h->param.analyse.i_subpel_refine = p->subme;
     h->param.analyse.b_chroma_me = p->chroma_me; h->param.analyse.b_mixed_references = p->mixed_refs;
     h->param.analyse.b_fast_pskip = p->fast_pskip; h->param.analyse.b_dct_decimate = p->dct_decimate;
     h->param.analyse.b_transform_8x8 = p->transform8x8; h->param.analyse.i_trellis = 0;

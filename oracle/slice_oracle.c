@@ -21,6 +21,7 @@ typedef struct {
     int transform8x8, fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs;
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
     int noise_reduction;
+    int mv_range;
 } slice_params;
 
 typedef struct {
@@ -685,7 +686,7 @@ static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2]
     static const u8 bw[7] = {16, 16, 8, 8, 8, 4, 4}, bh[7] = {16, 8, 16, 8, 4, 8, 4};
     int oy = (16 * m->mby + by) * S->sy + 16 * m->mbx + bx, oc = (8 * m->mby + by / 2) * S->sc + 8 * m->mbx + bx / 2, sp[4], fp[4];
     const sframe *r = S->fref[ref];
-    mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, 512, sp, fp);
+    mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, S->p->mv_range > 0 ? S->p->mv_range : 512, sp, fp);
     c->fenc = S->fenc->plane[0] + oy; c->fenc_u = S->fenc->plane[1] + oc; c->fenc_v = S->fenc->plane[2] + oc;
     c->sy = S->sy; c->sc = S->sc;
     for (int k = 0; k < 4; k++) c->fref[k] = r->filt[k] + oy;

@@ -145,7 +145,7 @@ def _random_case(seed):
               transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=int(r.integers(0, 2)), deblock=int(r.integers(0, 2)),
               fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])),
               noise_reduction=int(r.choice([0, 0, 0, 60, 400])), chroma_qp_offset=int(r.choice([0, 0, -4, 3, 6])), alpha_c0=int(r.choice([0, 0, -2, 3])),
-              beta=int(r.choice([0, 0, 2, -3])))
+              beta=int(r.choice([0, 0, 2, -3])), mv_range=int(r.choice([0, 0, 8, 16, 64])))
     if kw["me_method"] == 3:
         kw["subme"] = max(kw["subme"], 1); kw["me_range"] = min(kw["me_range"], 16)       # ESA: undefined at subme 0 in the reference; keep the scan small
     if not kw["transform8x8"]:

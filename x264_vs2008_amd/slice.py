@@ -77,13 +77,13 @@ class ChainEncoder:
 
     def __init__(self, lib, width, height, cqm, batch=1, qp=26, me_method=0, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
-                 chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0):
+                 chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0, mv_range=0):
         self.lib = lib
         self.ctx = FrameCtx(lib, width, height, batch=batch)
         self.opt = dict(qp=qp, me_method=me_method, me_range=me_range, subme=subme, n_refs=n_refs, inter=inter, intra=intra,
                         transform8x8=transform8x8, fast_pskip=fast_pskip, dct_decimate=dct_decimate, chroma_me=chroma_me, cabac=cabac,
                         deblock=deblock, alpha_c0=alpha_c0, beta=beta, chroma_qp_offset=chroma_qp_offset, keyint=keyint, mixed_refs=mixed_refs,
-                        noise_reduction=noise_reduction)
+                        noise_reduction=noise_reduction, mv_range=mv_range)
         self.cqm = CqmDevice(lib, cqm)
         self.cost = {}
         self.fenc = self.ctx.new_picture()
@@ -127,7 +127,7 @@ class ChainEncoder:
         poc = 2 * (self.t - self.last_idr)
         b = self.cqm.bufs
         p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
-                        subme=o["subme"], chroma_me=o["chroma_me"], mv_range=512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
+                        subme=o["subme"], chroma_me=o["chroma_me"], mv_range=o["mv_range"] or 512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
                         cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
                         quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,

@@ -37,6 +37,8 @@ CASES = [
     ("esa_fpel", (200, 120), 3, "static", dict(qp=30, subme=1, me_method=rs.ME_ESA, me_range=16, inter=0x10)),
     ("nr", (208, 144), 6, "moving", dict(qp=28, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1,
                                          cabac=1, deblock=1, noise_reduction=300)),
+    ("jvt", (208, 144), 4, "moving", dict(qp=24, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1,
+                                          cabac=1, deblock=1, cqm_preset=1)),
     ("umh_fpel", (200, 120), 4, "moving", dict(qp=32, subme=1, me_method=rs.ME_UMH, me_range=24, inter=0x10, n_refs=2, deblock=1)),
 ]
 

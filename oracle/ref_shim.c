@@ -30,6 +30,26 @@ int refshim_cqm_flat_init(void)
     g_h->param.rc.i_qp_min = 0;
     return x264_cqm_init(g_h);
 }
+/* x264_cqm_init for a preset (0 flat, 1 jvt) into a fresh context that the getters below then read */
+static x264_t *g_cq;
+int refshim_cqm_init_preset(int preset)
+{
+    int i;
+    g_cq = calloc(1, sizeof(x264_t));
+    if (!g_cq) return -1;
+    g_cq->pps = &g_cq->pps_array[0];
+    for (i = 0; i < 6; i++) g_cq->pps->scaling_list[i] = preset ? x264_cqm_jvt[i] : flat16;
+    g_cq->param.analyse.i_luma_deadzone[0] = 21; g_cq->param.analyse.i_luma_deadzone[1] = 11;
+    g_cq->param.analyse.b_transform_8x8 = 1;
+    g_cq->param.rc.i_qp_min = 51;                     /* do not refuse the low qps whose multipliers overflow 16 bits with jvt */
+    return x264_cqm_init(g_cq);
+}
+const uint16_t *refshim_cq_quant4_mf(int cat, int qp)   { return g_cq->quant4_mf[cat][qp]; }
+const uint16_t *refshim_cq_quant4_bias(int cat, int qp) { return g_cq->quant4_bias[cat][qp]; }
+const uint16_t *refshim_cq_quant8_mf(int cat, int qp)   { return g_cq->quant8_mf[cat][qp]; }
+const uint16_t *refshim_cq_quant8_bias(int cat, int qp) { return g_cq->quant8_bias[cat][qp]; }
+const int *refshim_cq_dequant4_mf(int cat) { return &g_cq->dequant4_mf[cat][0][0][0]; }
+const int *refshim_cq_dequant8_mf(int cat) { return &g_cq->dequant8_mf[cat][0][0][0]; }
 /* cat: 0 intra-Y 1 inter-Y 2 intra-C 3 inter-C (4x4); 0 intra-Y 1 inter-Y (8x8) */
 const uint16_t *refshim_quant4_mf(int cat, int qp)   { return g_h->quant4_mf[cat][qp]; }
 const uint16_t *refshim_quant4_bias(int cat, int qp) { return g_h->quant4_bias[cat][qp]; }

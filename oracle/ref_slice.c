@@ -24,6 +24,7 @@ typedef struct {
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
     int noise_reduction;                     /* param.analyse.i_noise_reduction */
     int mv_range;                            /* param.analyse.i_mv_range (0 = 512) */
+    int cqm_preset;                          /* param.i_cqm_preset: 0 X264_CQM_FLAT, 1 X264_CQM_JVT */
 } refslice_params;
 
 typedef struct {
@@ -96,14 +97,15 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->param.analyse.i_noise_reduction = p->noise_reduction; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
     h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
     h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
-    h->param.rc.i_qp_min = 0; h->param.rc.i_qp_max = 51;
+    h->param.rc.i_qp_min = p->cqm_preset ? 6 : 0; h->param.rc.i_qp_max = 51;   /* jvt: qp < 6 overflows the 16-bit multipliers (x264_cqm_init refuses) */
     h->thread[0] = h;
     h->sps = &h->sps_array[0]; h->pps = &h->pps_array[0];
     mb_w = h->sps->i_mb_width = (p->width + 15) / 16; mb_h = h->sps->i_mb_height = (p->height + 15) / 16;
     h->sps->b_frame_mbs_only = 1;
     n = h->mb.i_mb_count = mb_w * mb_h;
     h->pps->b_cabac = p->cabac; h->pps->b_transform_8x8_mode = p->transform8x8;
-    for (i = 0; i < 6; i++) h->pps->scaling_list[i] = flat16;
+    for (i = 0; i < 6; i++) h->pps->scaling_list[i] = p->cqm_preset ? x264_cqm_jvt[i] : flat16;   /* x264_pps_init, R/encoder/set.c */
+    h->param.i_cqm_preset = p->cqm_preset;
     h->chroma_qp_table = i_chroma_qp_table + 12 + p->chroma_qp_offset;
     if (x264_cqm_init(h) < 0) return -1;
     x264_pixel_init(0, &h->pixf); x264_dct_init(0, &h->dctf); x264_zigzag_init(0, &h->zigzagf, 0);

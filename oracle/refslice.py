@@ -20,17 +20,17 @@ class Params(C.Structure):
     _fields_ = [(k, C.c_int) for k in (
         "width", "height", "n_frames", "qp", "me_method", "me_range", "subme", "n_refs", "inter", "intra",
         "transform8x8", "fast_pskip", "dct_decimate", "chroma_me", "cabac", "mixed_refs",
-        "deblock", "alpha_c0", "beta", "chroma_qp_offset", "keyint", "noise_reduction", "mv_range")]
+        "deblock", "alpha_c0", "beta", "chroma_qp_offset", "keyint", "noise_reduction", "mv_range", "cqm_preset")]
 
 
 def make_params(width, height, n_frames, qp=26, me_method=ME_DIA, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
                 transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, mixed_refs=0, deblock=0,
-                alpha_c0=0, beta=0, chroma_qp_offset=0, keyint=0, noise_reduction=0, mv_range=0):
+                alpha_c0=0, beta=0, chroma_qp_offset=0, keyint=0, noise_reduction=0, mv_range=0, cqm_preset=0):
     if not transform8x8:                      # x264_validate_parameters, R/encoder/encoder.c:487-491
         inter &= ~ANALYSE_I8x8
         intra &= ~ANALYSE_I8x8
     return Params(width, height, n_frames, qp, me_method, me_range, subme, n_refs, inter, intra, transform8x8,
-                  fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs, deblock, alpha_c0, beta, chroma_qp_offset, keyint, noise_reduction, mv_range)
+                  fast_pskip, dct_decimate, chroma_me, cabac, mixed_refs, deblock, alpha_c0, beta, chroma_qp_offset, keyint, noise_reduction, mv_range, cqm_preset)
 
 
 OUT_FIELDS = [("mb_type", np.int8, lambda F, n, R, w, h: (F, n)),

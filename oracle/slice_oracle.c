@@ -22,6 +22,7 @@ typedef struct {
     int deblock, alpha_c0, beta, chroma_qp_offset, keyint;
     int noise_reduction;
     int mv_range;
+    int cqm_preset;                          /* 0 flat, 1 jvt */
 } slice_params;
 
 typedef struct {
@@ -69,7 +70,7 @@ static int s_te_size(int x, int v) { return x == 1 ? 1 : x > 1 ? s_ue_size(v) : 
 static x264hip_predict_t s_p16[7], s_p8c[7], s_p4[12];
 static x264hip_predict8x8_t s_p8[12];
 static x264hip_predict_8x8_filter_t s_p8filter;
-void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant);
+void x264o_cqm(int preset, int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant);
 void x264o_predict_16x16_init(x264hip_predict_t pf[7]);
 void x264o_predict_4x4_init(x264hip_predict_t pf[12]);
 #ifdef X264O_USE_REF
@@ -1220,8 +1221,8 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
         S.lambda = s_lambda_tab[S.qp]; S.lambda2 = s_lambda2_tab[S.qp];
         S.cost_mv = s_load_cost_mv(S.qp);
         for (int i = 0; i < 16; i++) S.ref_cost[i] = S.lambda * s_te_size(clip3i((S.n_ref <= 0 ? 1 : S.n_ref) - 1, 0, 2), i);
-        for (int cat = 0; cat < 4; cat++) x264o_cqm_flat(cat, cat < 2 ? S.qp : S.qpc, 0, S.mf4[cat], S.b4[cat], &S.dq4[cat][0][0]);
-        for (int cat = 0; cat < 2; cat++) x264o_cqm_flat(cat, S.qp, 1, S.mf8[cat], S.b8[cat], &S.dq8[cat][0][0]);
+        for (int cat = 0; cat < 4; cat++) x264o_cqm(p->cqm_preset, cat, cat < 2 ? S.qp : S.qpc, 0, S.mf4[cat], S.b4[cat], &S.dq4[cat][0][0]);
+        for (int cat = 0; cat < 2; cat++) x264o_cqm(p->cqm_preset, cat, S.qp, 1, S.mf8[cat], S.b8[cat], &S.dq8[cat][0][0]);
         /* x264_macroblock_slice_init, R/common/macroblock.c:771-808 */
         S.fdec->n_ref0 = S.n_ref;
         for (int i = 0; i < S.n_ref; i++) {

@@ -732,14 +732,26 @@ static int cls8(int i)
     static const u8 map[16] = {0,3,4,3, 3,1,5,1, 4,5,2,5, 3,1,5,1};
     return map[((i >> 1) & 12) | (i & 3)];
 }
-void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant /* [6][n] or NULL */)
+/* H.264 Table 7-3 / 7-4 default scaling lists (Default_4x4_Intra / _Inter, Default_8x8_Intra / _Inter) in raster order: what
+ * --cqm jvt selects (x264_cqm_jvt, R/common/set.h:166-220); list index = CQM_4IY, 4PY, 4IC, 4PC, 8IY, 8PY */
+static const u8 jvt4i[16] = {6, 13, 20, 28, 13, 20, 28, 32, 20, 28, 32, 37, 28, 32, 37, 42};
+static const u8 jvt4p[16] = {10, 14, 20, 24, 14, 20, 24, 27, 20, 24, 27, 30, 24, 27, 30, 34};
+static const u8 jvt8i[64] = {6, 10, 13, 16, 18, 23, 25, 27, 10, 11, 16, 18, 23, 25, 27, 29, 13, 16, 18, 23, 25, 27, 29, 31, 16, 18, 23, 25, 27, 29, 31, 33,
+                             18, 23, 25, 27, 29, 31, 33, 36, 23, 25, 27, 29, 31, 33, 36, 38, 25, 27, 29, 31, 33, 36, 38, 40, 27, 29, 31, 33, 36, 38, 40, 42};
+static const u8 jvt8p[64] = {9, 13, 15, 17, 19, 21, 22, 24, 13, 13, 17, 19, 21, 22, 24, 25, 15, 17, 19, 21, 22, 24, 25, 27, 17, 19, 21, 22, 24, 25, 27, 28,
+                             19, 21, 22, 24, 25, 27, 28, 30, 21, 22, 24, 25, 27, 28, 30, 32, 22, 24, 25, 27, 28, 30, 32, 33, 24, 25, 27, 28, 30, 32, 33, 35};
+/* x264_cqm_init (R/common/set.c:68-168) for one category and qp.  preset 0 = flat (all 16), 1 = jvt.
+ * cat: 4x4 0 intra-Y 1 inter-Y 2 intra-C 3 inter-C; 8x8 0 intra-Y 1 inter-Y */
+void x264o_cqm(int preset, int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant /* [6][n] or NULL */)
 {
     int n = is8x8 ? 64 : 16;
     int dz = (cat & 1) ? 32 - 21 : 32 - 11;
+    const u8 *list = !preset ? 0 : is8x8 ? (cat & 1 ? jvt8p : jvt8i) : (cat & 1 ? jvt4p : jvt4i);
     for (int i = 0; i < n; i++) {
+        int w = list ? list[i] : 16;
         int q = is8x8 ? base_q8[qp % 6][cls8(i)] : base_q4[qp % 6][cls4(i)];
-        /* flat list: scaling = 16, so the rounded division by it is exact;
-         * then a rounding shift by qp/6-1 (4x4) or qp/6 (8x8) */
+        q = (q * 16 + (w >> 1)) / w;                                   /* DIV(def_quant * 16, scaling_list) */
+        /* then a rounding shift by qp/6-1 (4x4) or qp/6 (8x8) */
         int s = is8x8 ? qp / 6 : qp / 6 - 1;
         int m = s < 0 ? q << -s : s == 0 ? q : (q + (1 << (s - 1))) >> s;
         mf[i] = (u16)m;
@@ -749,8 +761,9 @@ void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant
     if (dequant)
         for (int k = 0; k < 6; k++)
             for (int i = 0; i < n; i++)
-                dequant[k * n + i] = (is8x8 ? base_dq8[k][cls8(i)] : base_dq4[k][cls4(i)]) * 16;
+                dequant[k * n + i] = (is8x8 ? base_dq8[k][cls8(i)] : base_dq4[k][cls4(i)]) * (list ? list[i] : 16);
 }
+void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant) { x264o_cqm(0, cat, qp, is8x8, mf, bias, dequant); }
 
 /* ======================================================================
  * M1-M7: motion compensation and frame filters, R/common/mc.c

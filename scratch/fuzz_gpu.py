@@ -16,6 +16,10 @@ STATE = ["mb_type", "partition", "sub_partition", "ref", "i4mode", "i16mode", "c
 
 
 def run_gpu(hip, cqm, size, frames, y, u, v, kw):
+    kw = dict(kw)
+    if kw.pop("cqm_preset", 0):
+        with np.load(os.path.join(ROOT, "tests", "golden", "cqm_jvt.npz")) as z:
+            cqm = {k: z[k] for k in z.files}
     enc = sl.ChainEncoder(hip, size[0], size[1], cqm, batch=1, **kw)
     out = []
     try:
@@ -51,9 +55,11 @@ def main():
                   transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=int(r.integers(0, 2)), deblock=int(r.integers(0, 2)),
                   fast_pskip=int(r.integers(0, 2)), dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([3, 250])),
                   noise_reduction=int(r.choice([0, 0, 0, 60, 400])), chroma_qp_offset=int(r.choice([0, 0, -4, 3, 6])), alpha_c0=int(r.choice([0, 0, -2, 3])),
-                  beta=int(r.choice([0, 0, 2, -3])), mv_range=int(r.choice([0, 0, 8, 16, 64])))
+                  beta=int(r.choice([0, 0, 2, -3])), mv_range=int(r.choice([0, 0, 8, 16, 64])), cqm_preset=int(r.choice([0, 0, 1])))
         if kw["me_method"] == 3:
             kw["subme"] = max(kw["subme"], 1); kw["me_range"] = min(kw["me_range"], 16)   # ESA: undefined at subme 0 in the reference; keep the scan small
+        if kw["cqm_preset"]:
+            kw["qp"] = max(kw["qp"], 10)             # jvt matrices: qp < 6 overflows the 16-bit multipliers
         if not kw["transform8x8"]:
             kw["inter"] &= ~0x2; kw["intra"] &= ~0x2          # I8x8 needs the 8x8 transform (x264_validate_parameters)
         kind = "moving" if r.integers(0, 2) else "static"

@@ -11,7 +11,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import load_golden
+import os
+
+from conftest import GOLDEN, load_golden
 from oracle import harness
 from x264_vs2008_amd.tables import TableSet
 
@@ -66,3 +68,18 @@ def test_oracle_cqm_tables(oracle_lib, cqm):
                 assert np.array_equal(mf, cqm[mfk][cat][qp])
                 assert np.array_equal(b, cqm[bk][cat][qp])
                 assert np.array_equal(dq.reshape(6, n), cqm[dk][cat])
+
+
+def test_oracle_cqm_jvt_tables(oracle_lib):
+    """x264o_cqm with the H.264 default scaling lists (--cqm jvt) against the tables the reference's x264_cqm_init built for them
+    (tests/golden/cqm_jvt.npz, oracle/gen_golden_cqm.py), every category and qp including the low ones whose multipliers wrap."""
+    with np.load(os.path.join(GOLDEN, "cqm_jvt.npz")) as z:
+        jvt = {k: z[k] for k in z.files}
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for is8, (mfk, bk, dk, ncat, n) in enumerate((("quant4_mf", "quant4_bias", "dequant4_mf", 4, 16),
+                                                  ("quant8_mf", "quant8_bias", "dequant8_mf", 2, 64))):
+        for cat in range(ncat):
+            for qp in range(52):
+                mf = np.zeros(n, np.uint16); b = np.zeros(n, np.uint16); dq = np.zeros(6 * n, np.int32)
+                oracle_lib.x264o_cqm(1, cat, qp, is8, p(mf), p(b), p(dq))
+                assert np.array_equal(mf, jvt[mfk][cat][qp]) and np.array_equal(b, jvt[bk][cat][qp]) and np.array_equal(dq.reshape(6, n), jvt[dk][cat])

@@ -158,15 +158,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
 
-    # the dominant kernel (k_slice_sweep), timed live with HIP events on its launch stream
-    ms_p = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, st, nr in enc.events if st == sl.SLICE_P and nr == args.refs]
+    # the dominant kernel (k_slice_sweep), timed live with HIP events on its launch stream: every launch of the timed region
+    # (P launches with 1..R references and the I launch at the keyint), so that the mean is the one rocprofv3's kernel trace of
+    # the same command shows for the same launches (profiles/r01_bench_sweep_launches.json)
     ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, st, nr in enc.events]
+    # algorithmic bytes of each launch (SURVEY 8(d) terms that belong to this kernel): per frame the source (1.5 B/px), each
+    # reference's four luma planes + chroma (4.5 B/px) and the reconstruction (1.5 B/px)
+    by_all = [B * px * (1.5 + 4.5 * (nr if st == sl.SLICE_P else 0) + 1.5) for a, b, st, nr in enc.events]
     for a, b, _, _ in enc.events:
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
-    sweep_ms = float(np.mean(ms_p)) if ms_p else float(np.mean(ms_all))
-    # algorithmic bytes of one P sweep launch (SURVEY 8(d) terms that belong to this kernel): per frame the
-    # source (1.5 B/px), each reference's four luma planes + chroma (4.5 B/px) and the reconstruction (1.5 B/px)
-    sweep_bytes = int(B * px * (1.5 + 4.5 * args.refs + 1.5))
+    sweep_ms = float(np.mean(ms_all))
+    sweep_bytes = int(np.mean(by_all))
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
 
     # HBM-side traffic of one P sweep launch: not measurable from inside this process (PMC counters need rocprofv3), so the
@@ -181,8 +183,8 @@ def main():
         hit = [l for l in tj["launches"] if l["slice"] == "P" and l["refs"] == args.refs]
         if hit and tj["batch"] == B:
             traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
-            traffic_note = ("FETCH_SIZE + WRITE_SIZE of one P launch with %d references, rocprofv3 --pmc, separate passes, raw request-granular "
-                            "counters (profiles/r01_sweep_traffic.json)" % args.refs)
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE of one P launch with %d references (the most frequent launch of the timed region), rocprofv3 --pmc, "
+                            "separate passes, raw request-granular counters (profiles/r01_sweep_traffic.json)" % args.refs)
 
     if rank == 0:
         fps = world * B * args.steps / dt
@@ -207,7 +209,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_slice_sweep", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
-                         "note": "P-frame launches only; the sweep is bound by dependent memory round trips along the macroblock "
+                         "note": "mean over the timed launches (P with 1..R references and the I launch at the keyint); the sweep is bound by dependent memory round trips along the macroblock "
                                  "dependency chain (mb_w + 2*mb_h = %d serial macroblock steps per frame; PMC: waves wait ~75%% of their "
                                  "cycles), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }

@@ -49,6 +49,8 @@ def main():
     for i in range(n_cfg):
         r = np.random.default_rng(1000 + seed0 + i)
         w, h = int(r.integers(5, 16)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(5, 11)) * 16 - int(r.integers(0, 2)) * 8
+        if os.environ.get("FUZZ_BIG"):              # larger pictures: long vectors, many rows in flight
+            w, h = int(r.integers(20, 46)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(12, 31)) * 16 - int(r.integers(0, 2)) * 8
         frames = int(r.integers(3, 6))
         kw = dict(qp=int(r.integers(18, 42)), subme=int(r.integers(0, 6)), me_method=int(r.choice([0, 1, 1, 2, 2, 3])), me_range=int(r.choice([8, 16, 24])),
                   n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x1, 0x3, 0x10, 0x13, 0x30, 0x33])), intra=int(r.choice([0, 0x1, 0x2, 0x3])),

@@ -200,3 +200,22 @@ def test_sweep_tiny_frames_match_twin(hip_lib, oracle_lib, cqm, size):
             assert np.array_equal(got.reshape(ref.shape), ref), "frame %d: %s" % (f, k)
         for nm in ("y", "u", "v"):
             assert np.array_equal(out[f]["fin_" + nm][0], want["fin_" + nm][f]), "frame %d: %s" % (f, nm)
+
+
+def test_sweep_batched_chains_with_different_content(hip_lib, oracle_lib, cqm):
+    """Four chains in one launch, each fed a different rotation of the clip: every batch element must equal the twin's result for
+    ITS input (no state leaks between the chains of a launch: progress words, LDS, lane-indexed registers, --nr totals)."""
+    from oracle import refslice as rs
+    size, frames, batch = (208, 144), 5, 4
+    kw = dict(qp=27, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1, noise_reduction=150)
+    y, u, v = case_inputs(size, frames, "moving")
+    out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw, batch=batch, shift=1)
+    for b in range(batch):
+        order = [(f + b) % frames for f in range(frames)]
+        want = rs.run(oracle_lib, "x264o_encode_chain", rs.make_params(size[0], size[1], frames, **kw), y[order], u[order], v[order])
+        for f in range(frames):
+            for k in STATE:
+                got, ref = out[f][k][b], want[k][f]
+                assert np.array_equal(got.reshape(ref.shape), ref), "chain %d frame %d: %s" % (b, f, k)
+            for nm in ("y", "u", "v"):
+                assert np.array_equal(out[f]["fin_" + nm][b], want["fin_" + nm][f]), "chain %d frame %d: %s" % (b, f, nm)

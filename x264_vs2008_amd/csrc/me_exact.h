@@ -628,10 +628,7 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
     if (o.subme >= 3) {
         // me.c:188-210: the predictor and every distinct non-zero candidate at quarter-pel precision (SAD)
         const int px = bmx, py = bmy;
-        // Every group also scores the full-pel position its candidate rounds to, and the slot one past the list scores (0,0): the two
-        // COST_MVs that follow the predictor test (the winner's rounded position, then (0,0)) then need no round trip of their own.
-        int fp_win = 0, fp_zero = 0;
-        for (int base = 0; base < 2 + n_mvc; base += 8) {      // eight per trip: one trip for all but the longest lists
+        for (int base = 0; base < 1 + n_mvc; base += 8) {      // eight per trip: one trip for all but the longest lists
             const int k = base + g8;
             int x = px, y = py;
             bool ok = k == 0;
@@ -641,23 +638,16 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
                     ok = true; x = clip3(vx, L.fmin0 * 4, L.fmax0 * 4); y = clip3(vy, L.fmin1 * 4, L.fmax1 * 4);
                 }
             }
-            const bool zero_slot = k == n_mvc + 1;
-            const int rx = zero_slot ? 0 : (x + 2) >> 2, ry = zero_slot ? 0 : (y + 2) >> 2;
             const int cost = sad_qpel8_lane(c, x, y) + c.lane_cost(x, y);
-            const int fp = sad_fpel8_lane(c, rx, ry);
             const u32 key = mx_best_key<3>(cost, ok, lane);
-            if ((key >> 3) < (u32)bpcost) {
-                bpcost = (int)(key >> 3);
-                const int l = (int)(key & 7u) << 3;
-                bpx = __builtin_amdgcn_readlane(x, l); bpy = __builtin_amdgcn_readlane(y, l); fp_win = __builtin_amdgcn_readlane(fp, l);
-            }
-            const int zs = n_mvc + 1 - base;
-            if (zs >= 0 && zs < 8) fp_zero = __builtin_amdgcn_readlane(fp, zs << 3);
+            MX_TAKE(3, key, bpcost, x, y, bpx, bpy);
         }
         bmx = (bpx + 2) >> 2; bmy = (bpy + 2) >> 2;
         // COST_MV(bmx, bmy); COST_MV(0, 0)
-        { const int c0 = fp_win + c.cost(bmx << 2, bmy << 2); if (c0 < bcost) bcost = c0; }
-        { const int c1 = fp_zero + c.cost(0, 0); if (c1 < bcost) { bcost = c1; bmx = 0; bmy = 0; } }
+        const int x = g16 == 0 ? bmx : 0, y = g16 == 0 ? bmy : 0;
+        const int cost = sad_fpel16_lane(c, x, y) + c.lane_cost(x << 2, y << 2);
+        const u32 key = mx_best_key<4>(cost, g16 < 2, lane);
+        MX_TAKE(4, key, bcost, x, y, bmx, bmy);
     } else {
         // me.c:211-229: full-pel predictor (its mv cost taken out again), rounded candidates that differ from the running
         // best, then (0,0).  A candidate equal to the running best cannot win (same SAD, mv cost >= 0), so skipping it or

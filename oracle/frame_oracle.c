@@ -339,11 +339,12 @@ static int me_satd_chroma(const me_ctx *c, int mx, int my, int bcost, int chroma
     return cost;
 }
 
+static int g_me_lossless;             /* set by the slice twin for a lossless chain: every mbcmp is SAD */
 /* returns cost; *pmvx,*pmvy the vector; *thresh the half-pel threshold (NULL = none) */
 static int me_search16(const me_ctx *c, const i16 mvp[2], const i16 (*mvc)[2], int n_mvc, int method, int me_range, int subme,
                        int chroma_me, int *thresh, int *pmvx, int *pmvy, int *pcost_mv)
 {
-    const int satd = subme > 1;       /* mbcmp = SATD above subme 1; fpelcmp stays SAD (encoder.c:608-618) */
+    const int satd = subme > 1 && !g_me_lossless;   /* mbcmp = SATD above subme 1 unless lossless; fpelcmp stays SAD (encoder.c:608-618) */
     int bmx = clip3i(mvp[0], c->fmin[0] * 4, c->fmax[0] * 4), bmy = clip3i(mvp[1], c->fmin[1] * 4, c->fmax[1] * 4);
     int pmx = (bmx + 2) >> 2, pmy = (bmy + 2) >> 2;
     int bcost = ME_COST_MAX, bpx = 0, bpy = 0, bpcost = ME_COST_MAX, cost, i;

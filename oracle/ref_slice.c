@@ -45,7 +45,7 @@ typedef struct {
 
 static void sel_cmp(x264_t *h)        /* what mbcmp_init selects (R/encoder/encoder.c:608-618) */
 {
-    int satd = h->param.analyse.i_subpel_refine > 1;
+    int satd = !h->mb.b_lossless && h->param.analyse.i_subpel_refine > 1;
     memcpy(h->pixf.mbcmp, satd ? h->pixf.satd : h->pixf.sad_aligned, sizeof(h->pixf.mbcmp));
     memcpy(h->pixf.mbcmp_unaligned, satd ? h->pixf.satd : h->pixf.sad, sizeof(h->pixf.mbcmp_unaligned));
     h->pixf.intra_mbcmp_x3_16x16 = satd ? h->pixf.intra_satd_x3_16x16 : h->pixf.intra_sad_x3_16x16;
@@ -98,15 +98,21 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
     h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
     h->param.rc.i_qp_min = p->cqm_preset ? 6 : 0; h->param.rc.i_qp_max = 51;   /* jvt: qp < 6 overflows the 16-bit multipliers (x264_cqm_init refuses) */
+    if (p->qp == 0) {                                    /* x264_validate_parameters, R/encoder/encoder.c:401-421: lossless */
+        h->mb.b_lossless = 1;
+        h->param.rc.f_ip_factor = 1; h->param.rc.f_pb_factor = 1;
+        h->param.analyse.i_chroma_qp_offset = 0; h->param.analyse.b_fast_pskip = 0; h->param.analyse.i_noise_reduction = 0;
+        if (!h->param.b_cabac) h->param.analyse.b_transform_8x8 = 0;
+    }
     h->thread[0] = h;
     h->sps = &h->sps_array[0]; h->pps = &h->pps_array[0];
     mb_w = h->sps->i_mb_width = (p->width + 15) / 16; mb_h = h->sps->i_mb_height = (p->height + 15) / 16;
     h->sps->b_frame_mbs_only = 1;
     n = h->mb.i_mb_count = mb_w * mb_h;
-    h->pps->b_cabac = p->cabac; h->pps->b_transform_8x8_mode = p->transform8x8;
+    h->pps->b_cabac = p->cabac; h->pps->b_transform_8x8_mode = h->param.analyse.b_transform_8x8;
     for (i = 0; i < 6; i++) h->pps->scaling_list[i] = p->cqm_preset ? x264_cqm_jvt[i] : flat16;   /* x264_pps_init, R/encoder/set.c */
     h->param.i_cqm_preset = p->cqm_preset;
-    h->chroma_qp_table = i_chroma_qp_table + 12 + p->chroma_qp_offset;
+    h->chroma_qp_table = i_chroma_qp_table + 12 + h->param.analyse.i_chroma_qp_offset;
     if (x264_cqm_init(h) < 0) return -1;
     x264_pixel_init(0, &h->pixf); x264_dct_init(0, &h->dctf); x264_zigzag_init(0, &h->zigzagf, 0);
     x264_quant_init(h, 0, &h->quantf); x264_mc_init(0, &h->mc); x264_deblock_init(0, &h->loopf);

@@ -129,6 +129,7 @@ typedef struct {
     slice_out *o;
     int f;
     /* --nr: h->nr_residual_sum / nr_count / nr_offset, [0] 4x4, [1] 8x8 (R/common/common.h:308-310) */
+    int lossless;                            /* h->mb.b_lossless: constant QP 0 (R/encoder/encoder.c:401-421) */
     uint32_t nr_sum[2][64], nr_count[2];
     uint16_t nr_offset[2][64];
 } ssl;
@@ -254,8 +255,56 @@ static int predict_mv_ref16x16(const ssl *S, const smb *m, int i_ref, i16 mvc[8]
 
 /* ------------------------------------------------------------------ encode pieces
  * x264_mb_encode_i4x4 / _i8x8 / _i16x16 / _8x8_chroma, R/encoder/macroblock.c:116-363 (no trellis, not lossless) */
+/* ---- lossless (qp 0): predictive lossless intra prediction and the zigzag "transforms" (R/encoder/macroblock.c:405-470, R/common/dct.c:564-606) ---- */
+static const u8 s_z2r_yx[16] = {0, 4, 1, 5, 8, 12, 9, 13, 2, 6, 3, 7, 10, 14, 11, 15};  /* block_idx_yx_1d */
+static int any_nz(const i16 *l, int n) { for (int i = 0; i < n; i++) if (l[i]) return 1; return 0; }
+/* the source plane (with its borders) at pixel (x, y) of this macroblock: h->mb.pic.p_fenc_plane */
+static const u8 *ll_src(const ssl *S, const smb *m, int pl, int x, int y)
+{
+    const int w = pl ? 8 : 16, st = pl ? S->sc : S->sy;
+    return S->fenc->plane[pl] + (w * m->mby + y) * st + w * m->mbx + x;
+}
+static void ll_copy(u8 *dst, const u8 *src, int stride, int w, int h) { for (int y = 0; y < h; y++) memcpy(dst + y * FDEC, src + y * stride, w); }
+/* x264_predict_lossless_*: vertical / horizontal prediction copy the source shifted by one row / column, the other modes predict as usual */
+static void pred_16x16(const ssl *S, smb *m, int mode)
+{
+    if (S->lossless && mode == 0) ll_copy(m->fd[0], ll_src(S, m, 0, 0, -1), S->sy, 16, 16);
+    else if (S->lossless && mode == 1) ll_copy(m->fd[0], ll_src(S, m, 0, -1, 0), S->sy, 16, 16);
+    else s_p16[mode](m->fd[0]);
+}
+static void pred_chroma(const ssl *S, smb *m, int mode)     /* slots: DC 0, H 1, V 2, P 3 */
+{
+    for (int pl = 1; pl < 3; pl++) {
+        if (S->lossless && mode == 2) ll_copy(m->fd[pl], ll_src(S, m, pl, 0, -1), S->sc, 8, 8);
+        else if (S->lossless && mode == 1) ll_copy(m->fd[pl], ll_src(S, m, pl, -1, 0), S->sc, 8, 8);
+        else s_p8c[mode](m->fd[pl]);
+    }
+}
+static void pred_8x8(const ssl *S, smb *m, int idx, int mode, u8 *edge)
+{
+    u8 *dst = m->fd[0] + 8 * (idx & 1) + 8 * (idx >> 1) * FDEC;
+    if (S->lossless && mode == 0) ll_copy(dst, ll_src(S, m, 0, 8 * (idx & 1), 8 * (idx >> 1) - 1), S->sy, 8, 8);
+    else if (S->lossless && mode == 1) ll_copy(dst, ll_src(S, m, 0, 8 * (idx & 1) - 1, 8 * (idx >> 1)), S->sy, 8, 8);
+    else s_p8[mode](dst, edge);
+}
+static void pred_4x4(const ssl *S, smb *m, int idx, int mode)
+{
+    u8 *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
+    if (S->lossless && mode == 0) ll_copy(dst, ll_src(S, m, 0, blk_x[idx], blk_y[idx] - 1), S->sy, 4, 4);
+    else if (S->lossless && mode == 1) ll_copy(dst, ll_src(S, m, 0, blk_x[idx] - 1, blk_y[idx]), S->sy, 4, 4);
+    else s_p4[mode](dst);
+}
+
 static void enc_i4x4(ssl *S, smb *m, int idx)
 {
+    if (S->lossless) {                                   /* macroblock.c:123-130 */
+        u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
+        zigf[0].sub_4x4(m->luma4[idx], src, dst);
+        int nz = any_nz(m->luma4[idx], 16);
+        m->nnz[idx] = nz;
+        m->cbp_luma |= nz << (idx >> 2);
+        return;
+    }
     i16 d[4][4];
     u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
     dctf.sub4x4_dct(d, src, dst);
@@ -273,6 +322,13 @@ static void enc_i8x8(ssl *S, smb *m, int idx)
     i16 d[8][8];
     int x = 8 * (idx & 1), y = 8 * (idx >> 1);
     u8 *src = m->fe[0] + x + y * FENC, *dst = m->fd[0] + x + y * FDEC;
+    if (S->lossless) {                                   /* macroblock.c:160-167 */
+        zigf[0].sub_8x8(m->luma8[idx], src, dst);
+        int nz = any_nz(m->luma8[idx], 64);
+        for (int k = 0; k < 4; k++) m->nnz[4 * idx + k] = nz;
+        m->cbp_luma |= nz << idx;
+        return;
+    }
     dctf.sub8x8_dct8(d, src, dst);
     int nz = quantf.quant_8x8(d, S->mf8[0], S->b8[0]);
     if (nz) {
@@ -287,6 +343,20 @@ static void enc_i16x16(ssl *S, smb *m)
 {
     i16 d[16][4][4], dc[4][4];
     int b_decimate = S->p->dct_decimate && S->slice_type == S_SLICE_P, score = b_decimate ? 0 : 9, nz;
+    if (S->lossless) {                                   /* macroblock.c:196-213 */
+        for (int i = 0; i < 16; i++) {
+            zigf[0].sub_4x4(m->luma4[i], m->fe[0] + blk_x[i] + blk_y[i] * FENC, m->fd[0] + blk_x[i] + blk_y[i] * FDEC);
+            dc[0][s_z2r_yx[i]] = m->luma4[i][0];
+            m->luma4[i][0] = 0;
+            nz = any_nz(m->luma4[i], 16);
+            m->nnz[i] = nz;
+            m->cbp_luma |= nz;
+        }
+        m->cbp_luma *= 0xf;
+        m->nnz[24] = any_nz(&dc[0][0], 16);
+        zigf[0].scan_4x4(m->dc16, dc);
+        return;
+    }
     dctf.sub16x16_dct(d, m->fe[0], m->fd[0]);
     for (int i = 0; i < 16; i++) {
         dc[0][s_z2r[i]] = d[i][0][0];
@@ -323,6 +393,19 @@ static void enc_chroma(ssl *S, smb *m, int b_inter)
         u8 *ps = m->fe[1 + ch], *pd = m->fd[1 + ch];
         i16 d4[4][4][4], d2[2][2];
         int score = 0, nz_ac = 0;
+        if (S->lossless) {                               /* macroblock.c:288-303 */
+            for (int i = 0; i < 4; i++) {
+                i16 *lv = m->cac[4 * ch + i];
+                zigf[0].sub_4x4(lv, ps + 4 * (i & 1) + 4 * (i >> 1) * FENC, pd + 4 * (i & 1) + 4 * (i >> 1) * FDEC);
+                m->cdc[ch][i] = lv[0];
+                lv[0] = 0;
+                int nz = any_nz(lv, 16);
+                m->nnz[16 + 4 * ch + i] = nz;
+                m->cbp_chroma |= nz;
+            }
+            m->nnz[25 + ch] = any_nz(m->cdc[ch], 4);
+            continue;
+        }
         dctf.sub8x8_dct(d4, ps, pd);
         {   /* dct2x2dc, :73-85 */
             int a = d4[0][0][0] + d4[1][0][0], b = d4[2][0][0] + d4[3][0][0];
@@ -371,12 +454,21 @@ static void enc_chroma(ssl *S, smb *m, int b_inter)
 static void enc_inter_luma(ssl *S, smb *m)
 {
     int b_decimate = S->p->dct_decimate, decimate_mb = 0;
+    if (S->lossless) {                                   /* macroblock.c:602-626 (the 8x8 transform is never chosen for inter here, analyse.c:2111) */
+        for (int i = 0; i < 16; i++) {
+            zigf[0].sub_4x4(m->luma4[i], m->fe[0] + blk_x[i] + blk_y[i] * FENC, m->fd[0] + blk_x[i] + blk_y[i] * FDEC);
+            int nz = any_nz(m->luma4[i], 16);
+            m->nnz[i] = nz;
+            m->cbp_luma |= nz << (i >> 2);
+        }
+        return;
+    }
     if (m->t8) {
         i16 d8[4][8][8];
         dctf.sub16x16_dct8(d8, m->fe[0], m->fd[0]);
-        if (S->p->noise_reduction) S->nr_count[1] += 4;
+        if (S->p->noise_reduction && !S->lossless) S->nr_count[1] += 4;
         for (int idx = 0; idx < 4; idx++) {
-            if (S->p->noise_reduction) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
+            if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
             int nz = quantf.quant_8x8(d8[idx], S->mf8[1], S->b8[1]);
             if (nz) {
                 zigf[0].scan_8x8(m->luma8[idx], d8[idx]);
@@ -401,11 +493,11 @@ static void enc_inter_luma(ssl *S, smb *m)
     } else {
         i16 d4[16][4][4];
         dctf.sub16x16_dct(d4, m->fe[0], m->fd[0]);
-        if (S->p->noise_reduction) S->nr_count[0] += 16;
+        if (S->p->noise_reduction && !S->lossless) S->nr_count[0] += 16;
         for (int i8 = 0; i8 < 4; i8++) {
             int dec8 = 0, cbp = 0;
             for (int i4 = 0; i4 < 4; i4++) {
-                if (S->p->noise_reduction) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
+                if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
                 int idx = 4 * i8 + i4, nz = quantf.quant_4x4(d4[idx], S->mf4[1], S->b4[1]);
                 m->nnz[idx] = nz;
                 if (nz) {
@@ -538,11 +630,11 @@ static int pred_intra4x4_mode(const smb *m, int idx)
 /* x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610 */
 static void analyse_intra_chroma(ssl *S, smb *m)
 {
-    int mode[4], n, satd = S->p->subme > 1;
+    int mode[4], n, satd = S->p->subme > 1 && !S->lossless;
     if (m->satd_chroma < S_COST_MAX) return;
     n = modes_chroma(m->nb, mode);
     for (int i = 0; i < n; i++) {
-        s_p8c[mode[i]](m->fd[1]); s_p8c[mode[i]](m->fd[2]);
+        pred_chroma(S, m, mode[i]);
         int c = (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[1], FDEC, m->fe[1], FENC)
               + (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[2], FDEC, m->fe[2], FENC)
               + S->lambda * s_ue_size(s_fix8c[mode[i]]);
@@ -553,12 +645,12 @@ static void analyse_intra_chroma(ssl *S, smb *m)
 /* x264_mb_analyse_intra, :612-843 */
 static void analyse_intra(ssl *S, smb *m, int satd_inter)
 {
-    const int flags = S->slice_type == S_SLICE_I ? S->p->intra : S->p->inter, satd = S->p->subme > 1;
+    const int flags = S->slice_type == S_SLICE_I ? S->p->intra : S->p->inter, satd = S->p->subme > 1 && !S->lossless;
     x264hip_pixel_cmp_t *cmp = satd ? pixf.satd : pixf.sad;
     int mode[9], n;
     n = modes_16x16(m->nb, mode);
     for (int i = 0; i < n; i++) {
-        s_p16[mode[i]](m->fd[0]);
+        pred_16x16(S, m, mode[i]);
         int c = cmp[X264HIP_PIXEL_16x16](m->fd[0], FDEC, m->fe[0], FENC) + S->lambda * s_ue_size(s_fix16[mode[i]]);
         if (c < m->satd_i16) { m->satd_i16 = c; m->pred16 = mode[i]; }
     }
@@ -575,13 +667,13 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
             n = modes_4x4(m->nb8[idx], mode);
             s_p8filter(dst, edge, m->nb8[idx], 0xf);
             for (int i = 0; i < n; i++) {
-                s_p8[mode[i]](dst, edge);
+                pred_8x8(S, m, idx, mode[i], edge);
                 int c = sa8d(dst, FDEC, src, FENC) + S->lambda * (pm == s_fix4[mode[i] + 1] ? 1 : 4);
                 if (c < best) { best = c; m->pred8[idx] = mode[i]; }
             }
             cost += best;
             if (idx == 3 || cost > thresh) break;
-            s_p8[m->pred8[idx]](dst, edge);
+            pred_8x8(S, m, idx, m->pred8[idx], edge);
             enc_i8x8(S, m, idx);
             for (int k = 0; k < 4; k++) m->i4c[s_scan8(4 * idx) + (k & 1) + 8 * (k >> 1)] = m->pred8[idx];
         }
@@ -606,13 +698,13 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
             n = modes_4x4(m->nb4[idx], mode);
             if ((m->nb4[idx] & (NB_TOPRIGHT | NB_TOP)) == NB_TOP) memset(dst + 4 - FDEC, dst[3 - FDEC], 4);
             for (int i = 0; i < n; i++) {
-                s_p4[mode[i]](dst);
+                pred_4x4(S, m, idx, mode[i]);
                 int c = cmp[X264HIP_PIXEL_4x4](dst, FDEC, src, FENC) + S->lambda * (pm == s_fix4[mode[i] + 1] ? 1 : 4);
                 if (c < best) { best = c; m->pred4[idx] = mode[i]; }
             }
             cost += best;
             if (cost > thresh || idx == 15) break;
-            s_p4[m->pred4[idx]](dst);
+            pred_4x4(S, m, idx, m->pred4[idx]);
             enc_i4x4(S, m, idx);
             m->i4c[s_scan8(idx)] = m->pred4[idx];
         }
@@ -732,7 +824,7 @@ static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
 static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
 {
     int subme = S->p->subme, hpel = me_subpel_iters[subme][0], qpel = me_subpel_iters[subme][1];
-    int satd = subme > 1, chroma_me = S->p->chroma_me && subme >= 5 && c->pix <= X264HIP_PIXEL_8x8;   /* b_chroma_me && i_pixel <= PIXEL_8x8, me.c:654 */
+    int satd = subme > 1 && !S->lossless, chroma_me = S->p->chroma_me && subme >= 5 && c->pix <= X264HIP_PIXEL_8x8;   /* b_chroma_me && i_pixel <= PIXEL_8x8, me.c:654 */
     int bx = *pmx, by = *pmy, bc = cost, i, cst;
     if (hpel && subme < 3) {
         int mx = clip3i(mvp[0], c->smin[0], c->smax[0]), my = clip3i(mvp[1], c->smin[1], c->smax[1]);
@@ -778,7 +870,8 @@ static int p4x4_chroma(const ssl *S, const smb *m, int ref, int i8, int sub, con
         mcf.mc_chroma(&pix1[x + y * 16], 16, r->plane[1] + oc + x + y * S->sc, S->sc, me[k].mvx, me[k].mvy, w, h);
         mcf.mc_chroma(&pix2[x + y * 16], 16, r->plane[2] + oc + x + y * S->sc, S->sc, me[k].mvx, me[k].mvy, w, h);
     }
-    return (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[1] + oe, FENC, pix1, 16) + (S->p->subme > 1 ? pixf.satd : pixf.sad)[6](m->fe[2] + oe, FENC, pix2, 16);
+    const int satd = S->p->subme > 1 && !S->lossless;
+    return (satd ? pixf.satd : pixf.sad)[6](m->fe[1] + oe, FENC, pix1, 16) + (satd ? pixf.satd : pixf.sad)[6](m->fe[2] + oe, FENC, pix2, 16);
 }
 
 /* x264_noise_reduction_update, R/encoder/macroblock.c:890-911 (weights: x264_dct4_weight2_tab / x264_dct8_weight2_tab, dct.h:56-83) */
@@ -819,7 +912,7 @@ static void analyse_mb(ssl *S, smb *m)
         if (m->satd_i8 < i_cost) { i_cost = m->satd_i8; m->type = S_I_8x8; }
     } else {
         int b_skip = 0, try_pskip = 0;
-        if (p->fast_pskip) {
+        if (p->fast_pskip && !S->lossless) {
             if (p->subme >= 3) try_pskip = 1;
             else if (m->type_left == S_P_SKIP || m->type_top == S_P_SKIP || m->type_topleft == S_P_SKIP || m->type_topright == S_P_SKIP)
                 b_skip = probe_pskip(S, m);
@@ -1065,7 +1158,7 @@ static void update_mb(ssl *S, smb *m)
     }
     /* x264_mb_transform_8x8_allowed (R/common/macroblock.h): a P_8x8 macroblock only with four 8x8 sub-partitions */
     if ((m->type == S_P_L0 || (m->type == S_P_8x8 && m->sub[0] == S_D_L0_8x8 && m->sub[1] == S_D_L0_8x8 && m->sub[2] == S_D_L0_8x8 && m->sub[3] == S_D_L0_8x8))
-        && S->p->transform8x8) {
+        && S->p->transform8x8 && !S->lossless) {
         mc_parts(S, m);
         int c8 = pixf.sa8d[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
         int c4 = pixf.satd[X264HIP_PIXEL_16x16](m->fe[0], FENC, m->fd[0], FDEC);
@@ -1090,8 +1183,26 @@ static void encode_mb(ssl *S, smb *m)
     }
     if (m->type == S_I_16x16) {
         m->t8 = 0;
-        s_p16[m->i16mode](m->fd[0]);
+        pred_16x16(S, m, m->i16mode);
         enc_i16x16(S, m);
+    } else if (S->lossless && (m->type == S_I_8x8 || m->type == S_I_4x4)) {
+        /* i_skip_intra = 0 (analyse.c:250): nothing of the analysis' trial encode is kept, every block is predicted and coded again */
+        u8 edge[40];
+        m->t8 = m->type == S_I_8x8;
+        if (m->type == S_I_8x8)
+            for (int i = 0; i < 4; i++) {
+                const int mode = m->i4c[s_scan8(4 * i)];
+                s_p8filter(m->fd[0] + 8 * (i & 1) + 8 * (i >> 1) * FDEC, edge, m->nb8[i], s_pred4_nb[mode]);
+                pred_8x8(S, m, i, mode, edge);
+                enc_i8x8(S, m, i);
+            }
+        else
+            for (int i = 0; i < 16; i++) {
+                u8 *dst = m->fd[0] + blk_x[i] + blk_y[i] * FDEC;
+                if ((m->nb4[i] & (NB_TOPRIGHT | NB_TOP)) == NB_TOP) memset(dst + 4 - FDEC, dst[3 - FDEC], 4);
+                pred_4x4(S, m, i, m->i4c[s_scan8(i)]);
+                enc_i4x4(S, m, i);
+            }
     } else if (m->type == S_I_8x8) {
         u8 edge[40];
         m->t8 = 1;
@@ -1118,7 +1229,7 @@ static void encode_mb(ssl *S, smb *m)
         if (!m->skip_mc) mc_parts(S, m);
         enc_inter_luma(S, m);
     }
-    if (S_IS_INTRA(m->type)) { s_p8c[m->chroma_mode](m->fd[1]); s_p8c[m->chroma_mode](m->fd[2]); }
+    if (S_IS_INTRA(m->type)) pred_chroma(S, m, m->chroma_mode);
     enc_chroma(S, m, !S_IS_INTRA(m->type));
     if (m->type == S_P_L0 && m->partition == S_D_16x16 && !(m->cbp_luma | m->cbp_chroma) && m->mv4[0][0] == m->pskip_mv[0]
         && m->mv4[0][1] == m->pskip_mv[1] && m->ref8[0] == 0)
@@ -1191,6 +1302,8 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     if (p->subme > 5 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
     memset(&S, 0, sizeof(S));
     S.p = p; S.o = o;
+    S.lossless = p->qp == 0;                 /* constant QP 0 = lossless (x264_validate_parameters) */
+    g_me_lossless = S.lossless;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;
     S.w16 = 16 * S.mb_w; S.h16 = 16 * S.mb_h;
     S.sy = (S.w16 + 64 + 15) & ~15; S.sc = ((S.sy >> 1) + 15) & ~15;
@@ -1217,7 +1330,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
         S.slice_type = idr ? S_SLICE_I : S_SLICE_P;
         /* CQP: x264_ratecontrol_new / _start, R/encoder/ratecontrol.c:370-373,845-853 (ip_factor 1.4) */
         S.qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51) : p->qp;
-        S.qpc = s_chroma_qp[clip3i(S.qp + p->chroma_qp_offset, 0, 51)];
+        S.qpc = s_chroma_qp[clip3i(S.qp + (S.lossless ? 0 : p->chroma_qp_offset), 0, 51)];
         S.lambda = s_lambda_tab[S.qp]; S.lambda2 = s_lambda2_tab[S.qp];
         S.cost_mv = s_load_cost_mv(S.qp);
         for (int i = 0; i < 16; i++) S.ref_cost[i] = S.lambda * s_te_size(clip3i((S.n_ref <= 0 ? 1 : S.n_ref) - 1, 0, 2), i);

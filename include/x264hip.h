@@ -247,6 +247,10 @@ typedef struct {
      * x264_denoise_dct with nr->offset before quantisation and their magnitudes / block counts are added to nr->sum / nr->count */
     int noise_reduction;
     const struct x264hip_nr_state *nr;
+    /* h->mb.b_lossless (constant QP 0, R/encoder/encoder.c:401-421): predictive lossless intra prediction, the prediction error
+     * itself in zigzag order as levels, SAD for every comparison, no transform-size analysis.  The caller applies the rest of
+     * x264_validate_parameters: qp 0 for every slice, chroma_qp_offset 0, fast_pskip 0, noise_reduction 0, 8x8dct only with CABAC */
+    int lossless;
 } x264hip_slice_params;
 
 /* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:

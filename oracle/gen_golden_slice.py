@@ -40,6 +40,10 @@ CASES = [
     ("jvt", (208, 144), 4, "moving", dict(qp=24, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1,
                                           cabac=1, deblock=1, cqm_preset=1)),
     ("umh_fpel", (200, 120), 4, "moving", dict(qp=32, subme=1, me_method=rs.ME_UMH, me_range=24, inter=0x10, n_refs=2, deblock=1)),
+    # lossless (constant QP 0): predictive lossless intra prediction, zigzag residuals, SAD everywhere
+    ("lossless", (208, 144), 4, "moving", dict(qp=0, subme=5, me_method=rs.ME_HEX, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1,
+                                               cabac=1, deblock=1)),
+    ("lossless_cavlc", (176, 112), 3, "static", dict(qp=0, subme=2, me_method=rs.ME_UMH, n_refs=1, inter=0x11, intra=0x1, deblock=1)),
 ]
 
 

@@ -62,6 +62,10 @@ def main():
             kw["subme"] = max(kw["subme"], 1); kw["me_range"] = min(kw["me_range"], 16)   # ESA: undefined at subme 0 in the reference; keep the scan small
         if kw["cqm_preset"]:
             kw["qp"] = max(kw["qp"], 10)             # jvt matrices: qp < 6 overflows the 16-bit multipliers
+        if r.random() < float(os.environ.get("FUZZ_LOSSLESS", "0.12")):     # lossless: x264_validate_parameters' consequences
+            kw["qp"] = 0; kw["cqm_preset"] = 0
+            if not kw["cabac"]:
+                kw["transform8x8"] = 0
         if not kw["transform8x8"]:
             kw["inter"] &= ~0x2; kw["intra"] &= ~0x2          # I8x8 needs the 8x8 transform (x264_validate_parameters)
         kind = "moving" if r.integers(0, 2) else "static"

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * MX_WAVES) void k_me_search16(const u8 *__restr
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     const MeLimits L = me_limits(mbx, mby, g.mb_w, g.mb_h, g.mv_range);
-    const MeOpts o = {g.method, g.me_range, g.subme, g.chroma_me};
+    const MeOpts o = {g.method, g.me_range, g.subme, g.chroma_me, 0};
     int thresh = 0x7fffffff, bestc = 0x7fffffff, best_r = 0, best_x = 0, best_y = 0;
 
     for (int r = 0; r < g.n_refs; r++) {     // the loop of x264_mb_analyse_inter_p16x16, R/encoder/analyse.c:1090-1127

@@ -74,6 +74,7 @@ struct SwArgs {
     int *progress, *abort_flag;
     long long *prof;            // optional [batch][mb_h][8] accumulated wall-clock ticks per phase (developer aid)
     int nr;                     // param.analyse.i_noise_reduction != 0
+    int lossless;               // h->mb.b_lossless
     u32 *nr_sum, *nr_count;     // [batch][2][64], [batch][2]
     const u16 *nr_offset;       // [batch][2][64]
 };
@@ -242,7 +243,17 @@ __device__ __forceinline__ int sw_cmp_chroma(const SwLds &s, int satd, int lane)
 // ---- intra prediction into s.fd ----------------------------------------------------------------
 // x264_predict_16x16_* (R/common/predict.c:52-170): the sums the DC and plane modes need are reduced
 // across the wave once per call instead of per pixel
-__device__ __forceinline__ void sw_pred16(SwLds &s, int mode, int lane)
+// x264_predict_lossless_* (R/encoder/macroblock.c:405-470): vertical / horizontal prediction take the SOURCE one row up / one column
+// left.  Everything coded so far reconstructs to its source, so outside the macroblock that is the neighbour row / column
+// already in s.fd and inside it the macroblock's own source in s.fe.  (x, y) relative to the macroblock; plane 0 luma, 1 U, 2 V.
+__device__ __forceinline__ int sw_ll_px(const SwLds &s, int plane, int horiz, int x, int y)
+{
+    const int st = plane ? 8 : 16;
+    const u8 *fe = s.fe + (plane == 0 ? 0 : plane == 1 ? 256 : 320), *fd = s.fd + (plane == 0 ? FDY : plane == 1 ? FDU : FDV);
+    if (horiz) return x == 0 ? fd[y * FD - 1] : fe[y * st + x - 1];
+    return y == 0 ? fd[x - FD] : fe[(y - 1) * st + x];
+}
+__device__ __forceinline__ void sw_pred16(SwLds &s, int mode, int lane, int ll = 0)
 {
     const int r = lane >> 2, x = (lane & 3) * 4;
     const u8 *top = s.fd + FDY - FD, *left = s.fd + FDY - 1;
@@ -268,15 +279,20 @@ __device__ __forceinline__ void sw_pred16(SwLds &s, int mode, int lane)
         }
         v[0] = v[1] = v[2] = v[3] = dc;
     }
+    if (ll && mode < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = sw_ll_px(s, 0, mode, x + i, r);
+    }
     WAVE_SYNC();
 #pragma unroll
     for (int i = 0; i < 4; i++) s.fd[FDY + r * FD + x + i] = (u8)v[i];
     WAVE_SYNC();
 }
-__device__ __forceinline__ void sw_pred8c(SwLds &s, int mode, int lane)
+__device__ __forceinline__ void sw_pred8c(SwLds &s, int mode, int lane, int ll = 0)
 {
     const int x = lane & 7, y = lane >> 3;
     int pu = pred_px(1, mode, s.fd + FDU, FD, x, y), pv = pred_px(1, mode, s.fd + FDV, FD, x, y);
+    if (ll && (mode == 1 || mode == 2)) { pu = sw_ll_px(s, 1, mode == 1, x, y); pv = sw_ll_px(s, 2, mode == 1, x, y); }
     WAVE_SYNC();
     s.fd[FDU + y * FD + x] = (u8)pu; s.fd[FDV + y * FD + x] = (u8)pv;
     WAVE_SYNC();
@@ -365,9 +381,14 @@ __device__ __forceinline__ void sw_luma4x4_add(SwLds &s, int lane, int keep8)
     }
     WAVE_SYNC();
 }
+__device__ __forceinline__ void sw_ll_i4x4(SwLds &s, int idx, int &cbp_luma, int lane);
+__device__ __forceinline__ void sw_ll_i8x8(SwLds &s, int idx, int &cbp_luma, int lane);
+__device__ __forceinline__ int sw_ll_luma16(SwLds &s, bool dc_out, int lane);
+__device__ __forceinline__ int sw_ll_chroma(SwLds &s, int lane);
 // x264_macroblock_encode's inter 4x4-transform branch; returns cbp_luma, fills s.nnz[0..15]
 __device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane, int *nr_acc4 = nullptr)
 {
+    if (a.lossless) return sw_ll_luma16(s, false, lane);
     sw_luma4x4_fwd(s, a, 1, false, lane, nr_acc4);
     if (lane == 0) {
         int cbp = 0, dec_mb = 0;
@@ -395,6 +416,7 @@ __device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, i
 // x264_mb_encode_i16x16 (prediction already in s.fd); returns cbp_luma, fills s.nnz[0..15], s.nnz[24]
 __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int lane)
 {
+    if (a.lossless) return sw_ll_luma16(s, true, lane);
     sw_luma4x4_fwd(s, a, 0, true, lane);
     if (lane == 0) {
         const int b_decimate = a.dct_decimate && a.slice_type == 0;
@@ -463,6 +485,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
 // x264_mb_encode_8x8_chroma; returns cbp_chroma, fills s.nnz[16..23], s.nnz[25..26]
 __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b_inter, int lane)
 {
+    if (a.lossless) return sw_ll_chroma(s, lane);
     const int cat = 2 + b_inter, b_decimate = b_inter && a.dct_decimate;
     const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
     if (lane < 8) {
@@ -721,6 +744,7 @@ __device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, 
 // x264_mb_encode_i8x8 for block idx (prediction already in s.fd)
 __device__ __forceinline__ void sw_encode_i8x8(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
 {
+    if (a.lossless) { sw_ll_i8x8(s, idx, cbp_luma, lane); return; }
     sw_luma8x8_fwd(s, 0, 1 << idx, lane);
     const int nz = (__builtin_amdgcn_readfirstlane(s.score[idx]) >> 8) & 1;
     if (lane < 4) s.nnz[4 * idx + lane] = (u8)nz;
@@ -753,6 +777,7 @@ __device__ __forceinline__ int sw_inv4_quad(int v, int k, int last)   // dct.c:1
 }
 __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
 {
+    if (a.lossless) { sw_ll_i4x4(s, idx, cbp_luma, lane); return; }
     int bx, by;
     sw_blk_xy(idx, bx, by);
     const int l16 = lane & 15, x = l16 & 3, y = l16 >> 2, tl = (lane & 48) | (x << 2) | y;
@@ -778,6 +803,82 @@ __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int id
 
 // ---- intra 4x4 / 8x8 analysis helpers ------------------------------------------------------------
 // i_neighbour4 / i_neighbour8 (R/common/macroblock.c:733-743, 1172-1186)
+// ---- lossless (R/encoder/macroblock.c:123-130,160-167,196-213,288-303,602-626; zigzag_sub_*, R/common/dct.c:564-606) ----
+// The levels are the prediction error itself in zigzag order and the reconstruction is the source.  Lane = zigzag position.
+#define SW_ZZ4(p) ((int)((0xFBEDA7369C852140ull >> (4 * (p))) & 15))      /* position -> 4 * x + y */
+__device__ __forceinline__ void sw_ll_i4x4(SwLds &s, int idx, int &cbp_luma, int lane)
+{
+    int bx, by;
+    sw_blk_xy(idx, bx, by);
+    const int c = SW_ZZ4(lane & 15), o_e = (by + (c & 3)) * 16 + bx + (c >> 2), o_d = FDY + (by + (c & 3)) * FD + bx + (c >> 2);
+    const int v = (int)s.fe[o_e] - (int)s.fd[o_d];
+    const int nz = (__ballot(v != 0) & 0xffffull) != 0;
+    if (lane < 16) { s.lv_y[16 * idx + lane] = (i16)v; s.fd[o_d] = s.fe[o_e]; }
+    if (lane == 0) s.nnz[idx] = (u8)nz;
+    cbp_luma |= nz << (idx >> 2);
+    WAVE_SYNC();
+}
+__device__ __forceinline__ void sw_ll_i8x8(SwLds &s, int idx, int &cbp_luma, int lane)
+{
+    const int c = c_scan8[0][lane], bx = 8 * (idx & 1), by = 8 * (idx >> 1);
+    const int o_e = (by + (c & 7)) * 16 + bx + (c >> 3), o_d = FDY + (by + (c & 7)) * FD + bx + (c >> 3);
+    const int v = (int)s.fe[o_e] - (int)s.fd[o_d];
+    const int nz = __ballot(v != 0) != 0;
+    s.lv_y8[64 * idx + lane] = (i16)v; s.fd[o_d] = s.fe[o_e];
+    if (lane < 4) s.nnz[4 * idx + lane] = (u8)nz;
+    cbp_luma |= nz << idx;
+    WAVE_SYNC();
+}
+// the 16 luma 4x4 blocks (inter, or I_16x16 with dc_out: the first level of every block goes to the DC block); returns cbp_luma
+__device__ __forceinline__ int sw_ll_luma16(SwLds &s, bool dc_out, int lane)
+{
+    int cbp = 0, dc_any = 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int blk = 4 * pass + (lane >> 4), p = lane & 15, c = SW_ZZ4(p);
+        int bx, by;
+        sw_blk_xy(blk, bx, by);
+        const int o_e = (by + (c & 3)) * 16 + bx + (c >> 2), o_d = FDY + (by + (c & 3)) * FD + bx + (c >> 2);
+        int v = (int)s.fe[o_e] - (int)s.fd[o_d];
+        s.fd[o_d] = s.fe[o_e];
+        if (dc_out) {
+            dc_any |= __ballot(p == 0 && v != 0) != 0;
+            if (p == 0) { s.dc16[(bx >> 2) * 4 + (by >> 2)] = (i16)v; v = 0; }
+        }
+        s.lv_y[16 * blk + p] = (i16)v;
+        const unsigned long long m = __ballot(v != 0);
+        if (lane < 4) s.nnz[4 * pass + lane] = (u8)(((m >> (16 * lane)) & 0xffffull) != 0);
+        if (m) cbp |= dc_out ? 0xf : 1 << pass;
+    }
+    if (dc_out) {
+        WAVE_SYNC();
+        if (lane < 16) s.lv_dc[lane] = s.dc16[SW_ZZ4(lane)];
+        if (lane == 0) s.nnz[24] = (u8)dc_any;
+    }
+    WAVE_SYNC();
+    return cbp;
+}
+// both chroma planes; returns cbp_chroma
+__device__ __forceinline__ int sw_ll_chroma(SwLds &s, int lane)
+{
+    int ac = 0, dc = 0;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        const int blk = lane >> 4, p = lane & 15, c = SW_ZZ4(p), bx = (blk & 1) * 4, by = (blk >> 1) * 4;
+        const int o_e = 256 + 64 * ch + (by + (c & 3)) * 8 + bx + (c >> 2), o_d = (ch ? FDV : FDU) + (by + (c & 3)) * FD + bx + (c >> 2);
+        int v = (int)s.fe[o_e] - (int)s.fd[o_d];
+        s.fd[o_d] = s.fe[o_e];
+        const unsigned long long md = __ballot(p == 0 && v != 0);
+        if (p == 0) { s.lv_cdc[4 * ch + blk] = (i16)v; v = 0; }
+        s.lv_cac[(4 * ch + blk) * 16 + p] = (i16)v;
+        const unsigned long long m = __ballot(v != 0);
+        if (lane < 4) s.nnz[16 + 4 * ch + lane] = (u8)(((m >> (16 * lane)) & 0xffffull) != 0);
+        if (lane == 0) s.nnz[25 + ch] = (u8)(md != 0);
+        ac |= m != 0; dc |= md != 0;
+    }
+    WAVE_SYNC();
+    return ac ? 2 : dc ? 1 : 0;
+}
 __device__ __forceinline__ int sw_nb4(int idx, int nb)
 {
     const int all = NB_LEFT | NB_TOP | NB_TOPLEFT | NB_TOPRIGHT;
@@ -965,9 +1066,11 @@ __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_l
 // WPE = waves per SIMD the register allocation is held to.  A row wave spends most of its time waiting
 // on dependent LDS / L2 round trips, so throughput comes from other chains' waves filling those gaps:
 // fewer registers per wave (some spilled) and more waves resident beats one fat wave per SIMD.
-template <int WPE>
+// LL: lossless, as a compile-time constant (its branches cost the usual path nothing)
+template <int WPE, bool LL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs)
 {
+    a.lossless = LL;
     __shared__ SwLds s;
     const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
@@ -981,8 +1084,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz; a.cost_alt += nmb * bz;
     if (a.l0_type) { a.l0_type += nmb * bz; a.l0_ref += 4 * nmb * bz; a.l0_mv += 32 * nmb * bz; }
     int *prog = a.progress + (size_t)bz * a.mb_h;
-    const int satd = a.subme > 1, is_p = a.slice_type == 0;
-    const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me};
+    const int satd = a.subme > 1 && !a.lossless, is_p = a.slice_type == 0;
+    const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me, a.lossless};
     {   // tables that every macroblock of the row reads: into LDS once
         const int cat = lane >> 4, i = lane & 15, q = cat < 2 ? a.qp : a.qpc;
         s.qmf[cat][i] = a.q4mf[(cat * 52 + q) * 16 + i]; s.qbias[cat][i] = a.q4bias[(cat * 52 + q) * 16 + i];
@@ -1097,7 +1200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (satd_chroma < MX_COST_MAX) return;
             int m[4], n = sw_modes8c(nb, m);
             for (int i = 0; i < n; i++) {
-                sw_pred8c(s, m[i], lane);
+                sw_pred8c(s, m[i], lane, a.lossless);
                 int c = sw_cmp_chroma(s, satd, lane) + a.lambda * sw_ue_size(sw_fix8c(m[i]));
                 if (c < satd_chroma) { satd_chroma = c; predc = m[i]; }
             }
@@ -1132,7 +1235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             {
                 int m[4], n = sw_modes16(nb, m);
                 for (int i = 0; i < n; i++) {
-                    sw_pred16(s, m[i], lane);
+                    sw_pred16(s, m[i], lane, a.lossless);
                     int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m[i]));
                     if (c < satd_i16) { satd_i16 = c; pred16 = m[i]; }
                 }
@@ -1172,6 +1275,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 d[x] = (int)((f0 >> (8 * x)) & 255) - (int)s.pt8[(o0 >> (8 * x)) & 255];
                                 d[4 + x] = (int)((f1 >> (8 * x)) & 255) - (int)s.pt8[(o1 >> (8 * x)) & 255];
                             }
+                            if (a.lossless && mode < 2) {
+#pragma unroll
+                                for (int x = 0; x < 8; x++) d[x] = (int)s.fe[(by + r) * 16 + bx + x] - sw_ll_px(s, 0, mode, bx + x, by + r);
+                            }
                             int c;
                             if (satd) c = (sw_sa8d_rows_d(d, lane) + 2) >> 2;
                             else {
@@ -1191,7 +1298,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (lane == 0) s.pred8[idx] = (signed char)bmode;
                     if (idx == 3 || cost > thresh) break;
                     {
-                        const int v = s.pt8[(s.p8lut[(bmode * 8 + (lane >> 3)) * 2 + ((lane >> 2) & 1)] >> (8 * (lane & 3))) & 255];
+                        int v = s.pt8[(s.p8lut[(bmode * 8 + (lane >> 3)) * 2 + ((lane >> 2) & 1)] >> (8 * (lane & 3))) & 255];
+                        if (a.lossless && bmode < 2) v = sw_ll_px(s, 0, bmode, bx + (lane & 7), by + (lane >> 3));
                         WAVE_SYNC();
                         s.fd[FDY + (by + (lane >> 3)) * FD + bx + (lane & 7)] = (u8)v;
                         if (lane < 4) s.i4c[sw_scan8(4 * idx) + (lane & 1) + 8 * (lane >> 1)] = (signed char)bmode;
@@ -1229,8 +1337,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         if (g < n) {
                             const int mode = (int)((list >> (4 * g)) & 15);
                             const u32 off = s.p4lut[mode * 4 + r], fw = *(const u32 *)(s.fe + (by + r) * 16 + bx);
-                            const int d0 = (int)(fw & 255) - (int)s.pt4[off & 255], d1 = (int)((fw >> 8) & 255) - (int)s.pt4[(off >> 8) & 255];
-                            const int d2 = (int)((fw >> 16) & 255) - (int)s.pt4[(off >> 16) & 255], d3 = (int)(fw >> 24) - (int)s.pt4[off >> 24];
+                            int d0 = (int)(fw & 255) - (int)s.pt4[off & 255], d1 = (int)((fw >> 8) & 255) - (int)s.pt4[(off >> 8) & 255];
+                            int d2 = (int)((fw >> 16) & 255) - (int)s.pt4[(off >> 16) & 255], d3 = (int)(fw >> 24) - (int)s.pt4[off >> 24];
+                            if (a.lossless && mode < 2) {
+                                d0 = (int)(fw & 255) - sw_ll_px(s, 0, mode, bx, by + r); d1 = (int)((fw >> 8) & 255) - sw_ll_px(s, 0, mode, bx + 1, by + r);
+                                d2 = (int)((fw >> 16) & 255) - sw_ll_px(s, 0, mode, bx + 2, by + r); d3 = (int)(fw >> 24) - sw_ll_px(s, 0, mode, bx + 3, by + r);
+                            }
                             const int c = sw_cost4x4_rows(d0, d1, d2, d3, satd, lane);
                             key = ((u32)(c + a.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
                         }
@@ -1242,7 +1354,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     cost += best;
                     if (lane == 0) s.pred4[idx] = (signed char)bmode;
                     if (cost > thresh || idx == 15) break;
-                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = s.pt4[(s.p4lut[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
+                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = a.lossless && bmode < 2 ? (u8)sw_ll_px(s, 0, bmode, bx + (lane & 3), by + (lane >> 2))
+                                                                         : s.pt4[(s.p4lut[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
                     if (lane == 0) s.i4c[sw_scan8(idx)] = (signed char)bmode;
                     WAVE_SYNC();
                     sw_encode_i4x4(s, a, idx, acbp, lane);
@@ -1644,9 +1757,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         } else {
             if (type == T_I_16x16) {
                 analyse_chroma();
-                sw_pred16(s, pred16, lane);
+                sw_pred16(s, pred16, lane, a.lossless);
                 cbp_luma = sw_encode_i16x16(s, a, lane);
-                sw_pred8c(s, predc, lane);
+                sw_pred8c(s, predc, lane, a.lossless);
                 cbp_chroma = sw_encode_chroma(s, a, 0, lane);
             } else if (type == T_I_8x8 || type == T_I_4x4) {
                 // x264_analyse_update_cache: the winner's modes into the cache; then macroblock.c:527-590 with i_skip_intra:
@@ -1666,7 +1779,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                    : mode == 3 || mode == 7 ? NB_TOP | NB_TOPRIGHT : mode == 11 ? 0 : NB_LEFT | NB_TOPLEFT | NB_TOP;
                     if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + 8 * FD + 8, FD, nb8, need);
                     WAVE_SYNC();
-                    const int v = pred8_px(mode, s.edge8, lane & 7, lane >> 3);
+                    const int v = a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, 8 + (lane & 7), 8 + (lane >> 3)) : pred8_px(mode, s.edge8, lane & 7, lane >> 3);
                     WAVE_SYNC();
                     s.fd[FDY + (8 + (lane >> 3)) * FD + 8 + (lane & 7)] = (u8)v;
                     WAVE_SYNC();
@@ -1678,17 +1791,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     WAVE_SYNC();
                     if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
                     WAVE_SYNC();
-                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)pred4_px(mode, s.e4, lane & 3, lane >> 2);
+                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)(a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, 12 + (lane & 3), 12 + (lane >> 2))
+                                                                                                   : pred4_px(mode, s.e4, lane & 3, lane >> 2));
                     WAVE_SYNC();
                     sw_encode_i4x4(s, a, 15, cbp_luma, lane);
                 }
-                sw_pred8c(s, predc, lane);
+                sw_pred8c(s, predc, lane, a.lossless);
                 cbp_chroma = sw_encode_chroma(s, a, 0, lane);
             } else {
                 sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
                 WAVE_SYNC();
                 // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
-                if (a.transform8x8 && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
+                if (a.transform8x8 && !a.lossless && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
                     // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
                     int raw = 0;
                     if (lane < 32) {
@@ -1944,6 +2058,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
     a.prof = (long long *)p->profile;
     a.nr = p->noise_reduction != 0;
+    a.lossless = p->lossless != 0;
+    if (a.lossless && (p->qp != 0 || a.nr || p->fast_pskip)) { set_error("slice_sweep: lossless needs qp 0, no fast_pskip, no noise reduction (x264_validate_parameters)"); return -1; }
     if (a.nr && (!p->nr || !p->nr->sum || !p->nr->count || !p->nr->offset)) { set_error("slice_sweep: noise_reduction without an x264hip_nr_state"); return -1; }
     a.nr_sum = a.nr ? p->nr->sum : nullptr; a.nr_count = a.nr ? p->nr->count : nullptr; a.nr_offset = a.nr ? p->nr->offset : nullptr;
     SwRefs t;
@@ -1960,7 +2076,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         if (wpe < 1 || wpe > 3) wpe = 3;
     }
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
-    switch (wpe) {
+    switch (a.lossless ? 0 : wpe) {
+    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t); break;
     case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
     case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
     default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;

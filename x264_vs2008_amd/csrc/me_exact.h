@@ -535,7 +535,7 @@ __device__ __forceinline__ MeLimits me_limits(int mbx, int mby, int mb_w, int mb
     L.fmin0 = (L.smin0 >> 2) + 5; L.fmax0 = (L.smax0 >> 2) - 5; L.fmin1 = (L.smin1 >> 2) + 5; L.fmax1 = (L.smax1 >> 2) - 5;
     return L;
 }
-struct MeOpts { int method, me_range, subme, chroma_me; };
+struct MeOpts { int method, me_range, subme, chroma_me, sad_only; };   // sad_only: lossless (mbcmp = SAD at every subme, R/encoder/encoder.c:594-604)
 
 // Everything the search takes from its caller is the same in all lanes except MxCtx::lane; say so (v_readfirstlane), so
 // that the walk's comparisons and branches are scalar.
@@ -565,7 +565,7 @@ __device__ __forceinline__ MeLimits mx_uniform(const MeLimits &i)
 __device__ __forceinline__ MeOpts mx_uniform(const MeOpts &i)
 {
     MeOpts o;
-    o.method = MX_UNI(i.method); o.me_range = MX_UNI(i.me_range); o.subme = MX_UNI(i.subme); o.chroma_me = MX_UNI(i.chroma_me);
+    o.method = MX_UNI(i.method); o.me_range = MX_UNI(i.me_range); o.subme = MX_UNI(i.subme); o.chroma_me = MX_UNI(i.chroma_me); o.sad_only = MX_UNI(i.sad_only);
     return o;
 }
 
@@ -620,7 +620,7 @@ __device__ __forceinline__ int me_search_ref16(const MxCtx &c_in, const MeLimits
     const MeOpts o = mx_uniform(o_in);
     n_mvc = MX_UNI(n_mvc);
     const int lane = c.lane, g16 = lane >> 4, g8 = lane >> 3;
-    const int satd = o.subme > 1, mvpx = c.mvpx, mvpy = c.mvpy;
+    const int satd = o.subme > 1 && !o.sad_only, mvpx = c.mvpx, mvpy = c.mvpy;
     int bmx = clip3(mvpx, L.fmin0 * 4, L.fmax0 * 4), bmy = clip3(mvpy, L.fmin1 * 4, L.fmax1 * 4);
     const int pmx = (bmx + 2) >> 2, pmy = (bmy + 2) >> 2;
     int bcost = MX_COST_MAX, bpx = 0, bpy = 0, bpcost = MX_COST_MAX;
@@ -856,7 +856,7 @@ __device__ __forceinline__ int me_refine_qpel16(const MxCtx &c_in, const MeLimit
     const MeLimits L = mx_uniform(L_in);
     const MeOpts o = mx_uniform(o_in);
     const int lane = c.lane, g16 = lane >> 4;
-    const int hpel = c_subpel_iters[o.subme][0], qpel = c_subpel_iters[o.subme][1], satd = o.subme > 1;
+    const int hpel = c_subpel_iters[o.subme][0], qpel = c_subpel_iters[o.subme][1], satd = o.subme > 1 && !o.sad_only;
     int bx = MX_UNI(mvx), by = MX_UNI(mvy), bc = MX_UNI(cost_in);
     if (c.has_patch) mx_load_patch(c, bx, by);
     if (hpel && o.subme < 3) {

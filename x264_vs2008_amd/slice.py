@@ -38,7 +38,7 @@ class SliceParams(C.Structure):
                 ("quant4_mf", C.c_void_p), ("quant4_bias", C.c_void_p), ("quant8_mf", C.c_void_p), ("quant8_bias", C.c_void_p),
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
                 ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
-                ("mixed_refs", C.c_int), ("profile", C.c_void_p), ("noise_reduction", C.c_int), ("nr", C.c_void_p)]
+                ("mixed_refs", C.c_int), ("profile", C.c_void_p), ("noise_reduction", C.c_int), ("nr", C.c_void_p), ("lossless", C.c_int)]
 
 
 class NrState(C.Structure):
@@ -79,6 +79,12 @@ class ChainEncoder:
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
                  chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0, mv_range=0):
         self.lib = lib
+        self.lossless = int(qp == 0)
+        if self.lossless:              # x264_validate_parameters, R/encoder/encoder.c:401-421
+            fast_pskip, noise_reduction, chroma_qp_offset = 0, 0, 0
+            transform8x8 = int(bool(transform8x8 and cabac))
+            if not transform8x8:
+                inter, intra = inter & ~2, intra & ~2
         self.ctx = FrameCtx(lib, width, height, batch=batch)
         self.opt = dict(qp=qp, me_method=me_method, me_range=me_range, subme=subme, n_refs=n_refs, inter=inter, intra=intra,
                         transform8x8=transform8x8, fast_pskip=fast_pskip, dct_decimate=dct_decimate, chroma_me=chroma_me, cabac=cabac,
@@ -133,7 +139,7 @@ class ChainEncoder:
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
                         cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
                         profile=self.profile.ptr if self.profile else None,
-                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None)
+                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]
         arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None

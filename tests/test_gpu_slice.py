@@ -223,3 +223,28 @@ def test_sweep_batched_chains_with_different_content(hip_lib, oracle_lib, cqm):
                 assert np.array_equal(got.reshape(ref.shape), ref), "chain %d frame %d: %s" % (b, f, k)
             for nm in ("y", "u", "v"):
                 assert np.array_equal(out[f]["fin_" + nm][b], want["fin_" + nm][f]), "chain %d frame %d: %s" % (b, f, nm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,tweak,needle", [
+    (dict(subme=6), None, "subme"),                                        # RD: not built
+    (dict(subme=5, me_method=4), None, "me method"),                       # TESA: not built
+    (dict(subme=0, me_method=3), None, "subme"),                           # ESA at subme 0: undefined in the reference
+    (dict(subme=2), "lossless_qp", "lossless"),                            # lossless without x264_validate_parameters' consequences
+    (dict(subme=2), "nr_no_state", "noise_reduction"),                     # --nr without the per-chain sums
+], ids=["rd", "tesa", "esa_subme0", "lossless_qp26", "nr_without_state"])
+def test_sweep_refuses_what_it_does_not_build(hip_lib, cqm, kw, tweak, needle):
+    """No fallback: an option the sweep does not implement is an error string, not an approximation."""
+    y, u, v = case_inputs((96, 80), 1, "moving")
+    enc = sl.ChainEncoder(hip_lib, 96, 80, cqm, qp=26, **kw)
+    try:
+        if tweak == "lossless_qp":
+            enc.lossless = 1
+        if tweak == "nr_no_state":
+            enc.opt["noise_reduction"] = 100
+        enc.upload(y[0], u[0], v[0])
+        with pytest.raises(RuntimeError) as e:
+            enc.encode_frame()
+        assert needle in str(e.value), str(e.value)
+    finally:
+        enc.close()

@@ -47,13 +47,15 @@ enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
 struct SwRefs {
     const u8 *y[SW_MAX_REFS][4];
     const u8 *u[SW_MAX_REFS], *v[SW_MAX_REFS];
+    // everything indexed by a run-time reference number lives here, in the argument the kernel never writes: SwArgs is adjusted per
+    // chain at the top of the kernel, and a modified argument struct with a dynamically indexed member is kept in scratch memory whole
+    int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS], l0_inv_ref_poc[SW_MAX_REFS];
 };
 struct SwArgs {
     int mb_w, mb_h, sy, sc, batch, batch_pad;
     size_t bs_y, bs_c;
     int slice_type, qp, qpc, lambda, chroma_skip_thresh, n_refs;
-    int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS];
-    int l0_n_ref0, l0_inv_ref_poc[SW_MAX_REFS];
+    int l0_n_ref0;
     int me_method, me_range, subme, chroma_me, fast_pskip, dct_decimate, cabac, mv_range;
     int flags_inter, mixed_refs; // X264_ANALYSE_PSUB16x16 (0x10) / PSUB8x8 (0x20) of param.analyse.inter; param.analyse.b_mixed_references
     int flags_intra;            // X264_ANALYSE_I4x4 | I8x8 bits that apply to this slice type (param.analyse.intra / .inter)
@@ -298,19 +300,20 @@ __device__ __forceinline__ void sw_pred8c(SwLds &s, int mode, int lane, int ll =
     WAVE_SYNC();
 }
 // predict_16x16_mode_available / predict_8x8chroma_mode_available, R/encoder/analyse.c:374-433
-__device__ __forceinline__ int sw_modes16(int nb, int *m)
+// the list is a packed word, one nibble per mode in the reference's order (an array indexed in a loop would live in scratch memory)
+__device__ __forceinline__ u32 sw_modes16(int nb, int &n)
 {
-    if (nb & NB_TOPLEFT) { m[0] = 0; m[1] = 1; m[2] = 2; m[3] = 3; return 4; }
-    if (nb & NB_LEFT) { m[0] = 4; m[1] = 1; return 2; }
-    if (nb & NB_TOP) { m[0] = 5; m[1] = 0; return 2; }
-    m[0] = 6; return 1;
+    if (nb & NB_TOPLEFT) { n = 4; return 0x3210; }
+    if (nb & NB_LEFT) { n = 2; return 0x14; }
+    if (nb & NB_TOP) { n = 2; return 0x05; }
+    n = 1; return 6;
 }
-__device__ __forceinline__ int sw_modes8c(int nb, int *m)
+__device__ __forceinline__ u32 sw_modes8c(int nb, int &n)
 {
-    if (nb & NB_TOPLEFT) { m[0] = 2; m[1] = 1; m[2] = 0; m[3] = 3; return 4; }
-    if (nb & NB_LEFT) { m[0] = 4; m[1] = 1; return 2; }
-    if (nb & NB_TOP) { m[0] = 5; m[1] = 2; return 2; }
-    m[0] = 6; return 1;
+    if (nb & NB_TOPLEFT) { n = 4; return 0x3012; }
+    if (nb & NB_LEFT) { n = 2; return 0x14; }
+    if (nb & NB_TOP) { n = 2; return 0x25; }
+    n = 1; return 6;
 }
 __device__ __forceinline__ int sw_fix16(int m) { return m < 4 ? m : 2; }      // x264_mb_pred_mode16x16_fix
 __device__ __forceinline__ int sw_fix8c(int m) { return m < 4 ? m : 0; }      // x264_mb_pred_mode8x8c_fix
@@ -327,7 +330,7 @@ __device__ __forceinline__ int sw_denoise(int v, int off, int &la)
     level -= off;
     return level < 0 ? 0 : (level ^ sign) - sign;
 }
-__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr)
+__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
 {
     if (lane < 16) {
         int bx, by, r[16];
@@ -339,7 +342,7 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int ca
                 r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
         i16 c[16], lv[16];
         fwd4x4(c, r);
-        if (nr_acc4) {
+        if (nr_acc4 && nr_on) {
             // --nr: every coefficient but the first of every block, and the sum of magnitudes per coefficient index over the 16
             // blocks (lane i keeps index i's running sum for the whole row; added to the chain's totals at the end of the row)
 #pragma unroll
@@ -386,10 +389,10 @@ __device__ __forceinline__ void sw_ll_i8x8(SwLds &s, int idx, int &cbp_luma, int
 __device__ __forceinline__ int sw_ll_luma16(SwLds &s, bool dc_out, int lane);
 __device__ __forceinline__ int sw_ll_chroma(SwLds &s, int lane);
 // x264_macroblock_encode's inter 4x4-transform branch; returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane, int *nr_acc4 = nullptr)
+__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
 {
     if (a.lossless) return sw_ll_luma16(s, false, lane);
-    sw_luma4x4_fwd(s, a, 1, false, lane, nr_acc4);
+    sw_luma4x4_fwd(s, a, 1, false, lane, nr_acc4, nr_on);
     if (lane == 0) {
         int cbp = 0, dec_mb = 0;
         for (int i8 = 0; i8 < 4; i8++) {
@@ -623,7 +626,7 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
 // for the two 1-D passes (32 lanes), then 64 lanes x one coefficient per block.  Leaves the quantised
 // coefficients (transposed storage) in s.coef[4*b..][..] = [4][64], levels in s.lv_y8, per block
 // s.score[b] = decimate_score64 | nz << 8.  cat: 0 intra, 1 inter.
-__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane, int *nr_acc8 = nullptr)
+__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
 {
     i16 *tmp = s.t8, *coef = &s.coef[0][0];
     const int b = lane >> 3, k8 = lane & 7;
@@ -652,7 +655,7 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int 
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((mask >> j) & 1) {
-            if (nr_acc8 && lane) {      // --nr: lane = coefficient index, the first one is left alone
+            if (nr_acc8 && nr_on && lane) {      // --nr: lane = coefficient index, the first one is left alone
                 int la;
                 coef[64 * j + lane] = (i16)sw_denoise(coef[64 * j + lane], s.nr_off8[lane], la);
                 *nr_acc8 += la;
@@ -723,9 +726,9 @@ __device__ __forceinline__ void sw_luma8x8_add(SwLds &s, int cat, int qp, int ke
     WAVE_SYNC();
 }
 // inter, 8x8 transform (R/encoder/macroblock.c:627-669); returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane, int *nr_acc8 = nullptr)
+__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
 {
-    sw_luma8x8_fwd(s, 1, 0xf, lane, nr_acc8);
+    sw_luma8x8_fwd(s, 1, 0xf, lane, nr_acc8, nr_on);
     int cbp = 0, dec_mb = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1070,7 +1073,8 @@ __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_l
 template <int WPE, bool LL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs)
 {
-    a.lossless = LL;
+    __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
+                                                        // kernel argument is copied to scratch memory whole)
     __shared__ SwLds s;
     const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
@@ -1198,11 +1202,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610
         auto analyse_chroma = [&]() {
             if (satd_chroma < MX_COST_MAX) return;
-            int m[4], n = sw_modes8c(nb, m);
+            int n;
+            const u32 list = sw_modes8c(nb, n);
             for (int i = 0; i < n; i++) {
-                sw_pred8c(s, m[i], lane, a.lossless);
-                int c = sw_cmp_chroma(s, satd, lane) + a.lambda * sw_ue_size(sw_fix8c(m[i]));
-                if (c < satd_chroma) { satd_chroma = c; predc = m[i]; }
+                const int m = (int)((list >> (4 * i)) & 15);
+                sw_pred8c(s, m, lane, a.lossless);
+                int c = sw_cmp_chroma(s, satd, lane) + a.lambda * sw_ue_size(sw_fix8c(m));
+                if (c < satd_chroma) { satd_chroma = c; predc = m; }
             }
         };
         // a->b_fast_intra (R/encoder/analyse.c:345-362), evaluated only when its value matters.  Its last term counts
@@ -1233,11 +1239,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         auto analyse_intra = [&](int satd_inter) {
             LAUNDER();
             {
-                int m[4], n = sw_modes16(nb, m);
+                int n;
+                const u32 list = sw_modes16(nb, n);
                 for (int i = 0; i < n; i++) {
-                    sw_pred16(s, m[i], lane, a.lossless);
-                    int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m[i]));
-                    if (c < satd_i16) { satd_i16 = c; pred16 = m[i]; }
+                    const int m = (int)((list >> (4 * i)) & 15);
+                    sw_pred16(s, m, lane, a.lossless);
+                    int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m));
+                    if (c < satd_i16) { satd_i16 = c; pred16 = m; }
                 }
             }
             if (!(a.flags_intra & 3)) return;
@@ -1459,7 +1467,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 if ((dx && mbx >= a.mb_w - 1) || (dy && mby >= a.mb_h - 1)) continue;
                                 const int o = mb + dx + dy * a.mb_w, ref_col = a.l0_ref[o * 4];
                                 if (ref_col >= 0) {
-                                    const int scale = a.poc_delta[r] * a.l0_inv_ref_poc[ref_col];
+                                    const int scale = refs.poc_delta[r] * refs.l0_inv_ref_poc[ref_col];
                                     SETC((a.l0_mv[o * 32] * scale + 128) >> 8, (a.l0_mv[o * 32 + 1] * scale + 128) >> 8);
                                 }
                             }
@@ -1470,15 +1478,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     for (int k = 0; k < 4; k++) c.pl[k] = (MX_GLB(u8))(refs.y[r][k] + by_ + oy);
                     c.cu = (MX_GLB(u8))(refs.u[r] + bc_ + oc); c.cv = (MX_GLB(u8))(refs.v[r] + bc_ + oc);
                     c.mvpx = mvpx; c.mvpy = mvpy;
-                    thresh -= a.ref_cost[r];
+                    thresh -= refs.ref_cost[r];
                     int smx, smy, cost_mv;
                     LAUNDER(); c.lane = lane;
-                    int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], n_mvc, a.n_refs > 1 ? &thresh : nullptr, smx, smy, cost_mv);
+                    int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], n_mvc, &thresh, smx, smy, cost_mv);   // with one reference the threshold never bites (it starts at COST_MAX); a conditional
+                                                                                        // pointer would pin it in scratch memory
                     if (r == 0 && try_pskip && cost - cost_mv < 300 * a.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
                         if (sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
                     }
-                    cost += a.ref_cost[r];
-                    thresh += a.ref_cost[r];
+                    cost += refs.ref_cost[r];
+                    thresh += refs.ref_cost[r];
                     if (cost < best) { best = cost; mvx = smx; mvy = smy; ref = r; bmvpx = mvpx; bmvpy = mvpy; }
                     if (lane == 0) {
                         a.mvr[((size_t)r * nmb + mb) * 2] = (i16)smx; a.mvr[((size_t)r * nmb + mb) * 2 + 1] = (i16)smy;
@@ -1554,18 +1563,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
                                     c.mvpx = px; c.mvpy = py;
                                     LAUNDER(); c.lane = lane;
-                                    int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + a.ref_cost[r];
+                                    int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + refs.ref_cost[r];
                                     if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
                                     WAVE_SYNC();
                                     if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
                                 }
                                 cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, br, bvx, bvy, 1);
-                                pme_put(i, bvx, bvy, bcost + a.lambda, bcm, br, a.ref_cost[br], bpx, bpy);      // + lambda * i_sub_mb_p_cost_table[D_L0_8x8]
+                                pme_put(i, bvx, bvy, bcost + a.lambda, bcm, br, refs.ref_cost[br], bpx, bpy);      // + lambda * i_sub_mb_p_cost_table[D_L0_8x8]
                             }
                             cost8x8 = pme(0, 2) + pme(1, 2) + pme(2, 2) + pme(3, 2);
-                            if (!a.cabac && !(pme(0, 4) | pme(1, 4) | pme(2, 4) | pme(3, 4))) cost8x8 -= a.ref_cost[0] * 4;
+                            if (!a.cabac && !(pme(0, 4) | pme(1, 4) | pme(2, 4) | pme(3, 4))) cost8x8 -= refs.ref_cost[0] * 4;
                         } else {                                     // x264_mb_analyse_inter_p8x8, :1221-1272
-                            const int r = ref, ref_cost = a.cabac || r ? a.ref_cost[r] : 0;
+                            const int r = ref, ref_cost = a.cabac || r ? refs.ref_cost[r] : 0;
                             if (lane == 0) { s.l0mvc[r][0][0] = (i16)mvx; s.l0mvc[r][0][1] = (i16)mvy; }
                             WAVE_SYNC();
                             for (int i = 0; i < 4; i++) {
@@ -1611,7 +1620,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                         cache_set(x4, y4, sw, sh, r, vx, vy, 1);
                                         sum += cost;
                                     }
-                                    int cst = sum + a.ref_cost[r] + a.lambda * (t == 0 ? 5 : 3);          // i_sub_mb_p_cost_table
+                                    int cst = sum + refs.ref_cost[r] + a.lambda * (t == 0 ? 5 : 3);          // i_sub_mb_p_cost_table
                                     if (a.chroma_me && a.subme >= 5) cst += sw_sub_chroma(s, refs, a, r, i, t, rec0, sub_mx, sub_my, satd, oc, bc_, lane);
                                     if (t == 0) {
                                         if (!(cst < pme(i, 2))) break;
@@ -1651,11 +1660,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                         aim(r, dir ? 8 : 16, dir ? 16 : 8, dir ? 8 * i : 0, dir ? 0 : 8 * i);
                                         c.mvpx = px; c.mvpy = py;
                                         LAUNDER(); c.lane = lane;
-                                        const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + a.ref_cost[r];
+                                        const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + refs.ref_cost[r];
                                         if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
                                     }
                                     if (dir) cache_set(2 * i, 0, 2, 4, br, bvx, bvy, 1); else cache_set(0, 2 * i, 4, 2, br, bvx, bvy, 1);
-                                    pme_put(4 + 2 * dir + i, bvx, bvy, bcost, bcm, br, a.ref_cost[br], bpx, bpy);
+                                    pme_put(4 + 2 * dir + i, bvx, bvy, bcost, bcm, br, refs.ref_cost[br], bpx, bpy);
                                     sum += bcost;
                                 }
                                 if (sum < i_cost) { i_cost = sum; type = T_P_L0; part = dir ? 15 : 14; }
@@ -1665,7 +1674,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (part == 16) {
                         aim(ref, 16, 16, 0, 0);
                         c.mvpx = bmvpx; c.mvpy = bmvpy;
-                        best -= a.ref_cost[ref];
+                        best -= refs.ref_cost[ref];
                         LAUNDER(); c.lane = lane;
                         best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
                         i_cost = best;
@@ -1815,7 +1824,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     t8 = c8 < c4;
                 }
                 if (a.nr) { if (t8) nr_n8 += 4; else nr_n4 += 16; }
-                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane, a.nr ? &nr_acc8 : nullptr) : sw_encode_inter_luma(s, a, lane, a.nr ? &nr_acc4 : nullptr);
+                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane, &nr_acc8, a.nr) : sw_encode_inter_luma(s, a, lane, &nr_acc4, a.nr);   // never a conditional pointer: that pins the counter in scratch memory
                 cbp_chroma = sw_encode_chroma(s, a, 1, lane);
                 if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
             }
@@ -2017,6 +2026,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
     SwArgs a;
+    SwRefs t;
     memset(&a, 0, sizeof(a));
     a.mb_w = c->d.mb_w; a.mb_h = c->d.mb_h; a.sy = c->d.stride_y; a.sc = c->d.stride_c; a.batch = c->batch; a.batch_pad = (c->batch + 7) & ~7;
     a.bs_y = c->bs_y; a.bs_c = c->bs_c;
@@ -2030,9 +2040,9 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         int x = (n_refs <= 0 ? 1 : n_refs) - 1; x = x > 2 ? 2 : x;
         // REF_COST: lambda * bs_size_te(x, i), R/encoder/analyse.c:195-197
         int bits = x == 1 ? 1 : x > 1 ? (i == 0 ? 1 : i < 3 ? 3 : i < 7 ? 5 : 7) : 0;
-        a.ref_cost[i] = a.lambda * bits;
-        a.poc_delta[i] = i < n_refs ? p->poc - p->ref_poc[i] : 0;
-        a.l0_inv_ref_poc[i] = l0 ? l0->inv_ref_poc[i] : 0;
+        t.ref_cost[i] = a.lambda * bits;
+        t.poc_delta[i] = i < n_refs ? p->poc - p->ref_poc[i] : 0;
+        t.l0_inv_ref_poc[i] = l0 ? l0->inv_ref_poc[i] : 0;
     }
     a.l0_n_ref0 = l0 ? l0->n_ref0 : 0;
     a.me_method = p->me_method; a.me_range = p->me_range; a.subme = p->subme;
@@ -2062,7 +2072,6 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (a.lossless && (p->qp != 0 || a.nr || p->fast_pskip)) { set_error("slice_sweep: lossless needs qp 0, no fast_pskip, no noise reduction (x264_validate_parameters)"); return -1; }
     if (a.nr && (!p->nr || !p->nr->sum || !p->nr->count || !p->nr->offset)) { set_error("slice_sweep: noise_reduction without an x264hip_nr_state"); return -1; }
     a.nr_sum = a.nr ? p->nr->sum : nullptr; a.nr_count = a.nr ? p->nr->count : nullptr; a.nr_offset = a.nr ? p->nr->offset : nullptr;
-    SwRefs t;
     for (int i = 0; i < SW_MAX_REFS; i++) {
         const x264hip_picture *r = (is_p && n_refs > 0) ? refs[i < n_refs ? i : 0] : fenc;
         for (int k = 0; k < 4; k++) t.y[i][k] = r->filtered[k];

@@ -73,6 +73,9 @@ struct MxCtx {
     MX_LDS(u32) fe;           // LDS: 16 rows x 4 dwords
     MX_LDS(u8) fe_u; MX_LDS(u8) fe_v;    // LDS: 8x8 each
     MX_GLB(u8) pl[4];         // four half-pel planes at the macroblock origin
+    // a lane-dependent plane: selects, NOT pl[k] -- a dynamically indexed member forces the whole context into scratch memory
+    // (every field access a scratch load, every search a 200-byte-per-lane scratch copy)
+    __device__ __forceinline__ MX_GLB(u8) plane(int k) const { return k == 0 ? pl[0] : k == 1 ? pl[1] : k == 2 ? pl[2] : pl[3]; }
     MX_GLB(u8) cu; MX_GLB(u8) cv;        // chroma planes at the macroblock origin
     MX_GLB(i16) cost_g;       // p_cost_mv, centred (global memory)
     MX_LDS(i16) cost_l;       // LDS copy of cost_g[-MX_COST_LDS .. MX_COST_LDS] (only read when has_cost_l)
@@ -142,7 +145,7 @@ __device__ __forceinline__ void mx_load_patch(MxCtx &c, int qx, int qy)
         const int i = c.lane + 64 * pass;
         if (i < nl) {
             const int k = i / prow, r = i - k * prow;
-            MX_GLB(u8) src = c.pl[k] + (ptrdiff_t)(c.py0 + r) * c.sy + c.px0;
+            MX_GLB(u8) src = c.plane(k) + (ptrdiff_t)(c.py0 + r) * c.sy + c.px0;
             const uintptr_t a = (uintptr_t)src;
             const u32 sft = (u32)(a & 3);
             MX_GLB(u32) q = (MX_GLB(u32))(a - sft);
@@ -262,7 +265,7 @@ __device__ __forceinline__ int sad_qpel16_lane(const MxCtx &c, int mx, int my)
         return row_sum16(v);
     }
     if (row < c.bh) {
-        MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+        MX_GLB(u8) pa = c.plane(c_qpel_a[idx]) + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.plane(c_qpel_b[idx]) + base + (fx == 3);
         MX_LDS(u32) f = c.fe + c.fe_off + 4 * row;
         u32 s;
         if (c.bw == 16) {
@@ -297,7 +300,7 @@ __device__ __forceinline__ int sad_qpel8_lane(const MxCtx &c, int mx, int my)
         const int row = r + 8 * half;
         if (row < c.bh) {
             const ptrdiff_t base = (ptrdiff_t)((my >> 2) + row) * c.sy + (mx >> 2);
-            MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+            MX_GLB(u8) pa = c.plane(c_qpel_a[idx]) + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.plane(c_qpel_b[idx]) + base + (fx == 3);
             MX_LDS(u32) f = c.fe + c.fe_off + 4 * row;
             if (c.bw == 16) {
                 u32 a[4];
@@ -405,7 +408,7 @@ __device__ __forceinline__ int subpel_sum16_lane(const MxCtx &c, int mx, int my,
         const int bx = (nbx == 2 ? (j & 1) : 0) * 8, by = (nbx == 2 ? (j >> 1) : j) * 4;
         const int fx = mx & 3, fy = my & 3, idx = fy * 4 + fx;
         const ptrdiff_t base = (ptrdiff_t)((my >> 2) + by) * c.sy + (mx >> 2) + bx;
-        MX_GLB(u8) pa = c.pl[c_qpel_a[idx]] + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.pl[c_qpel_b[idx]] + base + (fx == 3);
+        MX_GLB(u8) pa = c.plane(c_qpel_a[idx]) + base + (fy == 3) * c.sy; MX_GLB(u8) pb = c.plane(c_qpel_b[idx]) + base + (fx == 3);
         u32 f[4][2], p[4][2];
         if (staged) {
             const int o = ((my >> 2) - c.py0 + by) * MX_PS + (mx >> 2) - c.px0 + bx;

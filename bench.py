@@ -210,7 +210,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
                          "note": "mean over the timed launches (P with 1..R references and the I launch at the keyint); the sweep is bound by dependent memory round trips along the macroblock "
-                                 "dependency chain (mb_w + 2*mb_h = %d serial macroblock steps per frame; PMC: waves wait ~75%% of their "
+                                 "dependency chain (mb_w + 2*mb_h = %d serial macroblock steps per frame; PMC: waves wait ~69%% of their "
                                  "cycles), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:

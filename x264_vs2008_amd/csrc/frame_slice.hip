@@ -1079,13 +1079,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
     if (bz >= a.batch) return;
-    const size_t nmb = (size_t)a.mb_w * a.mb_h, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
+    const size_t nmb = (size_t)a.mb_w * a.mb_h, cb = nmb * bz, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
     // batch element
     a.fy += by_; a.fu += bc_; a.fv += bc_; a.dy += by_; a.du += bc_; a.dv += bc_;
-    a.mb_type += nmb * bz; a.partition += nmb * bz; a.sub_partition += 4 * nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz; a.i16mode += nmb * bz;
-    a.chroma_mode += nmb * bz; a.qp_out += nmb * bz; a.t8 += nmb * bz; a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
-    a.cbp += nmb * bz; a.nnz += 27 * nmb * bz; a.luma += 256 * nmb * bz; a.luma_dc += 16 * nmb * bz; a.chroma_dc += 8 * nmb * bz;
-    a.chroma_ac += 128 * nmb * bz; a.cost_intra += nmb * bz; a.cost_inter += nmb * bz; a.cost_alt += nmb * bz;
+    // only what every macroblock reads is adjusted here; the arrays that are written once per macroblock are addressed as base + cb
+    // at the store (a base straight from the kernel arguments can be re-loaded; an adjusted one occupies two SGPRs for the whole body)
+    a.mb_type += nmb * bz; a.ref += 4 * nmb * bz; a.i4mode += 16 * nmb * bz;
+    a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
     if (a.l0_type) { a.l0_type += nmb * bz; a.l0_ref += 4 * nmb * bz; a.l0_mv += 32 * nmb * bz; }
     int *prog = a.progress + (size_t)bz * a.mb_h;
     const int satd = a.subme > 1 && !a.lossless, is_p = a.slice_type == 0;
@@ -1857,22 +1857,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             a.ref[(size_t)mb * 4 + lane] = rv;
             if (lane & 1) s.left_r8[lane >> 1] = rv;
         }
-        if (lane < 27) a.nnz[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
-        if (lane < 4) a.sub_partition[(size_t)mb * 4 + lane] = (signed char)(type == T_P_8x8 ? sub_t_mb : 0);
+        if (lane < 27) (a.nnz + 27 * cb)[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
+        if (lane < 4) (a.sub_partition + 4 * cb)[(size_t)mb * 4 + lane] = (signed char)(type == T_P_8x8 ? sub_t_mb : 0);
         if (lane == 0) {
             const int cbp_dc = a.cabac ? (s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2) : 0;
             a.mb_type[mb] = (signed char)type;
-            a.partition[mb] = (signed char)(intra || type == T_P_SKIP ? 16 : part);
-            a.i16mode[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
-            a.chroma_mode[mb] = (signed char)(intra ? predc : 0);
-            a.qp_out[mb] = (signed char)a.qp;
-            a.t8[mb] = (signed char)t8;
-            a.cbp[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
-            a.cost_intra[mb] = stat_intra; a.cost_inter[mb] = stat_inter; a.cost_alt[mb] = stat_alt;
+            (a.partition + cb)[mb] = (signed char)(intra || type == T_P_SKIP ? 16 : part);
+            (a.i16mode + cb)[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
+            (a.chroma_mode + cb)[mb] = (signed char)(intra ? predc : 0);
+            (a.qp_out + cb)[mb] = (signed char)a.qp;
+            (a.t8 + cb)[mb] = (signed char)t8;
+            (a.cbp + cb)[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
+            (a.cost_intra + cb)[mb] = stat_intra; (a.cost_inter + cb)[mb] = stat_inter; (a.cost_alt + cb)[mb] = stat_alt;
         }
         {   // coefficient levels, masked by what the entropy coder reads (cbp, then nnz)
             const bool coded = type != T_P_SKIP;
-            i16 *ly = a.luma + (size_t)mb * 256, *cac = a.chroma_ac + (size_t)mb * 128;
+            i16 *ly = (a.luma + 256 * cb) + (size_t)mb * 256, *cac = (a.chroma_ac + 128 * cb) + (size_t)mb * 128;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int i = lane + 64 * k, blk = i >> 4;
@@ -1883,8 +1883,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 const int i = lane + 64 * k, blk = i >> 4;
                 cac[i] = (coded && cbp_chroma == 2 && s.nnz[16 + blk]) ? s.lv_cac[i] : (i16)0;
             }
-            if (lane < 16) a.luma_dc[(size_t)mb * 16 + lane] = (coded && type == T_I_16x16 && s.nnz[24]) ? s.lv_dc[lane] : (i16)0;
-            if (lane < 8) a.chroma_dc[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
+            if (lane < 16) (a.luma_dc + 16 * cb)[(size_t)mb * 16 + lane] = (coded && type == T_I_16x16 && s.nnz[24]) ? s.lv_dc[lane] : (i16)0;
+            if (lane < 8) (a.chroma_dc + 8 * cb)[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
         }
         left_type = type;
         left_ref = is_p ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);

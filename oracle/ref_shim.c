@@ -379,3 +379,19 @@ void refshim_me_search16_frame(uint8_t *fy, uint8_t *fu, uint8_t *fv, const refs
 
 extern const int x264_lambda2_tab[52];   /* R/encoder/analyse.c:151-159 */
 int refshim_lambda2(int qp) { return x264_lambda2_tab[qp]; }
+
+/* round 2: the reference's trellis quantiser (R/encoder/rdo.c:632-660) on one block, against context states the caller supplies.
+ * kind 0: x264_quant_4x4_trellis, 1: x264_quant_8x8_trellis, 2: x264_quant_dc_trellis.  refshim_cqm_init_preset first.        */
+int x264_quant_dc_trellis(x264_t *h, int16_t *dct, int i_quant_cat, int i_qp, int i_ctxBlockCat, int b_intra);
+int x264_quant_4x4_trellis(x264_t *h, int16_t dct[4][4], int i_quant_cat, int i_qp, int i_ctxBlockCat, int b_intra, int idx);
+int x264_quant_8x8_trellis(x264_t *h, int16_t dct[8][8], int i_quant_cat, int i_qp, int b_intra, int idx);
+void x264_rdo_init(void);
+int refshim_trellis(int16_t *dct, int kind, int qcat, int ctxcat, int qp, int b_intra, const uint8_t *state)
+{
+    static int init;
+    if (!init) { x264_rdo_init(); x264_dct_init_weights(); init = 1; }
+    memcpy(g_cq->cabac.state, state, 460);
+    if (kind == 0) return x264_quant_4x4_trellis(g_cq, (int16_t (*)[4])dct, qcat, qp, ctxcat, b_intra, 0);
+    if (kind == 1) return x264_quant_8x8_trellis(g_cq, (int16_t (*)[8])dct, qcat, qp, b_intra, 0);
+    return x264_quant_dc_trellis(g_cq, dct, qcat, qp, ctxcat, b_intra);
+}

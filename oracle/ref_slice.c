@@ -7,10 +7,17 @@
  * x264_frame_deblock_row / x264_frame_expand_border / x264_frame_filter, i.e. what
  * x264_slice_write + x264_fdec_filter_row do (R/encoder/encoder.c:983-1056,1141-1291; both are
  * static in encoder.c, which cannot be built here, so their dozen lines of sequencing are restated
- * below).  The entropy writer is not called: without RD (subme < 6) nothing it computes feeds back
- * into analysis.  Frames come from x264_frame_new, tables from the x264_*_init functions, the QP
- * from x264_ratecontrol_new/start (CQP).  Every decision and every pixel is produced by reference
- * code; this file only sequences calls and copies results out.                                     */
+ * below).  refslice_encode_chain (round 1) does not call the entropy writer: without RD (subme < 6)
+ * nothing it computes feeds back into analysis.  refslice_encode_chain2 (round 2) is the same loop with
+ * the writer in it, exactly as x264_slice_write sequences it (R/encoder/encoder.c:1155-1165,1192-1219,
+ * 1269-1280): x264_cabac_context_init / x264_cabac_encode_init per slice, the terminal bit, the skip
+ * flag and x264_macroblock_write_cabac (or the skip run and x264_macroblock_write_cavlc) per
+ * macroblock, x264_cabac_encode_flush at the end -- so h->cabac evolves as in the encoder and the RD
+ * levels (subme >= 6), trellis, psy-rd and adaptive quantisation (x264_adaptive_quant_frame) see the
+ * state they see there.  It also returns each slice's payload bytes (slice_data(), i.e. everything
+ * after the slice header).  Frames come from x264_frame_new, tables from the x264_*_init functions,
+ * the QP from x264_ratecontrol_new/start (CQP).  Every decision, every pixel and every payload byte is
+ * produced by reference code; this file only sequences calls and copies results out.               */
 #include "common/common.h"
 #include "encoder/ratecontrol.h"
 #include "encoder/analyse.h"
@@ -26,6 +33,23 @@ typedef struct {
     int mv_range;                            /* param.analyse.i_mv_range (0 = 512) */
     int cqm_preset;                          /* param.i_cqm_preset: 0 X264_CQM_FLAT, 1 X264_CQM_JVT */
 } refslice_params;
+
+/* round 2: what refslice_encode_chain2 takes on top of refslice_params */
+typedef struct {
+    int trellis;                             /* param.analyse.i_trellis 0..2 */
+    float psy_rd, psy_trellis;               /* param.analyse.f_psy_rd / f_psy_trellis (x264_validate_parameters' effects are applied below) */
+    int aq_mode; float aq_strength;          /* param.rc.i_aq_mode / f_aq_strength */
+    int write;                               /* 1: call the entropy writer after every macroblock (required for subme >= 6) */
+    int payload_cap;                         /* bytes per frame available in refslice_out2.payload */
+    int cabac_init_idc;                      /* param.i_cabac_init_idc */
+} refslice_ext;
+
+typedef struct {
+    uint8_t *payload;                        /* [F][payload_cap]: slice_data() of every frame */
+    int32_t *payload_len;                    /* [F] */
+    int32_t *mb_bits;                        /* [F][n]: bits written once this macroblock is out (x264_cabac_pos / bs_pos) */
+    float *qp_offset;                        /* [F][n]: fenc->f_qp_offset (0 without AQ) */
+} refslice_out2;
 
 typedef struct {
     int8_t *mb_type, *partition, *sub_partition;     /* [F][n], [F][n], [F][n][4] */
@@ -76,10 +100,12 @@ static const uint8_t flat16[64] = {
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16 };
 
-int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
-                          refslice_out *o)
+static int run_chain(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
+                     refslice_out *o, refslice_out2 *o2)
 {
     x264_t *h = calloc(1, sizeof(x264_t));
+    uint8_t *bsbuf = NULL;
+    const int b_write = e && e->write;
     x264_frame_t *refs[16] = {0};
     int n_avail = 0, f, i, k, y, mb_w, mb_h, n, last_idr = 0;
     int cw = p->width / 2, ch = p->height / 2;
@@ -97,6 +123,21 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->param.analyse.i_noise_reduction = p->noise_reduction; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
     h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
     h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
+    if (e) {                                             /* x264_validate_parameters, R/encoder/encoder.c:493-522 */
+        h->param.analyse.i_trellis = p->cabac ? x264_clip3(e->trellis, 0, 2) : 0;
+        h->param.analyse.f_psy_rd = p->subme < 6 ? 0 : x264_clip3f(e->psy_rd, 0, 10);
+        h->param.analyse.f_psy_trellis = h->param.analyse.i_trellis ? x264_clip3f(e->psy_trellis, 0, 10) : 0;
+        h->mb.i_psy_rd = FIX8(h->param.analyse.f_psy_rd);
+        if (h->mb.i_psy_rd) h->param.analyse.i_chroma_qp_offset -= h->param.analyse.f_psy_rd < 0.25 ? 1 : 2;
+        h->mb.i_psy_trellis = FIX8(h->param.analyse.f_psy_trellis / 4);
+        if (h->mb.i_psy_trellis) h->param.analyse.i_chroma_qp_offset -= h->param.analyse.f_psy_trellis < 0.25 ? 1 : 2;
+        h->param.analyse.i_chroma_qp_offset = x264_clip3(h->param.analyse.i_chroma_qp_offset, -12, 12);
+        h->param.rc.f_aq_strength = x264_clip3f(e->aq_strength, 0, 3);
+        h->param.rc.i_aq_mode = h->param.rc.f_aq_strength == 0 ? 0 : x264_clip3(e->aq_mode, 0, 1);
+        h->param.i_cabac_init_idc = x264_clip3(e->cabac_init_idc, 0, 2);
+        if (p->subme >= 6 && !b_write) return -4;        /* the RD levels read the live entropy-coder state */
+        x264_rdo_init();                                 /* R/encoder/encoder.c:728 */
+    }
     h->param.rc.i_qp_min = p->cqm_preset ? 6 : 0; h->param.rc.i_qp_max = 51;   /* jvt: qp < 6 overflows the 16-bit multipliers (x264_cqm_init refuses) */
     if (p->qp == 0) {                                    /* x264_validate_parameters, R/encoder/encoder.c:401-421: lossless */
         h->mb.b_lossless = 1;
@@ -116,6 +157,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     if (x264_cqm_init(h) < 0) return -1;
     x264_pixel_init(0, &h->pixf); x264_dct_init(0, &h->dctf); x264_zigzag_init(0, &h->zigzagf, 0);
     x264_quant_init(h, 0, &h->quantf); x264_mc_init(0, &h->mc); x264_deblock_init(0, &h->loopf);
+    x264_dct_init_weights(); x264_init_vlc_tables();                                             /* R/encoder/encoder.c:736-743 */
     x264_predict_16x16_init(0, h->predict_16x16); x264_predict_8x8c_init(0, h->predict_8x8c);
     x264_predict_8x8_init(0, h->predict_8x8, &h->predict_8x8_filter); x264_predict_4x4_init(0, h->predict_4x4);
     sel_cmp(h);
@@ -124,6 +166,7 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     h->fenc = x264_frame_new(h);
     h->fdec = x264_frame_new(h);
     if (x264_macroblock_cache_init(h) < 0 || x264_ratecontrol_new(h) < 0) return -2;
+    if (b_write) bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
 
     for (f = 0; f < p->n_frames; f++) {
         int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
@@ -143,6 +186,8 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
         h->fenc->i_frame = f; h->fenc->i_poc = 2 * (f - last_idr);
         h->fenc->i_type = idr ? X264_TYPE_IDR : X264_TYPE_P;
         h->fdec->i_frame = f; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type; h->fdec->b_kept_as_ref = 1;
+        h->i_frame = f;                                   /* frames coded so far (x264_reference_update, encoder.c:1063) */
+        if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, h->fenc);   /* encoder.c:1421 */
         h->i_ref0 = n_avail < p->n_refs ? n_avail : p->n_refs;
         for (i = 0; i < h->i_ref0; i++) h->fref0[i] = refs[i];
         h->i_ref1 = 0;
@@ -154,10 +199,20 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
         h->sh.i_num_ref_idx_l1_active = 1;
         h->sh.i_disable_deblocking_filter_idc = !p->deblock;
         h->sh.i_alpha_c0_offset = p->alpha_c0; h->sh.i_beta_offset = p->beta;
+        h->sh.i_cabac_init_idc = h->param.i_cabac_init_idc;
         x264_ratecontrol_start(h, 0);
         h->sh.i_qp = x264_ratecontrol_qp(h);
         x264_macroblock_slice_init(h);
         memset(&h->stat.frame, 0, sizeof(h->stat.frame));
+        int i_skip = 0;
+        if (b_write) {                                    /* x264_slice_write after the header, encoder.c:1155-1165 */
+            memset(bsbuf, 0, 64 + (size_t)e->payload_cap + 4096);
+            bs_init(&h->out.bs, bsbuf + 64, e->payload_cap + 4096);
+            if (h->param.b_cabac) {
+                x264_cabac_context_init(&h->cabac, h->sh.i_type, h->sh.i_qp, h->sh.i_cabac_init_idc);
+                x264_cabac_encode_init(&h->cabac, h->out.bs.p, h->out.bs.p_end);
+            }
+        }
         h->mb.i_last_qp = h->sh.i_qp; h->mb.i_last_dqp = 0;
         o->frame_info[4 * F] = h->sh.i_type; o->frame_info[4 * F + 1] = h->sh.i_qp;
         o->frame_info[4 * F + 2] = h->i_ref0; o->frame_info[4 * F + 3] = h->fdec->i_poc;
@@ -178,8 +233,28 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
                 memcpy(o->rec_u + (F * 8 * mb_h + 8 * my + y) * 8 * mb_w + 8 * mx, h->mb.pic.p_fdec[1] + y * FDEC_STRIDE, 8);
                 memcpy(o->rec_v + (F * 8 * mb_h + 8 * my + y) * 8 * mb_w + 8 * mx, h->mb.pic.p_fdec[2] + y * FDEC_STRIDE, 8);
             }
+            if (b_write) {                                /* encoder.c:1192-1219 */
+                if (h->param.b_cabac) {
+                    if (mb > 0) x264_cabac_encode_terminal(&h->cabac);
+                    if (IS_SKIP(h->mb.i_type)) x264_cabac_mb_skip(h, 1);
+                    else {
+                        if (h->sh.i_type != SLICE_TYPE_I) x264_cabac_mb_skip(h, 0);
+                        x264_macroblock_write_cabac(h, &h->cabac);
+                    }
+                    o2->mb_bits[M] = x264_cabac_pos(&h->cabac);
+                } else {
+                    if (IS_SKIP(h->mb.i_type)) i_skip++;
+                    else {
+                        if (h->sh.i_type != SLICE_TYPE_I) { bs_write_ue(&h->out.bs, i_skip); i_skip = 0; }
+                        x264_macroblock_write_cavlc(h, &h->out.bs);
+                    }
+                    o2->mb_bits[M] = bs_pos(&h->out.bs);
+                }
+                if (o2->mb_bits[M] / 8 + 2048 > e->payload_cap) return -5;
+            }
             x264_macroblock_cache_save(h);
             h->stat.frame.i_mb_count[h->mb.i_type]++;
+            if (o2) o2->qp_offset[M] = h->param.rc.i_aq_mode ? h->fenc->f_qp_offset[mb] : 0;
 
             o->mb_type[M] = h->mb.i_type;
             o->partition[M] = IS_INTRA(h->mb.i_type) || h->mb.i_type == P_SKIP ? D_16x16 : h->mb.i_partition;
@@ -219,6 +294,14 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
                     for (i = 0; i < 8; i++) if (nz[16 + i]) memcpy(cac + 16 * i, h->dct.luma4x4[16 + i], 32);
             }
         }
+        if (b_write) {                                    /* encoder.c:1269-1280 */
+            if (h->param.b_cabac) { x264_cabac_encode_flush(h, &h->cabac); h->out.bs.p = h->cabac.p; }
+            else { if (i_skip > 0) bs_write_ue(&h->out.bs, i_skip); bs_rbsp_trailing(&h->out.bs); }
+            int len = (int)(h->out.bs.p - (bsbuf + 64));
+            if (len > e->payload_cap) return -5;
+            o2->payload_len[F] = len;
+            memcpy(o2->payload + F * e->payload_cap, bsbuf + 64, len);
+        }
         filter_row(h, mb_h);
         x264_noise_reduction_update(h);                      /* x264_encoder_frame_end, R/encoder/encoder.c:1755 */
         o->stat[4 * F] = h->stat.frame.i_intra_cost; o->stat[4 * F + 1] = h->stat.frame.i_inter_cost;
@@ -241,6 +324,19 @@ int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const 
     x264_ratecontrol_delete(h);
     x264_macroblock_cache_end(h);
     x264_cqm_delete(h);
+    free(bsbuf);
     free(h);
     return 0;
+}
+
+int refslice_encode_chain(const refslice_params *p, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
+                          refslice_out *o)
+{
+    return run_chain(p, NULL, src_y, src_u, src_v, o, NULL);
+}
+
+int refslice_encode_chain2(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u,
+                           const uint8_t *src_v, refslice_out *o, refslice_out2 *o2)
+{
+    return run_chain(p, e, src_y, src_u, src_v, o, o2);
 }

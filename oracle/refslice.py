@@ -60,6 +60,26 @@ OUT_FIELDS = [("mb_type", np.int8, lambda F, n, R, w, h: (F, n)),
               ("stat", np.int64, lambda F, n, R, w, h: (F, 4))]
 
 
+class Ext(C.Structure):
+    """refslice_ext (oracle/ref_slice.c): what refslice_encode_chain2 takes on top of Params."""
+    _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_float), ("psy_trellis", C.c_float), ("aq_mode", C.c_int),
+                ("aq_strength", C.c_float), ("write", C.c_int), ("payload_cap", C.c_int), ("cabac_init_idc", C.c_int)]
+
+
+def make_ext(trellis=0, psy_rd=0.0, psy_trellis=0.0, aq_mode=0, aq_strength=1.0, write=1, payload_cap=0, cabac_init_idc=0):
+    return Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc)
+
+
+OUT2_FIELDS = [("payload", np.uint8, lambda F, n, cap: (F, cap)),
+               ("payload_len", np.int32, lambda F, n, cap: (F,)),
+               ("mb_bits", np.int32, lambda F, n, cap: (F, n)),
+               ("qp_offset", np.float32, lambda F, n, cap: (F, n))]
+
+
+class Out2(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in OUT2_FIELDS]
+
+
 class Out(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in OUT_FIELDS]
 
@@ -87,6 +107,26 @@ def run(lib, fn, p, y, u, v):
     return arrs
 
 
+def run2(lib, fn, p, e, y, u, v):
+    """The round-2 entry (entropy writer in the loop): the same arrays plus payload / payload_len / mb_bits / qp_offset."""
+    mb_w, mb_h = (p.width + 15) // 16, (p.height + 15) // 16
+    if not e.payload_cap:
+        e.payload_cap = mb_w * mb_h * 800 + 4096
+    arrs, o = alloc_out(p)
+    arrs2 = {name: np.zeros(shape(p.n_frames, mb_w * mb_h, e.payload_cap), dt) for name, dt, shape in OUT2_FIELDS}
+    o2 = Out2(**{k: v.ctypes.data for k, v in arrs2.items()})
+    f = getattr(lib, fn)
+    f.restype = C.c_int
+    rc = f(C.byref(p), C.byref(e), y.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+           C.byref(o), C.byref(o2))
+    if rc != 0:
+        raise RuntimeError("%s failed: %d" % (fn, rc))
+    arrs.update(arrs2)
+    # keep only the bytes that were written: the fixture stays small
+    arrs["payload"] = np.ascontiguousarray(arrs["payload"][:, :max(int(arrs["payload_len"].max()), 1)])
+    return arrs
+
+
 def reference_lib():
     from oracle import hostpic
     return hostpic.load_lazy(os.path.join(HERE, "_ref", "libx264ref.so"))
@@ -94,3 +134,7 @@ def reference_lib():
 
 def run_reference(p, y, u, v):
     return run(reference_lib(), "refslice_encode_chain", p, y, u, v)
+
+
+def run_reference2(p, e, y, u, v):
+    return run2(reference_lib(), "refslice_encode_chain2", p, e, y, u, v)

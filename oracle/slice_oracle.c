@@ -40,6 +40,19 @@ typedef struct {
     int64_t *stat;
 } slice_out;
 
+/* round 2: the twin of refslice_ext / refslice_out2 (oracle/ref_slice.c) */
+typedef struct {
+    int trellis;
+    float psy_rd, psy_trellis;
+    int aq_mode; float aq_strength;
+    int write, payload_cap, cabac_init_idc;
+} slice_ext;
+typedef struct {
+    u8 *payload;
+    int32_t *payload_len, *mb_bits;
+    float *qp_offset;
+} slice_out2;
+
 /* mb types / partitions / slice types with the reference's numbering (R/common/macroblock.h:55-102, R/common/common.h:128-134) */
 enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6 };
 enum { S_D_L0_4x4 = 0, S_D_L0_8x4 = 1, S_D_L0_4x8 = 2, S_D_L0_8x8 = 3, S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
@@ -71,6 +84,7 @@ static x264hip_predict_t s_p16[7], s_p8c[7], s_p4[12];
 static x264hip_predict8x8_t s_p8[12];
 static x264hip_predict_8x8_filter_t s_p8filter;
 void x264o_cqm(int preset, int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant);
+void x264o_cqm_unquant(int preset, int cat, int qp, int is8x8, int *unq);
 void x264o_predict_16x16_init(x264hip_predict_t pf[7]);
 void x264o_predict_4x4_init(x264hip_predict_t pf[12]);
 #ifdef X264O_USE_REF
@@ -114,6 +128,14 @@ typedef struct {
     int poc, n_ref0, ref_poc[16], inv_ref_poc[16];
 } sframe;
 
+typedef struct {                             /* x264_cabac_t, R/common/cabac.h:27-46 */
+    int low, range, queue, outstanding;
+    u8 *p, *start, *end;
+    int f8;                                  /* f8_bits_encoded */
+    int i_frame;                             /* frames coded before this one (x264_cabac_encode_flush's padding bit) */
+    u8 state[460];
+} o_cabac;
+
 typedef struct {
     const slice_params *p;
     int mb_w, mb_h, n, sy, sc, w16, h16;
@@ -130,6 +152,22 @@ typedef struct {
     int f;
     /* --nr: h->nr_residual_sum / nr_count / nr_offset, [0] 4x4, [1] 8x8 (R/common/common.h:308-310) */
     int lossless;                            /* h->mb.b_lossless: constant QP 0 (R/encoder/encoder.c:401-421) */
+    /* round 2: RD levels, trellis, the entropy coder, per-macroblock QP */
+    const slice_ext *e;
+    slice_out2 *o2;
+    int mbrd, psy_rd, trellis, b_trellis;    /* a->i_mbrd, h->mb.i_psy_rd, param i_trellis, h->mb.b_trellis (what the encode functions obey now) */
+    int chroma_qp_offset;                    /* after x264_validate_parameters' psy adjustment */
+    int frame_qp, qp_min, qp_max;            /* rc->qpm of the frame; param.rc.i_qp_min / max */
+    float f_qpm, *aq_offset;                 /* rc->f_qpm; fenc->f_qp_offset[n] (adaptive quantisation) */
+    int last_qp, last_dqp, prev_mb;          /* h->mb.i_last_qp / i_last_dqp / i_mb_prev_xy */
+    i16 *cbp;                                /* h->mb.cbp[n] */
+    int8_t *chroma_pm;                       /* h->mb.chroma_pred_mode[n] ("fixed" numbering, DC for anything not intra) */
+    i16 *mvd;                                /* h->mb.mvd[0]: [n][16][2] */
+    int8_t *qp_mb;                           /* h->mb.qp[n] */
+    int unq4[4][16], unq8[2][64];            /* h->unquant4_mf / unquant8_mf at the current QPs */
+    u8 zz4[16], zz8[64]; int w4z[16], w8z[64];   /* x264_zigzag_scan4/8[0], x264_dct4/8_weight2_zigzag[0] */
+    u8 *bsbuf; int i_skip;
+    o_cabac cb;                              /* h->cabac */
     uint32_t nr_sum[2][64], nr_count[2];
     uint16_t nr_offset[2][64];
 } ssl;
@@ -155,7 +193,25 @@ typedef struct {
     int satd_i16, satd_i8, satd_i4, satd_chroma, fast_intra, pred16, pred8[4], pred4[16], predc;
     u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     int i4_cbp, i8_cbp;
+    /* round 2 */
+    int qp;                              /* h->mb.i_qp */
+    int skip_intra;                      /* h->mb.i_skip_intra */
+    i16 i4_dct[16][16], i8_dct[4][64];   /* h->mb.pic.i4x4_dct_buf / i8x8_dct_buf (i_skip_intra == 2) */
+    int cbp_left, cbp_top, cpm_left, cpm_top, nb_t8;   /* cache.i_cbp_left / top (-1: none), neighbours' chroma modes, i_neighbour_transform_size */
+    u8 nz_l[4], nz_t[4], nz_lc[2][2], nz_tc[2][2];      /* neighbours' non_zero_count next to this macroblock (0x80: none) */
+    i16 cmvd[48][2];                     /* h->mb.cache.mvd[0], x264_scan8 layout */
+    int fenc_satd[4][4], fenc_sa8d[2][2], fenc_satd_sum, fenc_sa8d_sum;   /* h->mb.pic.fenc_satd ... (psy-RD) */
 } smb;
+
+/* what x264_mb_analysis_t keeps of the P analysis (R/encoder/analyse.c:42-137) */
+typedef struct { int mvx, mvy, cost, cost_mv, ref, ref_cost; i16 mvp[2]; } pme;
+typedef struct { int mvx, mvy, cost; i16 mvp[2]; } sub_me;
+typedef struct {
+    pme me16, me8[4], me16x8[2], me8x16[2];
+    sub_me me4[4][4], me84[4][2], me48[4][2];
+    int sub[4];
+    int cost8x8, cost16x8, cost8x16, rd16;
+} panalysis;
 
 static int s_scan8(int i)
 {   /* x264_scan8, R/common/common.h:196-238 */
@@ -295,6 +351,32 @@ static void pred_4x4(const ssl *S, smb *m, int idx, int mode)
     else s_p4[mode](dst);
 }
 
+/* x264_quant_4x4 / x264_quant_8x8 (R/encoder/macroblock.c:87-103) and the DC calls: plain dead-zone quantisation or trellis */
+static int trellis_quant(const ssl *S, i16 *dct, const u16 *mf, const int *unq, const int *weight, const u8 *zz,
+                         int cat, int lambda2, int b_ac, int dc, int n_coef);
+static const int s_trellis_lambda2[2][52];
+static int q4(const ssl *S, i16 d[4][4], int qcat, int ctxcat, int b_intra, int qp)
+{
+    if (S->b_trellis)
+        return trellis_quant(S, &d[0][0], S->mf4[qcat], S->unq4[qcat], S->w4z, S->zz4, ctxcat, s_trellis_lambda2[b_intra][qp],
+                             ctxcat == 1 || ctxcat == 4, 0, 16);
+    return quantf.quant_4x4(d, (u16 *)S->mf4[qcat], (u16 *)S->b4[qcat]);
+}
+static int q8(const ssl *S, i16 d[8][8], int qcat, int b_intra, int qp)
+{
+    if (S->b_trellis)
+        return trellis_quant(S, &d[0][0], S->mf8[qcat], S->unq8[qcat], S->w8z, S->zz8, 5, s_trellis_lambda2[b_intra][qp], 0, 0, 64);
+    return quantf.quant_8x8(d, (u16 *)S->mf8[qcat], (u16 *)S->b8[qcat]);
+}
+static int qdc(const ssl *S, i16 *d, int qcat, int ctxcat, int b_intra, int qp)
+{   /* x264_quant_dc_trellis (rdo.c:632-639) or quant_4x4_dc / quant_2x2_dc */
+    static const u8 zz2[4] = {0, 1, 2, 3};
+    if (S->b_trellis)
+        return trellis_quant(S, d, S->mf4[qcat], S->unq4[qcat], 0, ctxcat == 3 ? zz2 : S->zz4, ctxcat, s_trellis_lambda2[b_intra][qp], 0, 1, ctxcat == 3 ? 4 : 16);
+    if (ctxcat == 3) return quantf.quant_2x2_dc((i16 (*)[2])d, S->mf4[qcat][0] >> 1, S->b4[qcat][0] << 1);
+    return quantf.quant_4x4_dc((i16 (*)[4])d, S->mf4[qcat][0] >> 1, S->b4[qcat][0] << 1);
+}
+
 static void enc_i4x4(ssl *S, smb *m, int idx)
 {
     if (S->lossless) {                                   /* macroblock.c:123-130 */
@@ -308,7 +390,7 @@ static void enc_i4x4(ssl *S, smb *m, int idx)
     i16 d[4][4];
     u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
     dctf.sub4x4_dct(d, src, dst);
-    int nz = quantf.quant_4x4(d, S->mf4[0], S->b4[0]);
+    int nz = q4(S, d, 0, 2, 1, S->qp);
     m->nnz[idx] = nz;
     if (nz) {
         m->cbp_luma |= 1 << (idx >> 2);
@@ -330,7 +412,7 @@ static void enc_i8x8(ssl *S, smb *m, int idx)
         return;
     }
     dctf.sub8x8_dct8(d, src, dst);
-    int nz = quantf.quant_8x8(d, S->mf8[0], S->b8[0]);
+    int nz = q8(S, d, 0, 1, S->qp);
     if (nz) {
         m->cbp_luma |= 1 << idx;
         zigf[0].scan_8x8(m->luma8[idx], d);
@@ -361,7 +443,7 @@ static void enc_i16x16(ssl *S, smb *m)
     for (int i = 0; i < 16; i++) {
         dc[0][s_z2r[i]] = d[i][0][0];
         d[i][0][0] = 0;
-        nz = quantf.quant_4x4(d[i], S->mf4[0], S->b4[0]);
+        nz = q4(S, d[i], 0, 1, 1, S->qp);
         m->nnz[i] = nz;
         if (nz) {
             zigf[0].scan_4x4(m->luma4[i], d[i]);
@@ -372,7 +454,7 @@ static void enc_i16x16(ssl *S, smb *m)
     }
     if (score < 6) { m->cbp_luma = 0; memset(m->nnz, 0, 16); }
     dctf.dct4x4dc(dc);
-    nz = quantf.quant_4x4_dc(dc, S->mf4[0][0] >> 1, S->b4[0][0] << 1);
+    nz = qdc(S, &dc[0][0], 0, 0, 1, S->qp);
     m->nnz[24] = nz;
     if (nz) {
         zigf[0].scan_4x4(m->dc16, dc);
@@ -414,7 +496,7 @@ static void enc_chroma(ssl *S, smb *m, int b_inter)
             d4[0][0][0] = d4[1][0][0] = d4[2][0][0] = d4[3][0][0] = 0;
         }
         for (int i = 0; i < 4; i++) {
-            int nz = quantf.quant_4x4(d4[i], S->mf4[cat], S->b4[cat]);
+            int nz = q4(S, d4[i], cat, 4, !b_inter, qpc);
             m->nnz[16 + 4 * ch + i] = nz;
             if (nz) {
                 nz_ac = 1;
@@ -423,7 +505,7 @@ static void enc_chroma(ssl *S, smb *m, int b_inter)
                 if (b_decimate) score += quantf.decimate_score15(m->cac[4 * ch + i]);
             }
         }
-        int nz_dc = quantf.quant_2x2_dc(d2, S->mf4[cat][0] >> 1, S->b4[cat][0] << 1);
+        int nz_dc = qdc(S, &d2[0][0], cat, 3, !b_inter, qpc);
         m->nnz[25 + ch] = nz_dc;
         /* IDCT_DEQUANT_START, :40-51 */
         int e0 = d2[0][0] + d2[0][1], e1 = d2[1][0] + d2[1][1], e2 = d2[0][0] - d2[0][1], e3 = d2[1][0] - d2[1][1];
@@ -465,11 +547,12 @@ static void enc_inter_luma(ssl *S, smb *m)
     }
     if (m->t8) {
         i16 d8[4][8][8];
+        b_decimate &= !S->b_trellis;                     /* "8x8 trellis is inherently optimal decimation", macroblock.c:630 */
         dctf.sub16x16_dct8(d8, m->fe[0], m->fd[0]);
         if (S->p->noise_reduction && !S->lossless) S->nr_count[1] += 4;
         for (int idx = 0; idx < 4; idx++) {
             if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
-            int nz = quantf.quant_8x8(d8[idx], S->mf8[1], S->b8[1]);
+            int nz = q8(S, d8[idx], 1, 0, S->qp);
             if (nz) {
                 zigf[0].scan_8x8(m->luma8[idx], d8[idx]);
                 if (b_decimate) {
@@ -498,7 +581,7 @@ static void enc_inter_luma(ssl *S, smb *m)
             int dec8 = 0, cbp = 0;
             for (int i4 = 0; i4 < 4; i4++) {
                 if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
-                int idx = 4 * i8 + i4, nz = quantf.quant_4x4(d4[idx], S->mf4[1], S->b4[1]);
+                int idx = 4 * i8 + i4, nz = q4(S, d4[idx], 1, 2, 0, S->qp);
                 m->nnz[idx] = nz;
                 if (nz) {
                     zigf[0].scan_4x4(m->luma4[idx], d4[idx]);
@@ -659,7 +742,7 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
     if (flags & 2) {                                           /* X264_ANALYSE_I8x8 */
         u8 edge[40];
         x264hip_pixel_cmp_t sa8d = satd ? pixf.sa8d[X264HIP_PIXEL_8x8] : pixf.sad[X264HIP_PIXEL_8x8];
-        int thresh = satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = 0, idx;
+        int thresh = S->mbrd ? S_COST_MAX : satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = 0, idx;
         m->cbp_luma = 0;
         for (idx = 0;; idx++) {
             int x = idx & 1, y = idx >> 1, best = S_COST_MAX, pm = pred_intra4x4_mode(m, 4 * idx);
@@ -679,18 +762,22 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
         }
         if (idx == 3) {
             m->satd_i8 = cost;
-            for (int r = 0; r < 16; r++) memcpy(m->i8_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
-            memcpy(m->i8_nnz, m->nnz, 16); m->i8_cbp = m->cbp_luma;
+            if (m->skip_intra) {
+                for (int r = 0; r < 16; r++) memcpy(m->i8_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
+                memcpy(m->i8_nnz, m->nnz, 16); m->i8_cbp = m->cbp_luma;
+                if (m->skip_intra == 2) memcpy(m->i8_dct, m->luma8, sizeof(m->i8_dct));
+            }
         } else {
             static const u16 div8[3] = {1024, 512, 341};
             m->satd_i8 = S_COST_MAX;
             cost = (cost * div8[idx]) >> 8;
         }
-        if ((cost < m->satd_i16 ? cost : m->satd_i16) > satd_inter * 5 / 4) return;
+        if ((cost < m->satd_i16 ? cost : m->satd_i16) > satd_inter * (5 + !!S->mbrd) / 4) return;
     }
     if (flags & 1) {                                           /* X264_ANALYSE_I4x4 */
         int thresh = satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = S->lambda * 24, idx;
         if (m->satd_i8 < thresh) thresh = m->satd_i8;
+        if (S->mbrd) thresh = thresh * (10 - m->fast_intra) / 8;
         m->cbp_luma = 0;
         for (idx = 0;; idx++) {
             u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
@@ -710,8 +797,11 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
         }
         if (idx == 15) {
             m->satd_i4 = cost;
-            for (int r = 0; r < 16; r++) memcpy(m->i4_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
-            memcpy(m->i4_nnz, m->nnz, 16); m->i4_cbp = m->cbp_luma;
+            if (m->skip_intra) {
+                for (int r = 0; r < 16; r++) memcpy(m->i4_fdec + 16 * r, m->fd[0] + r * FDEC, 16);
+                memcpy(m->i4_nnz, m->nnz, 16); m->i4_cbp = m->cbp_luma;
+                if (m->skip_intra == 2) memcpy(m->i4_dct, m->luma4, sizeof(m->i4_dct));
+            }
         } else
             m->satd_i4 = S_COST_MAX;
     }
@@ -772,6 +862,28 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
 #undef NBSET
     }
     m->partition = S_D_16x16;
+    /* what the entropy coder reads of the neighbours (R/common/macroblock.c:896-1010,1129-1160) */
+    m->cbp_left = m->cbp_top = -1; m->cpm_left = m->cpm_top = 0; m->nb_t8 = 0;
+    memset(m->nz_l, 0x80, 4); memset(m->nz_t, 0x80, 4); memset(m->nz_lc, 0x80, 4); memset(m->nz_tc, 0x80, 4);
+    memset(m->cmvd, 0, sizeof(m->cmvd));
+    if (S->cbp) {
+        if (m->nb & NB_TOP) {
+            const int t = m->mb - S->mb_w;
+            const u8 *nz = S->nnz + t * 27;
+            m->cbp_top = S->cbp[t]; m->cpm_top = S->chroma_pm[t]; m->nb_t8 += S->t8[t];
+            m->nz_t[0] = nz[10]; m->nz_t[1] = nz[11]; m->nz_t[2] = nz[14]; m->nz_t[3] = nz[15];
+            for (int ch = 0; ch < 2; ch++) { m->nz_tc[ch][0] = nz[16 + 4 * ch + 2]; m->nz_tc[ch][1] = nz[16 + 4 * ch + 3]; }
+            for (int i = 0; i < 4; i++) { m->cmvd[4 + i][0] = S->mvd[(t * 16 + 12 + i) * 2]; m->cmvd[4 + i][1] = S->mvd[(t * 16 + 12 + i) * 2 + 1]; }
+        }
+        if (m->nb & NB_LEFT) {
+            const int l = m->mb - 1;
+            const u8 *nz = S->nnz + l * 27;
+            m->cbp_left = S->cbp[l]; m->cpm_left = S->chroma_pm[l]; m->nb_t8 += S->t8[l];
+            m->nz_l[0] = nz[5]; m->nz_l[1] = nz[7]; m->nz_l[2] = nz[13]; m->nz_l[3] = nz[15];
+            for (int ch = 0; ch < 2; ch++) { m->nz_lc[ch][0] = nz[16 + 4 * ch + 1]; m->nz_lc[ch][1] = nz[16 + 4 * ch + 3]; }
+            for (int i = 0; i < 4; i++) { m->cmvd[11 + 8 * i][0] = S->mvd[(l * 16 + 3 + 4 * i) * 2]; m->cmvd[11 + 8 * i][1] = S->mvd[(l * 16 + 3 + 4 * i) * 2 + 1]; }
+        }
+    }
 }
 
 static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by)
@@ -820,6 +932,16 @@ static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
     else if (rb == -2 && rc == -2 && ra != -2) { mvp[0] = a[0]; mvp[1] = a[1]; }
     else { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
 }
+/* x264_mb_transform_8x8_allowed (R/common/macroblock.h:452-466): large P partitions, P_8x8 only with four 8x8 sub-partitions */
+static int s_t8_allowed(const ssl *S, const smb *m)
+{
+    if (!S->p->transform8x8) return 0;
+    if (m->type == S_P_L0) return 1;
+    return m->type == S_P_8x8 && m->sub[0] == S_D_L0_8x8 && m->sub[1] == S_D_L0_8x8 && m->sub[2] == S_D_L0_8x8 && m->sub[3] == S_D_L0_8x8;
+}
+#include "cabac_oracle.c"
+#include "rd_oracle.c"
+
 /* x264_me_refine_qpel -> refine_subpel(.., b_refine_qpel = 1), R/encoder/me.c:634-778, 16x16 */
 static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
 {
@@ -858,7 +980,6 @@ static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int 
 }
 
 /* x264_mb_analyse_inter_p4x4_chroma, R/encoder/analyse.c:1373-1405: mc_chroma of every sub-block into a 4x4, then mbcmp 4x4 on U and V */
-typedef struct { int mvx, mvy, cost; i16 mvp[2]; } sub_me;
 static int p4x4_chroma(const ssl *S, const smb *m, int ref, int i8, int sub, const sub_me *me)
 {
     u8 pix1[16 * 8], *pix2 = pix1 + 8;
@@ -894,7 +1015,102 @@ static void nr_update(ssl *S)
     }
 }
 
-static void analyse_mb(ssl *S, smb *m)
+/* x264_analyse_update_cache, R/encoder/analyse.c:2777-2846 (I and P types): the candidate `m->type / m->partition` names becomes
+ * the macroblock's vectors, references (h->mb.cache and what cache_save will store) or intra modes.                              */
+static void fill_part(smb *m, int x, int y, int w, int h, int ref, int mvx, int mvy)
+{
+    cache_set(m, x, y, w, h, ref, mvx, mvy, 1);
+    for (int j = y; j < y + h; j++)
+        for (int i = x; i < x + w; i++) { m->mv4[j * 4 + i][0] = (i16)mvx; m->mv4[j * 4 + i][1] = (i16)mvy; m->ref8[(j >> 1) * 2 + (i >> 1)] = (int8_t)ref; }
+}
+static void update_cache(ssl *S, smb *m, const panalysis *A)
+{
+    switch (m->type) {
+    case S_I_4x4:
+        for (int i = 0; i < 16; i++) m->i4c[s_scan8(i)] = m->pred4[i];
+        analyse_intra_chroma(S, m);
+        break;
+    case S_I_8x8:
+        for (int i = 0; i < 16; i++) m->i4c[s_scan8(i)] = m->pred8[i >> 2];
+        analyse_intra_chroma(S, m);
+        break;
+    case S_I_16x16:
+        m->i16mode = m->pred16;
+        analyse_intra_chroma(S, m);
+        break;
+    case S_P_L0:
+        if (m->partition == S_D_16x16) fill_part(m, 0, 0, 4, 4, A->me16.ref, A->me16.mvx, A->me16.mvy);
+        else if (m->partition == S_D_16x8)
+            for (int i = 0; i < 2; i++) fill_part(m, 0, 2 * i, 4, 2, A->me16x8[i].ref, A->me16x8[i].mvx, A->me16x8[i].mvy);
+        else
+            for (int i = 0; i < 2; i++) fill_part(m, 2 * i, 0, 2, 4, A->me8x16[i].ref, A->me8x16[i].mvx, A->me8x16[i].mvy);
+        break;
+    case S_P_8x8:
+        for (int i = 0; i < 4; i++) {                        /* x264_mb_cache_mv_p8x8, :1058-1075 */
+            const int x0 = 2 * (i & 1), y0 = 2 * (i >> 1), r = A->me8[i].ref, t = A->sub[i];
+            m->sub[i] = (int8_t)t;
+            if (t == S_D_L0_8x8) fill_part(m, x0, y0, 2, 2, r, A->me8[i].mvx, A->me8[i].mvy);
+            else if (t == S_D_L0_8x4) for (int k = 0; k < 2; k++) fill_part(m, x0, y0 + k, 2, 1, r, A->me84[i][k].mvx, A->me84[i][k].mvy);
+            else if (t == S_D_L0_4x8) for (int k = 0; k < 2; k++) fill_part(m, x0 + k, y0, 1, 2, r, A->me48[i][k].mvx, A->me48[i][k].mvy);
+            else for (int k = 0; k < 4; k++) fill_part(m, x0 + (k & 1), y0 + (k >> 1), 1, 1, r, A->me4[i][k].mvx, A->me4[i][k].mvy);
+        }
+        break;
+    case S_P_SKIP:
+        m->partition = S_D_16x16;
+        fill_part(m, 0, 0, 4, 4, 0, m->pskip_mv[0], m->pskip_mv[1]);
+        m->mvx = m->pskip_mv[0]; m->mvy = m->pskip_mv[1]; m->ref = 0;
+        break;
+    default:
+        break;
+    }
+}
+/* x264_mb_analyse_p_rd, :1935-2005 (sub-8x8 partitions are refused with the RD levels for now) */
+static void analyse_p_rd(ssl *S, smb *m, panalysis *A, int i_satd)
+{
+    const int thresh = i_satd * 5 / 4;
+    m->type = S_P_L0;
+    if (A->rd16 == S_COST_MAX && A->me16.cost <= i_satd * 3 / 2) {
+        m->partition = S_D_16x16;
+        update_cache(S, m, A);
+        A->rd16 = rd_cost_mb(S, m, S->lambda2);
+    }
+    A->me16.cost = A->rd16;
+    if (A->cost16x8 <= thresh) { m->partition = S_D_16x8; update_cache(S, m, A); A->cost16x8 = rd_cost_mb(S, m, S->lambda2); }
+    else A->cost16x8 = S_COST_MAX;
+    if (A->cost8x16 <= thresh) { m->partition = S_D_8x16; update_cache(S, m, A); A->cost8x16 = rd_cost_mb(S, m, S->lambda2); }
+    else A->cost8x16 = S_COST_MAX;
+    if (A->cost8x8 <= thresh) {
+        m->type = S_P_8x8; m->partition = S_D_8x8;
+        update_cache(S, m, A);
+        A->cost8x8 = rd_cost_mb(S, m, S->lambda2);
+    } else A->cost8x8 = S_COST_MAX;
+}
+/* x264_intra_rd, :845-874 */
+static void intra_rd(ssl *S, smb *m, const panalysis *A, int thresh)
+{
+    if (m->satd_i16 <= thresh) { m->type = S_I_16x16; update_cache(S, m, A); m->satd_i16 = rd_cost_mb(S, m, S->lambda2); }
+    else m->satd_i16 = S_COST_MAX;
+    if (m->satd_i4 <= thresh && m->satd_i4 < S_COST_MAX) { m->type = S_I_4x4; update_cache(S, m, A); m->satd_i4 = rd_cost_mb(S, m, S->lambda2); }
+    else m->satd_i4 = S_COST_MAX;
+    if (m->satd_i8 <= thresh && m->satd_i8 < S_COST_MAX) { m->type = S_I_8x8; update_cache(S, m, A); m->satd_i8 = rd_cost_mb(S, m, S->lambda2); }
+    else m->satd_i8 = S_COST_MAX;
+}
+/* x264_mb_analyse_transform_rd, :2127-2150 */
+static void transform_rd(ssl *S, smb *m, const panalysis *A, int *i_satd, int *i_rd)
+{
+    if (!s_t8_allowed(S, m) || !S->p->transform8x8) return;
+    update_cache(S, m, A);
+    m->t8 = !m->t8;
+    const int rd8 = rd_cost_mb(S, m, S->lambda2);
+    if (*i_rd >= rd8) {
+        if (*i_rd > 0) *i_satd = (int)((int64_t)*i_satd * rd8 / *i_rd);
+        if (*i_satd == 0) *i_satd = 1;
+        *i_rd = rd8;
+    } else
+        m->t8 = !m->t8;
+}
+
+static void analyse_mb(ssl *S, smb *m, panalysis *A)
 {
     const slice_params *p = S->p;
     int i_cost = S_COST_MAX;
@@ -905,11 +1121,15 @@ static void analyse_mb(ssl *S, smb *m)
                   || S_IS_INTRA(S->fref[0]->mb_type[m->mb]) || m->mb < 3 * S->intra_count;
         m->fast_intra = !likely;
     }
+    const int satd_pcm = !S->psy_rd && S->mbrd ? (int)(((uint64_t)(386 * 8) * S->lambda2 + 128) >> 8) : S_COST_MAX;   /* a->i_satd_pcm, :246 */
     if (S->slice_type == S_SLICE_I) {
+        if (S->mbrd) cache_fenc_satd(S, m);
         analyse_intra(S, m, S_COST_MAX);
+        if (S->mbrd) intra_rd(S, m, A, S_COST_MAX);
         i_cost = m->satd_i16; m->type = S_I_16x16;
         if (m->satd_i4 < i_cost) { i_cost = m->satd_i4; m->type = S_I_4x4; }
         if (m->satd_i8 < i_cost) { i_cost = m->satd_i8; m->type = S_I_8x8; }
+        if (satd_pcm < i_cost) m->type = S_I_PCM;
     } else {
         int b_skip = 0, try_pskip = 0;
         if (p->fast_pskip && !S->lossless) {
@@ -946,10 +1166,20 @@ static void analyse_mb(ssl *S, smb *m)
             m->type = S_P_L0;
             cache_set(m, 0, 0, 4, 4, bref, 0, 0, 0);
             /* ---- sub-16x16 partitions (X264_ANALYSE_PSUB16x16), R/encoder/analyse.c:2222-2265 ---- */
-            struct { int mvx, mvy, cost, cost_mv, ref, ref_cost; i16 mvp[2]; } me8[4], me16x8[2], me8x16[2];
             int cost8x8 = S_COST_MAX, cost16x8 = S_COST_MAX, cost8x16 = S_COST_MAX, part = S_D_16x16;
-            sub_me me4[4][4], me84[4][2], me48[4][2];
-            int sub[4] = {S_D_L0_8x8, S_D_L0_8x8, S_D_L0_8x8, S_D_L0_8x8};
+            for (int i = 0; i < 4; i++) A->sub[i] = S_D_L0_8x8;
+            A->me16.mvx = bmx; A->me16.mvy = bmy; A->me16.cost = best; A->me16.ref = bref; A->me16.ref_cost = S->ref_cost[bref];
+            A->me16.mvp[0] = bmvp[0]; A->me16.mvp[1] = bmvp[1];
+            A->rd16 = S_COST_MAX;
+            if (S->mbrd) {                                       /* :1134-1143 */
+                cache_fenc_satd(S, m);
+                if (bref == 0 && bmx == m->pskip_mv[0] && bmy == m->pskip_mv[1]) {
+                    m->partition = S_D_16x16;
+                    update_cache(S, m, A);
+                    A->rd16 = rd_cost_mb(S, m, S->lambda2);
+                    if (m->type == S_P_SKIP) return;              /* :2230: the trial encode found nothing to code on the skip vector */
+                }
+            }
             i_cost = best;
             if (p->inter & 0x10) {
                 m->partition = S_D_8x8;
@@ -961,7 +1191,7 @@ static void analyse_mb(ssl *S, smb *m)
                         for (int k = 0; k < 6; k++) if (m->cref[look[k]] > maxref) maxref = m->cref[look[k]];
                     }
                     for (int i = 0; i < 4; i++) {
-                        me8[i].cost = 0x7fffffff;
+                        A->me8[i].cost = 0x7fffffff;
                         for (int r = 0; r <= maxref; r++) {
                             me_ctx c; i16 mvp[2]; int mx, my, cmv = 0, cost;
                             cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, r, 0, 0, 0);
@@ -970,14 +1200,14 @@ static void analyse_mb(ssl *S, smb *m)
                             cost = me_search16(&c, mvp, (const i16 (*)[2])m->l0mvc[r], i + 1, p->me_method, p->me_range, p->subme, chroma_me, 0, &mx, &my, &cmv);
                             cost += S->ref_cost[r];
                             m->l0mvc[r][i + 1][0] = mx; m->l0mvc[r][i + 1][1] = my;
-                            if (cost < me8[i].cost) { me8[i].cost = cost; me8[i].mvx = mx; me8[i].mvy = my; me8[i].cost_mv = cmv; me8[i].ref = r;
-                                                      me8[i].ref_cost = S->ref_cost[r]; me8[i].mvp[0] = mvp[0]; me8[i].mvp[1] = mvp[1]; }
+                            if (cost < A->me8[i].cost) { A->me8[i].cost = cost; A->me8[i].mvx = mx; A->me8[i].mvy = my; A->me8[i].cost_mv = cmv; A->me8[i].ref = r;
+                                                      A->me8[i].ref_cost = S->ref_cost[r]; A->me8[i].mvp[0] = mvp[0]; A->me8[i].mvp[1] = mvp[1]; }
                         }
-                        cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, me8[i].ref, me8[i].mvx, me8[i].mvy, 1);
-                        me8[i].cost += S->lambda * 1;                /* i_sub_mb_p_cost_table[D_L0_8x8] */
+                        cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, A->me8[i].ref, A->me8[i].mvx, A->me8[i].mvy, 1);
+                        A->me8[i].cost += S->lambda * 1;                /* i_sub_mb_p_cost_table[D_L0_8x8] */
                     }
-                    cost8x8 = me8[0].cost + me8[1].cost + me8[2].cost + me8[3].cost;
-                    if (!p->cabac && !(me8[0].ref | me8[1].ref | me8[2].ref | me8[3].ref)) cost8x8 -= S->ref_cost[0] * 4;
+                    cost8x8 = A->me8[0].cost + A->me8[1].cost + A->me8[2].cost + A->me8[3].cost;
+                    if (!p->cabac && !(A->me8[0].ref | A->me8[1].ref | A->me8[2].ref | A->me8[3].ref)) cost8x8 -= S->ref_cost[0] * 4;
                 } else {                                             /* x264_mb_analyse_inter_p8x8, :1221-1272 */
                     const int r = bref, ref_cost = p->cabac || r ? S->ref_cost[r] : 0;
                     int n_mvc = 1;
@@ -989,10 +1219,10 @@ static void analyse_mb(ssl *S, smb *m)
                         cost = me_search16(&c, mvp, (const i16 (*)[2])m->l0mvc[r], n_mvc, p->me_method, p->me_range, p->subme, chroma_me, 0, &mx, &my, &cmv);
                         cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, r, mx, my, 1);
                         m->l0mvc[r][n_mvc][0] = mx; m->l0mvc[r][n_mvc][1] = my; n_mvc++;
-                        me8[i].cost = cost + ref_cost + S->lambda * 1; me8[i].mvx = mx; me8[i].mvy = my; me8[i].cost_mv = cmv; me8[i].ref = r;
-                        me8[i].ref_cost = ref_cost; me8[i].mvp[0] = mvp[0]; me8[i].mvp[1] = mvp[1];
+                        A->me8[i].cost = cost + ref_cost + S->lambda * 1; A->me8[i].mvx = mx; A->me8[i].mvy = my; A->me8[i].cost_mv = cmv; A->me8[i].ref = r;
+                        A->me8[i].ref_cost = ref_cost; A->me8[i].mvp[0] = mvp[0]; A->me8[i].mvp[1] = mvp[1];
                     }
-                    cost8x8 = me8[0].cost + me8[1].cost + me8[2].cost + me8[3].cost;
+                    cost8x8 = A->me8[0].cost + A->me8[1].cost + A->me8[2].cost + A->me8[3].cost;
                     if (p->cabac) cost8x8 -= ref_cost;
                 }
                 if (cost8x8 < best) { m->type = S_P_8x8; part = S_D_8x8; i_cost = cost8x8; }
@@ -1000,15 +1230,15 @@ static void analyse_mb(ssl *S, smb *m)
                     static const int subw[3] = {1, 2, 1}, subh[3] = {1, 1, 2}, subn[3] = {4, 2, 2}, subpix[3] = {6, 4, 5}, subbits[3] = {5, 3, 3};
                     m->partition = S_D_8x8;
                     for (int i = 0; i < 4; i++) {
-                        const int r = me8[i].ref, x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
+                        const int r = A->me8[i].ref, x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
                         int c8 = 0, costs[3];
                         for (int t = 0; t < 3; t++) {                /* D_L0_4x4, then (only if that beats the 8x8) D_L0_8x4 and D_L0_4x8 */
-                            sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                            sub_me *me = t == 0 ? A->me4[i] : t == 1 ? A->me84[i] : A->me48[i];
                             int sum = 0;
                             for (int k = 0; k < subn[t]; k++) {
                                 const int x4 = x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y4 = y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0), idx = 4 * i + (y4 - y0) * 2 + (x4 - x0);
                                 me_ctx c; i16 mvp[2], mvc1[1][2]; int mx, my, cmv = 0;
-                                mvc1[0][0] = t == 0 ? me8[i].mvx : me4[i][0].mvx; mvc1[0][1] = t == 0 ? me8[i].mvy : me4[i][0].mvy;
+                                mvc1[0][0] = t == 0 ? A->me8[i].mvx : A->me4[i][0].mvx; mvc1[0][1] = t == 0 ? A->me8[i].mvy : A->me4[i][0].mvy;
                                 predict_mv_blk(m, idx, subw[t], mvp);
                                 set_me_ctx_blk(S, m, r, mvp, &c, subpix[t], 4 * x4, 4 * y4);
                                 me[k].cost = me_search16(&c, mvp, (const i16 (*)[2])mvc1, k == 0, p->me_method, p->me_range, p->subme, 0, 0, &mx, &my, &cmv);
@@ -1019,29 +1249,29 @@ static void analyse_mb(ssl *S, smb *m)
                             costs[t] = sum + S->ref_cost[r] + S->lambda * subbits[t];
                             if (p->chroma_me && p->subme >= 5) costs[t] += p4x4_chroma(S, m, r, i, t, me);
                             if (t == 0) {
-                                if (!(costs[0] < me8[i].cost)) break;
-                                c8 = costs[0]; sub[i] = S_D_L0_4x4;
-                            } else if (costs[t] < c8) { c8 = costs[t]; sub[i] = t; }
+                                if (!(costs[0] < A->me8[i].cost)) break;
+                                c8 = costs[0]; A->sub[i] = S_D_L0_4x4;
+                            } else if (costs[t] < c8) { c8 = costs[t]; A->sub[i] = t; }
                         }
-                        if (sub[i] != S_D_L0_8x8) i_cost += c8 - me8[i].cost;
+                        if (A->sub[i] != S_D_L0_8x8) i_cost += c8 - A->me8[i].cost;
                         /* x264_mb_cache_mv_p8x8 */
-                        if (sub[i] == S_D_L0_8x8) cache_set(m, x0, y0, 2, 2, r, me8[i].mvx, me8[i].mvy, 1);
+                        if (A->sub[i] == S_D_L0_8x8) cache_set(m, x0, y0, 2, 2, r, A->me8[i].mvx, A->me8[i].mvy, 1);
                         else {
-                            const int t = sub[i];
-                            const sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                            const int t = A->sub[i];
+                            const sub_me *me = t == 0 ? A->me4[i] : t == 1 ? A->me84[i] : A->me48[i];
                             for (int k = 0; k < subn[t]; k++)
                                 cache_set(m, x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0), subw[t], subh[t], r, me[k].mvx, me[k].mvy, 1);
                         }
                     }
                     cost8x8 = i_cost;
                 }
-                const int thresh16x8 = me8[1].cost_mv + me8[2].cost_mv;
+                const int thresh16x8 = A->me8[1].cost_mv + A->me8[2].cost_mv;
                 if (cost8x8 < best + thresh16x8) {
                     for (int dir = 0; dir < 2; dir++) {              /* 0: x264_mb_analyse_inter_p16x8 (:1274), 1: _p8x16 (:1324) */
                         int sum = 0;
                         m->partition = dir ? S_D_8x16 : S_D_16x8;
                         for (int i = 0; i < 2; i++) {
-                            const int ra = dir ? me8[i].ref : me8[2 * i].ref, rb = dir ? me8[i + 2].ref : me8[2 * i + 1].ref;
+                            const int ra = dir ? A->me8[i].ref : A->me8[2 * i].ref, rb = dir ? A->me8[i + 2].ref : A->me8[2 * i + 1].ref;
                             const int rr[2] = {ra, rb}, nr = ra == rb ? 1 : 2;
                             int bcost = 0x7fffffff, bx = 0, by = 0, br = 0, bcm = 0; i16 bp[2] = {0, 0};
                             for (int j = 0; j < nr; j++) {
@@ -1059,7 +1289,7 @@ static void analyse_mb(ssl *S, smb *m)
                                 if (cost < bcost) { bcost = cost; bx = mx; by = my; br = r; bcm = cmv; bp[0] = mvp[0]; bp[1] = mvp[1]; }
                             }
                             if (dir) cache_set(m, 2 * i, 0, 2, 4, br, bx, by, 1); else cache_set(m, 0, 2 * i, 4, 2, br, bx, by, 1);
-                            typeof(me16x8[0]) *d = dir ? &me8x16[i] : &me16x8[i];
+                            pme *d = dir ? &A->me8x16[i] : &A->me16x8[i];
                             d->cost = bcost; d->mvx = bx; d->mvy = by; d->ref = br; d->cost_mv = bcm; d->ref_cost = S->ref_cost[br]; d->mvp[0] = bp[0]; d->mvp[1] = bp[1];
                             sum += bcost;
                         }
@@ -1069,8 +1299,11 @@ static void analyse_mb(ssl *S, smb *m)
                 }
             }
             m->partition = part;
-            /* x264_me_refine_qpel on the winning partition (:2289-2352; the reference cost leaves every block's sum, me.c:639-640) */
-            if (part == S_D_16x16) {
+            A->cost8x8 = cost8x8; A->cost16x8 = cost16x8; A->cost8x16 = cost8x16;
+            /* x264_me_refine_qpel on the winning partition (:2289-2352; the reference cost leaves every block's sum, me.c:639-640);
+             * with the RD levels the vectors stay as the searches left them ("refine later", :2296-2299) */
+            if (S->mbrd) {
+            } else if (part == S_D_16x16) {
                 me_ctx c;
                 set_me_ctx(S, m, bref, bmvp, &c);
                 best -= S->ref_cost[bref];
@@ -1081,23 +1314,23 @@ static void analyse_mb(ssl *S, smb *m)
             } else {
                 i_cost = 0;
                 for (int i = 0; i < (part == S_D_8x8 ? 4 : 2); i++) {
-                    if (part == S_D_8x8 && sub[i] != S_D_L0_8x8) {   /* the sub-8x8 blocks: no reference cost in their sums, no chroma (me.c:639, :654) */
+                    if (part == S_D_8x8 && A->sub[i] != S_D_L0_8x8) {   /* the sub-8x8 blocks: no reference cost in their sums, no chroma (me.c:639, :654) */
                         static const int subw[3] = {1, 2, 1}, subh[3] = {1, 1, 2}, subn[3] = {4, 2, 2}, subpix[3] = {6, 4, 5};
-                        const int t = sub[i], x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
-                        sub_me *me = t == 0 ? me4[i] : t == 1 ? me84[i] : me48[i];
+                        const int t = A->sub[i], x0 = 2 * (i & 1), y0 = 2 * (i >> 1);
+                        sub_me *me = t == 0 ? A->me4[i] : t == 1 ? A->me84[i] : A->me48[i];
                         for (int k = 0; k < subn[t]; k++) {
                             const int x4 = x0 + (t == 0 ? (k & 1) : t == 2 ? k : 0), y4 = y0 + (t == 0 ? (k >> 1) : t == 1 ? k : 0);
                             me_ctx c;
-                            set_me_ctx_blk(S, m, me8[i].ref, me[k].mvp, &c, subpix[t], 4 * x4, 4 * y4);
+                            set_me_ctx_blk(S, m, A->me8[i].ref, me[k].mvp, &c, subpix[t], 4 * x4, 4 * y4);
                             me[k].cost = refine_qpel16(S, &c, me[k].cost, &me[k].mvx, &me[k].mvy, me[k].mvp);
                             i_cost += me[k].cost;
                             for (int y = 0; y < subh[t]; y++)
                                 for (int x = 0; x < subw[t]; x++) { m->mv4[(y4 + y) * 4 + x4 + x][0] = me[k].mvx; m->mv4[(y4 + y) * 4 + x4 + x][1] = me[k].mvy; }
                         }
-                        m->ref8[i] = me8[i].ref;
+                        m->ref8[i] = A->me8[i].ref;
                         continue;
                     }
-                    typeof(me8[0]) *d = part == S_D_8x8 ? &me8[i] : part == S_D_16x8 ? &me16x8[i] : &me8x16[i];
+                    pme *d = part == S_D_8x8 ? &A->me8[i] : part == S_D_16x8 ? &A->me16x8[i] : &A->me8x16[i];
                     const int pix = part == S_D_8x8 ? X264HIP_PIXEL_8x8 : part == S_D_16x8 ? X264HIP_PIXEL_16x8 : X264HIP_PIXEL_8x16;
                     const int bx = part == S_D_8x8 ? 8 * (i & 1) : part == S_D_8x16 ? 8 * i : 0, by = part == S_D_8x8 ? 8 * (i >> 1) : part == S_D_16x8 ? 8 * i : 0;
                     const int w4 = part == S_D_16x8 ? 4 : 2, h4 = part == S_D_8x16 ? 4 : 2;
@@ -1112,7 +1345,7 @@ static void analyse_mb(ssl *S, smb *m)
                 }
             }
             m->mvx = bmx; m->mvy = bmy; m->ref = bref;
-            for (int i = 0; i < 4; i++) m->sub[i] = part == S_D_8x8 ? sub[i] : S_D_L0_8x8;
+            for (int i = 0; i < 4; i++) m->sub[i] = part == S_D_8x8 ? A->sub[i] : S_D_L0_8x8;
             (void)cost16x8; (void)cost8x16;
             if (chroma_me) {
                 analyse_intra_chroma(S, m);
@@ -1122,9 +1355,22 @@ static void analyse_mb(ssl *S, smb *m)
                 analyse_intra(S, m, i_cost);
             int satd_inter = i_cost, satd_intra = m->satd_i16 < m->satd_i8 ? m->satd_i16 : m->satd_i8;
             if (m->satd_i4 < satd_intra) satd_intra = m->satd_i4;
+            if (S->mbrd) {                                       /* :2375-2389 */
+                analyse_p_rd(S, m, A, satd_inter < satd_intra ? satd_inter : satd_intra);
+                m->type = S_P_L0; part = S_D_16x16; i_cost = A->me16.cost;
+                if (A->cost16x8 < i_cost) { i_cost = A->cost16x8; part = S_D_16x8; }
+                if (A->cost8x16 < i_cost) { i_cost = A->cost8x16; part = S_D_8x16; }
+                if (A->cost8x8 < i_cost) { i_cost = A->cost8x8; part = S_D_8x8; m->type = S_P_8x8; }
+                m->partition = part;
+                if (i_cost < S_COST_MAX) transform_rd(S, m, A, &satd_inter, &i_cost);
+                const int keep = m->type == S_P_SKIP ? (part == S_D_8x8 ? S_P_8x8 : S_P_L0) : m->type;   /* i_type is a local of the reference: the trial's P_SKIP does not stick */
+                intra_rd(S, m, A, satd_inter * 5 / 4);
+                m->type = keep;
+            }
             int itype = S_I_16x16, icost = m->satd_i16;
             if (m->satd_i8 < icost) { icost = m->satd_i8; itype = S_I_8x8; }
             if (m->satd_i4 < icost) { icost = m->satd_i4; itype = S_I_4x4; }
+            if (satd_pcm < icost) { icost = satd_pcm; itype = S_I_PCM; }
             if (icost < i_cost) { i_cost = icost; m->type = itype; }
             if (icost == S_COST_MAX) icost = i_cost * satd_intra / satd_inter + 1;
             S->stat_intra += icost; S->stat_inter += i_cost; S->stat_n++;
@@ -1173,7 +1419,7 @@ static void encode_mb(ssl *S, smb *m)
     m->cbp_luma = 0; m->nnz[24] = 0;
     if (m->type == S_P_SKIP) {
         if (!m->skip_mc) {
-            int mvx = m->mvx, mvy = m->mvy;
+            int mvx = m->mv4[0][0], mvy = m->mv4[0][1];          /* h->mb.cache.mv[0][x264_scan8[0]], macroblock.c:380-383 */
             mv_clip_frame(S, m, &mvx, &mvy);
             mc_16x16(S, m, 0, mvx, mvy);
         }
@@ -1185,8 +1431,8 @@ static void encode_mb(ssl *S, smb *m)
         m->t8 = 0;
         pred_16x16(S, m, m->i16mode);
         enc_i16x16(S, m);
-    } else if (S->lossless && (m->type == S_I_8x8 || m->type == S_I_4x4)) {
-        /* i_skip_intra = 0 (analyse.c:250): nothing of the analysis' trial encode is kept, every block is predicted and coded again */
+    } else if (!m->skip_intra && (m->type == S_I_8x8 || m->type == S_I_4x4)) {
+        /* i_skip_intra = 0 (lossless, analyse.c:250; trellis 1 or --nr, :2772): nothing of the analysis' trial encode is kept, every block is predicted and coded again */
         u8 edge[40];
         m->t8 = m->type == S_I_8x8;
         if (m->type == S_I_8x8)
@@ -1208,6 +1454,7 @@ static void encode_mb(ssl *S, smb *m)
         m->t8 = 1;
         for (int r = 0; r < 16; r++) memcpy(m->fd[0] + r * FDEC, m->i8_fdec + 16 * r, 16);
         memcpy(m->nnz, m->i8_nnz, 16); m->cbp_luma = m->i8_cbp;
+        if (m->skip_intra == 2) memcpy(m->luma8, m->i8_dct, sizeof(m->i8_dct));   /* "In RD mode, restore the now-overwritten DCT data", macroblock.c:543 */
         {
             u8 *dst = m->fd[0] + 8 + 8 * FDEC;
             int mode = m->i4c[s_scan8(12)];
@@ -1219,6 +1466,7 @@ static void encode_mb(ssl *S, smb *m)
         m->t8 = 0;
         for (int r = 0; r < 16; r++) memcpy(m->fd[0] + r * FDEC, m->i4_fdec + 16 * r, 16);
         memcpy(m->nnz, m->i4_nnz, 16); m->cbp_luma = m->i4_cbp;
+        if (m->skip_intra == 2) memcpy(m->luma4, m->i4_dct, sizeof(m->i4_dct));
         {
             u8 *dst = m->fd[0] + 12 + 12 * FDEC;
             if ((m->nb4[15] & (NB_TOPRIGHT | NB_TOP)) == NB_TOP) memset(dst + 4 - FDEC, dst[3 - FDEC], 4);
@@ -1242,6 +1490,24 @@ static void save_mb(ssl *S, smb *m)
     slice_out *o = S->o;
     size_t M = (size_t)S->f * S->n + m->mb;
     int intra = S_IS_INTRA(m->type), cbp_dc = S->p->cabac ? (m->nnz[24] | m->nnz[25] << 1 | m->nnz[26] << 2) : 0;
+    if (m->type == S_I_PCM) {                            /* R/common/macroblock.c:1245-1255 */
+        m->qp = 0; S->last_dqp = 0; m->cbp_chroma = 2; m->cbp_luma = 0xf; m->t8 = 0; cbp_dc = 7;
+        memset(m->nnz, 16, 24); m->nnz[24] = m->nnz[25] = m->nnz[26] = 1;
+    } else {                                             /* :1268-1272: a macroblock without coefficients has no QP of its own */
+        if (m->type != S_I_16x16 && m->cbp_luma == 0 && m->cbp_chroma == 0) m->qp = S->last_qp;
+        S->last_dqp = m->qp - S->last_qp;
+        S->last_qp = m->qp;
+    }
+    S->prev_mb = m->mb;
+    if (S->cbp) {
+        S->cbp[m->mb] = (i16)(m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma);
+        S->chroma_pm[m->mb] = (int8_t)(intra && m->type != S_I_PCM ? s_fix8c[m->chroma_mode] : 0);
+        S->qp_mb[m->mb] = (int8_t)m->qp;
+        for (int i = 0; i < 16; i++) {
+            const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2), keep = !intra && m->type != S_P_SKIP;
+            S->mvd[(m->mb * 16 + i) * 2] = keep ? m->cmvd[k][0] : 0; S->mvd[(m->mb * 16 + i) * 2 + 1] = keep ? m->cmvd[k][1] : 0;
+        }
+    }
     for (int pl = 0; pl < 3; pl++) {
         int w = pl ? 8 : 16, st = pl ? S->sc : S->sy;
         u8 *rec = S->fdec->plane[pl] + w * m->mby * st + w * m->mbx;
@@ -1264,7 +1530,7 @@ static void save_mb(ssl *S, smb *m)
     o->mb_type[M] = m->type; o->partition[M] = intra || m->type == S_P_SKIP ? S_D_16x16 : m->partition;
     for (int i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = m->type == S_P_8x8 ? m->sub[i] : 0;
     memcpy(o->nnz + M * 27, m->nnz, 27);
-    o->qp[M] = S->qp;
+    o->qp[M] = m->qp;
     o->cbp[M] = m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
     o->t8[M] = m->t8;
     o->i16mode[M] = m->type == S_I_16x16 ? m->i16mode : 0;
@@ -1281,7 +1547,7 @@ static void save_mb(ssl *S, smb *m)
         memset(o->ref + M * 4, -1, 4);
     i16 *ly = o->luma + M * 256, *ldc = o->luma_dc + M * 16, *cdc = o->chroma_dc + M * 8, *cac = o->chroma_ac + M * 128;
     memset(ly, 0, 512); memset(ldc, 0, 32); memset(cdc, 0, 16); memset(cac, 0, 256);
-    if (m->type != S_P_SKIP) {
+    if (m->type != S_P_SKIP && m->type != S_I_PCM) {
         if (m->type == S_I_16x16 && m->nnz[24]) memcpy(ldc, m->dc16, 32);
         if (m->t8) {
             for (int i = 0; i < 4; i++) if ((m->cbp_luma >> i & 1) && m->nnz[4 * i]) memcpy(ly + 64 * i, m->luma8[i], 128);
@@ -1293,15 +1559,74 @@ static void save_mb(ssl *S, smb *m)
 }
 
 /* ------------------------------------------------------------------ the chain */
-int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, const u8 *src_v, slice_out *o)
+/* per-QP tables of the current macroblock: h->quant4_mf[..][qp] etc., the lambdas and the mv / reference cost tables
+ * (x264_mb_analyse_init + x264_mb_analyse_load_costs, R/encoder/analyse.c:220-232,182-218) */
+static void set_mb_qp(ssl *S, smb *m, int qp)
+{
+    const slice_params *p = S->p;
+    if (m) m->qp = qp;
+    if (qp == S->qp && S->cost_mv) return;
+    S->qp = qp;
+    S->qpc = s_chroma_qp[clip3i(qp + (S->lossless ? 0 : S->chroma_qp_offset), 0, 51)];
+    S->lambda = s_lambda_tab[qp]; S->lambda2 = s_lambda2_tab[qp];
+    S->cost_mv = s_load_cost_mv(qp);
+    for (int i = 0; i < 16; i++) S->ref_cost[i] = S->lambda * s_te_size(clip3i((S->n_ref <= 0 ? 1 : S->n_ref) - 1, 0, 2), i);
+    for (int cat = 0; cat < 4; cat++) {
+        x264o_cqm(p->cqm_preset, cat, cat < 2 ? S->qp : S->qpc, 0, S->mf4[cat], S->b4[cat], &S->dq4[cat][0][0]);
+        x264o_cqm_unquant(p->cqm_preset, cat, cat < 2 ? S->qp : S->qpc, 0, S->unq4[cat]);
+    }
+    for (int cat = 0; cat < 2; cat++) {
+        x264o_cqm(p->cqm_preset, cat, S->qp, 1, S->mf8[cat], S->b8[cat], &S->dq8[cat][0][0]);
+        x264o_cqm_unquant(p->cqm_preset, cat, S->qp, 1, S->unq8[cat]);
+    }
+}
+/* x264_adaptive_quant_frame, R/encoder/ratecontrol.c:231-249 (float, compiled like the reference: -ffp-contract=off) */
+static void aq_frame(ssl *S)
+{
+    static const float log2_lut[128] = {
+        0.00000, 0.01123, 0.02237, 0.03342, 0.04439, 0.05528, 0.06609, 0.07682, 0.08746, 0.09803, 0.10852, 0.11894, 0.12928, 0.13955, 0.14975, 0.15987,
+        0.16993, 0.17991, 0.18982, 0.19967, 0.20945, 0.21917, 0.22882, 0.23840, 0.24793, 0.25739, 0.26679, 0.27612, 0.28540, 0.29462, 0.30378, 0.31288,
+        0.32193, 0.33092, 0.33985, 0.34873, 0.35755, 0.36632, 0.37504, 0.38370, 0.39232, 0.40088, 0.40939, 0.41785, 0.42626, 0.43463, 0.44294, 0.45121,
+        0.45943, 0.46761, 0.47573, 0.48382, 0.49185, 0.49985, 0.50779, 0.51570, 0.52356, 0.53138, 0.53916, 0.54689, 0.55459, 0.56224, 0.56986, 0.57743,
+        0.58496, 0.59246, 0.59991, 0.60733, 0.61471, 0.62205, 0.62936, 0.63662, 0.64386, 0.65105, 0.65821, 0.66534, 0.67243, 0.67948, 0.68650, 0.69349,
+        0.70044, 0.70736, 0.71425, 0.72110, 0.72792, 0.73471, 0.74147, 0.74819, 0.75489, 0.76155, 0.76818, 0.77479, 0.78136, 0.78790, 0.79442, 0.80090,
+        0.80735, 0.81378, 0.82018, 0.82655, 0.83289, 0.83920, 0.84549, 0.85175, 0.85798, 0.86419, 0.87036, 0.87652, 0.88264, 0.88874, 0.89482, 0.90087,
+        0.90689, 0.91289, 0.91886, 0.92481, 0.93074, 0.93664, 0.94251, 0.94837, 0.95420, 0.96000, 0.96578, 0.97154, 0.97728, 0.98299, 0.98868, 0.99435};
+    const float strength = S->e->aq_strength * 1.0397;
+    for (int mby = 0; mby < S->mb_h; mby++)
+        for (int mbx = 0; mbx < S->mb_w; mbx++) {
+            uint32_t energy = pixf.var[X264HIP_PIXEL_16x16](S->fenc->plane[0] + 16 * (mbx + mby * S->sy), S->sy)
+                            + pixf.var[X264HIP_PIXEL_8x8](S->fenc->plane[1] + 8 * (mbx + mby * S->sc), S->sc)
+                            + pixf.var[X264HIP_PIXEL_8x8](S->fenc->plane[2] + 8 * (mbx + mby * S->sc), S->sc);
+            if (energy < 1) energy = 1;
+            const int lz = __builtin_clz(energy);
+            S->aq_offset[mbx + mby * S->mb_w] = strength * (log2_lut[(energy << lz >> 24) & 0x7f] - lz + 16.573f);
+        }
+}
+
+static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *src_y, const u8 *src_u, const u8 *src_v, slice_out *o, slice_out2 *o2)
 {
     ssl S;
+    const int b_write = e && e->write;
     sframe *refs[16] = {0};
     int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
     s_setup();
-    if (p->subme > 5 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
+    if (p->subme > 7 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
+    if (p->subme > 5 && (!b_write || !p->cabac || (p->inter & 0x20) || p->qp == 0)) return -3;  /* RD levels: CABAC with the writer in the loop; not yet sub-8x8 / CAVLC / lossless */
+    if (b_write && !p->cabac) return -3;
+    if (e && e->psy_trellis != 0) return -3;
     memset(&S, 0, sizeof(S));
-    S.p = p; S.o = o;
+    S.p = p; S.o = o; S.e = e; S.o2 = o2;
+    S.chroma_qp_offset = p->chroma_qp_offset;
+    S.qp_min = p->cqm_preset ? 6 : 0; S.qp_max = 51;
+    if (e) {                                 /* x264_validate_parameters, R/encoder/encoder.c:493-522 */
+        const float psy = p->subme < 6 ? 0 : e->psy_rd < 0 ? 0 : e->psy_rd > 10 ? 10 : e->psy_rd;
+        S.trellis = p->cabac ? clip3i(e->trellis, 0, 2) : 0;
+        S.psy_rd = (int)(psy * (1 << 8) + .5);
+        if (S.psy_rd) S.chroma_qp_offset -= psy < 0.25 ? 1 : 2;
+        S.chroma_qp_offset = clip3i(S.chroma_qp_offset, -12, 12);
+    }
+    S.mbrd = (p->subme >= 6) + (p->subme >= 8);
     S.lossless = p->qp == 0;                 /* constant QP 0 = lossless (x264_validate_parameters) */
     g_me_lossless = S.lossless;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;
@@ -1310,6 +1635,22 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     S.nnz = calloc(S.n, 27); S.i4mode = calloc(S.n, 16); S.t8 = calloc(S.n, 1);
     S.mvr = calloc((size_t)p->n_refs * S.n * 2, sizeof(i16));
     S.fenc = sframe_new(&S);
+    if (e) {
+        S.cbp = calloc(S.n, sizeof(i16)); S.chroma_pm = calloc(S.n, 1); S.mvd = calloc((size_t)S.n * 32, sizeof(i16)); S.qp_mb = calloc(S.n, 1);
+        S.aq_offset = calloc(S.n, sizeof(float));
+        if (b_write) S.bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
+        {   /* scan position -> raster index, from the scan functions themselves; the trellis weights in scan order (R/common/dct.c:476-483) */
+            static const u16 w4[3] = {800, 320, 128}, w8[6] = {256, 201, 656, 227, 410, 363};
+            static const u8 k8[16] = {0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1};
+            i16 d4[4][4], l4[16], d8[8][8], l8[64];
+            for (int i = 0; i < 16; i++) (&d4[0][0])[i] = (i16)i;
+            zigf[0].scan_4x4(l4, d4);
+            for (int i = 0; i < 16; i++) { S.zz4[i] = (u8)l4[i]; S.w4z[i] = w4[(l4[i] & 1) + ((l4[i] >> 2) & 1)]; }
+            for (int i = 0; i < 64; i++) (&d8[0][0])[i] = (i16)i;
+            zigf[0].scan_8x8(l8, d8);
+            for (int i = 0; i < 64; i++) { S.zz8[i] = (u8)l8[i]; S.w8z[i] = w8[k8[((l8[i] >> 1) & 12) | (l8[i] & 3)]]; }
+        }
+    }
     for (int f = 0; f < p->n_frames; f++) {
         int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
         size_t F = f;
@@ -1329,13 +1670,12 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
         for (int i = 0; i < S.n_ref; i++) S.fref[i] = refs[i];
         S.slice_type = idr ? S_SLICE_I : S_SLICE_P;
         /* CQP: x264_ratecontrol_new / _start, R/encoder/ratecontrol.c:370-373,845-853 (ip_factor 1.4) */
-        S.qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51) : p->qp;
-        S.qpc = s_chroma_qp[clip3i(S.qp + (S.lossless ? 0 : p->chroma_qp_offset), 0, 51)];
-        S.lambda = s_lambda_tab[S.qp]; S.lambda2 = s_lambda2_tab[S.qp];
-        S.cost_mv = s_load_cost_mv(S.qp);
-        for (int i = 0; i < 16; i++) S.ref_cost[i] = S.lambda * s_te_size(clip3i((S.n_ref <= 0 ? 1 : S.n_ref) - 1, 0, 2), i);
-        for (int cat = 0; cat < 4; cat++) x264o_cqm(p->cqm_preset, cat, cat < 2 ? S.qp : S.qpc, 0, S.mf4[cat], S.b4[cat], &S.dq4[cat][0][0]);
-        for (int cat = 0; cat < 2; cat++) x264o_cqm(p->cqm_preset, cat, S.qp, 1, S.mf8[cat], S.b8[cat], &S.dq8[cat][0][0]);
+        S.frame_qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51) : p->qp;
+        S.f_qpm = (float)S.frame_qp;                      /* rc->f_qpm = q, ratecontrol.c:868 (constant QP: an integer) */
+        S.cost_mv = 0;
+        set_mb_qp(&S, 0, S.frame_qp);
+        const int b_aq = e && e->aq_mode > 0 && e->aq_strength != 0;
+        if (b_aq) aq_frame(&S);
         /* x264_macroblock_slice_init, R/common/macroblock.c:771-808 */
         S.fdec->n_ref0 = S.n_ref;
         for (int i = 0; i < S.n_ref; i++) {
@@ -1344,15 +1684,59 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
             S.fdec->inv_ref_poc[i] = (256 + delta / 2) / delta;
         }
         S.intra_count = 0; S.stat_intra = S.stat_inter = S.stat_n = 0;
-        o->frame_info[4 * F] = S.slice_type; o->frame_info[4 * F + 1] = S.qp; o->frame_info[4 * F + 2] = S.n_ref;
+        S.last_qp = S.frame_qp; S.last_dqp = 0; S.i_skip = 0;
+        if (b_write) {                                    /* x264_slice_write, R/encoder/encoder.c:1155-1165 */
+            memset(S.bsbuf, 0, 64 + (size_t)e->payload_cap + 4096);
+            cb_context_init(&S.cb, S.slice_type, S.frame_qp, clip3i(e->cabac_init_idc, 0, 2));
+            cb_encode_init(&S.cb, S.bsbuf + 64, S.bsbuf + 64 + e->payload_cap + 4096);
+            S.cb.i_frame = f;
+        }
+        o->frame_info[4 * F] = S.slice_type; o->frame_info[4 * F + 1] = S.frame_qp; o->frame_info[4 * F + 2] = S.n_ref;
         o->frame_info[4 * F + 3] = S.fdec->poc;
         for (int mb = 0; mb < S.n; mb++) {
             smb m;
+            panalysis A;
             load_mb(&S, &m, mb % S.mb_w, mb / S.mb_w);
-            analyse_mb(&S, &m);
-            update_mb(&S, &m);
+            /* x264_ratecontrol_qp + x264_adaptive_quant, R/encoder/analyse.c:2162-2164, ratecontrol.c:257-265 */
+            int qp = S.frame_qp;
+            if (b_aq) {
+                qp = clip3i((int)(S.f_qpm + S.aq_offset[mb] + .5), S.qp_min, S.qp_max);
+                if (abs(qp - S.last_qp) == 1) qp = S.last_qp;
+            }
+            set_mb_qp(&S, &m, qp);
+            /* x264_mb_analyse_init, analyse.c:235-252 */
+            S.b_trellis = S.trellis > 1 && S.mbrd;
+            m.skip_intra = S.lossless ? 0 : S.mbrd ? 2 : !S.trellis && !p->noise_reduction;
+            memset(&A, 0, sizeof(A));
+            analyse_mb(&S, &m, &A);
+            if (S.mbrd) update_cache(&S, &m, &A);          /* :2763 */
+            else update_mb(&S, &m);
+            S.b_trellis = S.trellis;                       /* :2768-2773 */
+            if (S.b_trellis == 1 || p->noise_reduction) m.skip_intra = 0;
             encode_mb(&S, &m);
+            if (b_write) {                                 /* encoder.c:1192-1205 */
+                if (mb > 0) cb_encode_terminal(&S.cb);
+                if (m.type == S_P_SKIP) cw_mb_skip(&S, &S.cb, &m, 1);
+                else {
+                    if (S.slice_type != S_SLICE_I) cw_mb_skip(&S, &S.cb, &m, 0);
+                    if (!S_IS_INTRA(m.type)) for (int i = 0; i < 16; i++) {   /* the cache as x264_analyse_update_cache leaves it */
+                        const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2);
+                        m.cmv[k][0] = m.mv4[i][0]; m.cmv[k][1] = m.mv4[i][1]; m.cref[k] = m.ref8[(i >> 3) * 2 + ((i & 3) >> 1)];
+                    }
+                    cw_macroblock(&S, &S.cb, 0, &m);
+                }
+                o2->mb_bits[F * S.n + mb] = cb_pos(&S.cb);
+                if (o2->mb_bits[F * S.n + mb] / 8 + 2048 > e->payload_cap) return -5;
+            }
             save_mb(&S, &m);
+            if (o2) o2->qp_offset[F * S.n + mb] = b_aq ? S.aq_offset[mb] : 0;
+        }
+        if (b_write) {                                     /* encoder.c:1269-1273 */
+            cb_encode_flush(&S.cb, f);
+            const int len = (int)(S.cb.p - (S.bsbuf + 64));
+            if (len > e->payload_cap) return -5;
+            o2->payload_len[F] = len;
+            memcpy(o2->payload + F * e->payload_cap, S.bsbuf + 64, len);
         }
         if (p->noise_reduction) nr_update(&S);
         o->stat[4 * F] = S.stat_intra; o->stat[4 * F + 1] = S.stat_inter; o->stat[4 * F + 2] = S.stat_n; o->stat[4 * F + 3] = 0;
@@ -1366,7 +1750,7 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
                 memcpy(nz + mb * 26, S.nnz + mb * 27, 24); nz[mb * 26 + 24] = S.nnz[mb * 27 + 25]; nz[mb * 26 + 25] = S.nnz[mb * 27 + 26];
             }
             x264o_frame_deblock(S.fdec->plane[0], S.fdec->plane[1], S.fdec->plane[2], S.mb_w, S.mb_h, S.sy, S.sc, t, q, nz, t8,
-                                S.fdec->mv, S.fdec->ref, p->alpha_c0, p->beta, p->chroma_qp_offset);
+                                S.fdec->mv, S.fdec->ref, p->alpha_c0, p->beta, S.chroma_qp_offset);
             free(t); free(q); free(t8); free(nz);
         }
         x264o_plane_expand_border(S.fdec->plane[0], S.sy, S.w16, S.h16, 32, 32);
@@ -1386,5 +1770,15 @@ int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, 
     for (int i = 0; i < n_avail; i++) sframe_free(refs[i]);
     sframe_free(S.fenc);
     free(S.nnz); free(S.i4mode); free(S.t8); free(S.mvr);
+    free(S.cbp); free(S.chroma_pm); free(S.mvd); free(S.qp_mb); free(S.aq_offset); free(S.bsbuf);
     return 0;
+}
+
+int x264o_encode_chain(const slice_params *p, const u8 *src_y, const u8 *src_u, const u8 *src_v, slice_out *o)
+{
+    return s_encode_chain(p, 0, src_y, src_u, src_v, o, 0);
+}
+int x264o_encode_chain2(const slice_params *p, const slice_ext *e, const u8 *src_y, const u8 *src_u, const u8 *src_v, slice_out *o, slice_out2 *o2)
+{
+    return s_encode_chain(p, e, src_y, src_u, src_v, o, o2);
 }

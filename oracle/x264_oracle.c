@@ -763,6 +763,18 @@ void x264o_cqm(int preset, int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *
             for (int i = 0; i < n; i++)
                 dequant[k * n + i] = (is8x8 ? base_dq8[k][cls8(i)] : base_dq4[k][cls4(i)]) * (list ? list[i] : 16);
 }
+/* h->unquant4_mf / unquant8_mf (R/common/set.c:146,158): the inverse of the quantiser multiplier before its qp/6 shift, used by trellis */
+void x264o_cqm_unquant(int preset, int cat, int qp, int is8x8, int *unq)
+{
+    int n = is8x8 ? 64 : 16;
+    const u8 *list = !preset ? 0 : is8x8 ? (cat & 1 ? jvt8p : jvt8i) : (cat & 1 ? jvt4p : jvt4i);
+    for (int i = 0; i < n; i++) {
+        int w = list ? list[i] : 16;
+        int q = is8x8 ? base_q8[qp % 6][cls8(i)] : base_q4[qp % 6][cls4(i)];
+        q = (q * 16 + (w >> 1)) / w;
+        unq[i] = (int)((1ULL << (qp / 6 + (is8x8 ? 16 : 15) + 8)) / q);
+    }
+}
 void x264o_cqm_flat(int cat, int qp, int is8x8, u16 *mf, u16 *bias, int *dequant) { x264o_cqm(0, cat, qp, is8x8, mf, bias, dequant); }
 
 /* ======================================================================

@@ -93,8 +93,25 @@ typedef struct { int64_t score; int lv; u8 st[10]; } tnode;
 
 /* quant_trellis_cabac, rdo.c:411-628.  dct is in raster order, zz maps scan position -> raster index;
  * dc: the block is a DC block (one multiplier, weight 256); b_ac: scan position 0 is not part of it.     */
+static int trellis_quant_twin(const ssl *S, i16 *dct, const u16 *mf, const int *unq, const int *weight, const u8 *zz,
+                              int cat, int lambda2, int b_ac, int dc, int n_coef);
 static int trellis_quant(const ssl *S, i16 *dct, const u16 *mf, const int *unq, const int *weight, const u8 *zz,
                          int cat, int lambda2, int b_ac, int dc, int n_coef)
+{
+#ifdef X264O_DEVCHECK
+    i16 copy[64];
+    memcpy(copy, dct, n_coef * sizeof(i16));
+    const int r2 = devhost_trellis(copy, mf, unq, weight, zz, S->cb.state, cat, lambda2, b_ac, dc, n_coef);
+    const int r1 = trellis_quant_twin(S, dct, mf, unq, weight, zz, cat, lambda2, b_ac, dc, n_coef);
+    g_devcheck_calls++;
+    if (r1 != r2 || memcmp(copy, dct, n_coef * sizeof(i16))) { if (!g_devcheck_bad) fprintf(stderr, "devcheck: trellis differs (cat %d, n %d)\n", cat, n_coef); g_devcheck_bad++; }
+    return r1;
+#else
+    return trellis_quant_twin(S, dct, mf, unq, weight, zz, cat, lambda2, b_ac, dc, n_coef);
+#endif
+}
+static int trellis_quant_twin(const ssl *S, i16 *dct, const u16 *mf, const int *unq, const int *weight, const u8 *zz,
+                              int cat, int lambda2, int b_ac, int dc, int n_coef)
 {
     int abs_c[64], sgn[64];
     tnode nodes[2][8], *cur = nodes[0], *prev = nodes[1];

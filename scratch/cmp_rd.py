@@ -51,7 +51,7 @@ if __name__ == "__main__":
             run_case(ora, *c)
     else:
         nbad = 0
-        for size in ((208, 144), (200, 120), (64, 48)):
+        for size in ((208, 144), (200, 120), (96, 80)):
             for qp in (10, 18, 26, 34, 44):
                 for subme in (5, 6, 7):
                     for ekw in (dict(), dict(psy_rd=1.0), dict(trellis=1, psy_rd=1.0), dict(trellis=2, psy_rd=0.0), dict(trellis=1, psy_rd=1.0, aq_mode=1),
@@ -59,5 +59,9 @@ if __name__ == "__main__":
                         for clipf in (rs.clip, static_clip):
                             for var in (dict(), dict(n_refs=1, mixed_refs=0), dict(transform8x8=0, inter=0x11, intra=0x1), dict(me_method=2, dct_decimate=0, fast_pskip=0)):
                                 kw = dict(base); kw.update(var); kw.update(qp=qp, subme=subme)
-                                nbad += bool(run_case(ora, size, 4, clipf, kw, ekw, verbose=False))
+                                bad = run_case(ora, size, 4, clipf, kw, ekw, verbose=False)
+                                if bad:
+                                    nbad += 1
+                                    print("DIFF", size, kw, ekw, clipf.__name__, bad[:3], flush=True)
+            print("done", size, qp, "bad so far", nbad, flush=True)
         print("configurations with differences:", nbad)

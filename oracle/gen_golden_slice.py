@@ -47,6 +47,24 @@ CASES = [
 ]
 
 
+# round 2: chains through refslice_encode_chain2 -- the entropy writer in the loop (payload bytes in the fixture), the RD levels
+# (subme 6 / 7), trellis, psy-rd, adaptive quantisation.  (name, size, frames, clip kind, parameters, ext parameters)
+MED = dict(me_method=rs.ME_HEX, n_refs=3, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
+CASES2 = [
+    ("w_medium_ip", (208, 144), 4, "static", dict(qp=26, subme=5, **MED), dict()),                          # the round-1 medium-like chain, now with its payload
+    ("rd6", (208, 144), 4, "moving", dict(qp=28, subme=6, **MED), dict()),
+    ("rd7_psy", (208, 144), 4, "static", dict(qp=26, subme=7, **MED), dict(psy_rd=1.0)),
+    ("rd7_trellis1", (208, 144), 5, "moving", dict(qp=24, subme=7, **MED), dict(trellis=1, psy_rd=1.0)),      # the medium preset's analysis options at constant QP
+    ("rd7_trellis2", (200, 120), 4, "static", dict(qp=30, subme=7, **MED), dict(trellis=2, psy_rd=0.0)),      # psy-rd off: the I_PCM decision is live
+    ("rd7_aq", (208, 144), 5, "moving", dict(qp=26, subme=7, **MED), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0)),   # per-macroblock QP
+    ("rd7_umh_1ref", (200, 120), 4, "moving", dict(qp=34, subme=7, me_method=rs.ME_UMH, n_refs=1, inter=0x11, intra=0x1, cabac=1, deblock=1),
+     dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.5)),
+    ("t1_subme4", (200, 120), 4, "moving", dict(qp=30, subme=4, me_method=rs.ME_HEX, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, cabac=1, deblock=1),
+     dict(trellis=1)),                                                                                       # trellis without the RD levels: every intra block is coded again
+    ("rd7_lowqp", (96, 80), 3, "moving", dict(qp=8, subme=7, **MED), dict(trellis=2, psy_rd=0.0)),            # long levels: the escape codes of the level coding
+]
+
+
 def static_clip(w, h, n):
     """Synthetic clip whose background is frozen at frame 0 outside a moving window (P_SKIP territory)."""
     y, u, v = rs.clip(w, h, n)
@@ -74,8 +92,24 @@ def masked(a):
     return a
 
 
+def masked2(a):
+    a = masked(a)
+    a.pop("mb_bits", None)                   # a debugging aid of the harness, not part of the fixture
+    return a
+
+
 def main():
     only = sys.argv[1:]                      # optional: regenerate just the named chains
+    for name, size, frames, kind, kw, ekw in CASES2:
+        if only and name not in only:
+            continue
+        p = rs.make_params(size[0], size[1], frames, **kw)
+        y, u, v = case_inputs(size, frames, kind)
+        a = masked2(rs.run_reference2(p, rs.make_ext(**ekw), y, u, v))
+        path = os.path.join(GOLDEN, "slice2_%s.npz" % name)
+        np.savez_compressed(path, **a)
+        types = [np.bincount(a["mb_type"][f], minlength=7).tolist() for f in range(frames)]
+        print("%s: %d bytes, payload %s, types per frame (I4 I8 I16 PCM P P8 skip) %s" % (path, os.path.getsize(path), a["payload_len"].tolist(), types))
     for name, size, frames, kind, kw in CASES:
         if only and name not in only:
             continue

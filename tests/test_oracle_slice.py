@@ -10,7 +10,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import refslice as rs
-from oracle.gen_golden_slice import CASES, case_inputs, masked
+from oracle.gen_golden_slice import CASES, CASES2, case_inputs, masked, masked2
 
 
 def load_case(name):
@@ -41,3 +41,28 @@ def test_sweep_twin_matches_reference_loop(oracle_lib, name, size, frames, kind,
         assert (want["mb_type"] == rs.I_8x8).any() and want["t8"][1:].any()
     if kw.get("n_refs", 1) > 1:
         assert (want["ref"] > 0).any()
+
+
+def load_case2(name):
+    with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", CASES2, ids=[c[0] for c in CASES2])
+def test_twin_with_entropy_writer_matches_reference_loop(oracle_lib, name, size, frames, kind, kw, ekw):
+    """Round 2: the reference's loop with x264_macroblock_write_cabac in it (so the RD levels, trellis, psy-rd and adaptive
+    quantisation see the coder state they see in the encoder) against the twin: every array as above AND the slice payload bytes."""
+    want = load_case2(name)
+    p = rs.make_params(size[0], size[1], frames, **kw)
+    y, u, v = case_inputs(size, frames, kind)
+    got = masked2(rs.run2(oracle_lib, "x264o_encode_chain2", p, rs.make_ext(**ekw), y, u, v))
+    n = want["payload_len"]
+    assert np.array_equal(got["payload_len"], n)
+    for f in range(frames):
+        assert np.array_equal(got["payload"][f, :n[f]], want["payload"][f, :n[f]]), "payload of frame %d differs" % f
+    assert_same({k: v for k, v in got.items() if k != "payload"}, {k: v for k, v in want.items() if k != "payload"})
+    assert (n > 16).all()
+    if ekw.get("aq_mode"):
+        assert len(np.unique(want["qp"][1])) > 2 and np.abs(want["qp_offset"]).max() > 0.5
+    if kw["subme"] >= 6:
+        assert (want["mb_type"][1:] == rs.P_8x8).any() or (want["mb_type"][1:] == rs.P_L0).any()

@@ -137,7 +137,15 @@ int x264hip_lookahead_intra_frame(x264hip_frame_ctx *c, const x264hip_picture *p
 /* AQ energy: pixf.var of Y 16x16 and U,V 8x8 per macroblock
  * (x264_adaptive_quant_frame's ac_energy_mb, R/encoder/ratecontrol.c:171-195).
  * out[mb] = var16(Y) + var8(U) + var8(V)                                    */
+/* Host tables with floating-point arithmetic in the reference, built in C with its expression (no GPU involved):
+ * p_cost_mv for one lambda (R/encoder/analyse.c:182-198), out[2 * span + 1] centred at span; h->unquant4_mf / unquant8_mf
+ * (R/common/set.c:146,158) for every QP from the unshifted multipliers quant_mf6 [n_cat][6][n] -> out [n_cat][52][n]. */
+void x264hip_cost_mv_table(int lambda, int span, int16_t *out);
+void x264hip_unquant_table(const int32_t *quant_mf6, int n_cat, int n, int32_t *out);
 int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, int32_t *out_dev);
+/* x264_adaptive_quant_frame (R/encoder/ratecontrol.c:231-249): fenc->f_qp_offset[batch][n_mb] (float, device) from the energies
+ * above; aq_strength = param.rc.f_aq_strength.  energy_dev: scratch [batch][n_mb] int32. */
+int x264hip_adaptive_quant_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, float aq_strength, int32_t *energy_dev, float *offset_dev);
 /* x264_pixel_ssd_wxh over the three planes (PSNR, R/encoder/encoder.c:1034-1045) */
 int x264hip_ssd_frame(x264hip_frame_ctx *c, const x264hip_picture *a, const x264hip_picture *b, int64_t ssd_host[3]);
 /* same, stream-ordered with the three sums left in device memory (no host sync) */
@@ -227,8 +235,38 @@ typedef struct {
     int32_t *cost_intra_alt;                           /* scratch of the sweep: b_fast_intra's raster-order term, settled after the frame */
     int32_t *progress;     /* [batch][mb_h] + abort flag: the sweep's row counters */
     int poc, n_ref0, inv_ref_poc[8];                   /* x264_frame_t.i_poc / i_ref[0] / inv_ref_poc, filled by the sweep */
+    int16_t *mvd;          /* [n][16][2] h->mb.mvd[0] (CABAC contexts of the row below; raster variant only) */
 } x264hip_mb_state;
 
+/* ---- round 2: the raster-order variant of the sweep ------------------------------------------------
+ * With the RD levels (subme >= 6: every trial encode is priced against the LIVE CABAC contexts, R/encoder/rdo.c:62,139-171),
+ * trellis quantisation (rdo.c:475-493) or adaptive quantisation (a macroblock's QP follows from the previous one's,
+ * R/encoder/ratecontrol.c:263-264) a slice is one serial chain of macroblocks.  When x264hip_slice_params.rd is set, one
+ * wavefront owns a whole frame of one chain of the batch and walks it in raster order, and the entropy coder runs inside the
+ * loop exactly where x264_slice_write has it (R/encoder/encoder.c:1155-1165,1192-1205,1269-1273): the launch also returns every
+ * chain's slice_data() bytes.  Throughput then comes from the number of chains in flight (the batch), not from a wavefront
+ * schedule inside the frame.  I and P slices, CABAC; sub-8x8 partitions, psy-trellis and subme >= 8 are refused.        */
+typedef struct x264hip_slice_rd {
+    int trellis;                   /* param.analyse.i_trellis 0..2 */
+    int psy_rd;                    /* h->mb.i_psy_rd = FIX8(param.analyse.f_psy_rd) (0 below subme 6); the caller lowers chroma_qp_offset
+                                      as x264_validate_parameters does (R/encoder/encoder.c:509-514) */
+    int write;                     /* 1: x264_macroblock_write_cabac after every macroblock (required for subme >= 6 / trellis) */
+    int cabac_init_idc;            /* param.i_cabac_init_idc */
+    int i_frame;                   /* frames coded before this one (x264_cabac_encode_flush's padding bit, R/common/cabac.c:918) */
+    int qp_min, qp_max;            /* param.rc.i_qp_min / i_qp_max (adaptive quantisation clips to them) */
+    float f_qpm;                   /* rc->f_qpm: the frame's QP before the per-macroblock offset */
+    const float *aq_offset;        /* device [batch][n_mb]: fenc->f_qp_offset (x264_adaptive_quant_frame), or NULL = no AQ */
+    const int16_t *cost_mv_all;    /* device [52][2 * cost_mv_range + 1]: p_cost_mv of every QP (needed with aq_offset) */
+    const int32_t *unquant4_mf;    /* device [4][52][16]  h->unquant4_mf (trellis) */
+    const int32_t *unquant8_mf;    /* device [2][52][64]  h->unquant8_mf */
+    uint8_t *payload;              /* device [batch][payload_cap]: every chain's slice_data() starts 64 bytes into its slot */
+    int payload_cap;
+    int32_t *payload_len;          /* device [batch] */
+    int32_t *mb_bits;              /* optional device [batch][n_mb]: x264_cabac_pos after every macroblock */
+} x264hip_slice_rd;
+#define X264HIP_PAYLOAD_LEAD 64
+
+struct x264hip_slice_rd;
 typedef struct {
     int slice_type;                    /* 0 = SLICE_TYPE_P, 2 = SLICE_TYPE_I (R/common/common.h:128-134) */
     int qp, chroma_qp_offset;
@@ -251,6 +289,7 @@ typedef struct {
      * itself in zigzag order as levels, SAD for every comparison, no transform-size analysis.  The caller applies the rest of
      * x264_validate_parameters: qp 0 for every slice, chroma_qp_offset 0, fast_pskip 0, noise_reduction 0, 8x8dct only with CABAC */
     int lossless;
+    const struct x264hip_slice_rd *rd;   /* NULL: the wavefront schedule of round 1; set: the raster-order variant (below) */
 } x264hip_slice_params;
 
 /* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:

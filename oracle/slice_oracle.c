@@ -1476,6 +1476,7 @@ static void update_mb(ssl *S, smb *m)
 static void encode_mb(ssl *S, smb *m)
 {
     m->cbp_luma = 0; m->nnz[24] = 0;
+    if (m->type == S_I_PCM) return;          /* the reference runs its inter branch on nothing here (no list is active); the writer stores the source */
     if (m->type == S_P_SKIP) {
         if (!m->skip_mc) {
             int mvx = m->mv4[0][0], mvy = m->mv4[0][1];          /* h->mb.cache.mv[0][x264_scan8[0]], macroblock.c:380-383 */
@@ -1551,7 +1552,7 @@ static void save_mb(ssl *S, smb *m)
     int intra = S_IS_INTRA(m->type), cbp_dc = S->p->cabac ? (m->nnz[24] | m->nnz[25] << 1 | m->nnz[26] << 2) : 0;
     if (m->type == S_I_PCM) {                            /* R/common/macroblock.c:1245-1255 */
         m->qp = 0; S->last_dqp = 0; m->cbp_chroma = 2; m->cbp_luma = 0xf; m->t8 = 0; cbp_dc = 7;
-        memset(m->nnz, 16, 24); m->nnz[24] = m->nnz[25] = m->nnz[26] = 1;
+        memset(m->nnz, 16, 27);                           /* the harness reports 16 for every entry of an I_PCM macroblock */
     } else {                                             /* :1268-1272: a macroblock without coefficients has no QP of its own */
         if (m->type != S_I_16x16 && m->cbp_luma == 0 && m->cbp_chroma == 0) m->qp = S->last_qp;
         S->last_dqp = m->qp - S->last_qp;

@@ -30,6 +30,7 @@
 #include "me_exact.h"
 #include "intra_pred.h"
 #include "frame_internal.h"
+#include "trellis_dev.h"
 
 using namespace x264hip;
 
@@ -49,7 +50,7 @@ struct SwRefs {
     const u8 *u[SW_MAX_REFS], *v[SW_MAX_REFS];
     // everything indexed by a run-time reference number lives here, in the argument the kernel never writes: SwArgs is adjusted per
     // chain at the top of the kernel, and a modified argument struct with a dynamically indexed member is kept in scratch memory whole
-    int ref_cost[SW_MAX_REFS], poc_delta[SW_MAX_REFS], l0_inv_ref_poc[SW_MAX_REFS];
+    int ref_bits[SW_MAX_REFS], poc_delta[SW_MAX_REFS], l0_inv_ref_poc[SW_MAX_REFS];   // REF_COST = lambda * ref_bits (bs_size_te, R/encoder/analyse.c:195-197)
 };
 struct SwArgs {
     int mb_w, mb_h, sy, sc, batch, batch_pad;
@@ -80,6 +81,10 @@ struct SwArgs {
     u32 *nr_sum, *nr_count;     // [batch][2][64], [batch][2]
     const u16 *nr_offset;       // [batch][2][64]
 };
+
+// the macroblock's QP and what follows from it (x264_mb_analyse_init, R/encoder/analyse.c:227-230): one set per slice at constant
+// QP, per macroblock with adaptive quantisation
+struct SwQp { int qp, qpc, lambda, lambda2, skip_thresh; };
 
 struct SwLds {
     __attribute__((aligned(16))) u8 fe[384];   // source: Y 16x16 | U 8x8 | V 8x8
@@ -120,6 +125,56 @@ struct SwLds {
     int qdq[4][16];
     i16 costl[2 * MX_COST_LDS + 2];
 };
+
+// ---- round 2: what the raster-order variant of the sweep (RD levels, trellis, adaptive quantisation, the entropy coder) adds ----
+struct SwRd {                       // kernel argument
+    int on;                         // this launch is the raster variant
+    int mbrd, trellis, psy_rd;      // a->i_mbrd, param.analyse.i_trellis, h->mb.i_psy_rd
+    int write, cabac_init_idc, i_frame;
+    int aq, qp_min, qp_max, chroma_qp_offset;
+    float f_qpm;
+    const float *aq_offset;         // [batch][n_mb]
+    const i16 *cost_mv_all;         // [52][2 * cost_center + 1]: p_cost_mv of every QP
+    const int *unq4, *unq8;         // h->unquant4_mf [4][52][16], h->unquant8_mf [2][52][64]
+    u8 *payload; int payload_cap; int *payload_len, *mb_bits;
+    i16 *mvd;                       // h->mb.mvd[0]: [batch][n_mb][16][2]
+};
+struct SwLdsRd {
+    u8 cabac[460], cabac_tmp[460];  // h->cabac.state and the RD trial's copy (COPY_CABAC, R/encoder/rdo.c:62)
+    // what the entropy coder reads beyond SwLds (MbSynDev below points into both)
+    signed char cref[48], sub[4];
+    i16 cmv[48][2], cmvd[48][2];
+    u8 nz_l[4], nz_t[4], nz_lc[2][2], nz_tc[2][2];
+    i16 i4_dct[256], i8_dct[256];   // h->mb.pic.i4x4_dct_buf / i8x8_dct_buf (i_skip_intra == 2)
+    int fenc_satd[16], fenc_sa8d[4];   // h->mb.pic.fenc_satd / fenc_sa8d (psy-RD)
+    int unq4[4][16], unq8[2][64];   // unquant rows of the current QPs
+    i16 left_mvd[4][2];             // the left macroblock's mvd of blocks 3, 7, 11, 15
+    u8 left_nz[8];                  // its non_zero_count of blocks 5 7 13 15 | U 1 3 | V 1 3
+    u8 zero16[16];                  // sixteen zeros (SATD / SA8D of the source against nothing)
+    int tmp_i[4];                   // lane 0 -> wave: bit count / QP after the writer
+    TrellisScratch ts;
+};
+struct SwLdsNone { int unused; };
+// the record cabac_dev.h's writer walks (same member names as MbSyn): scalars in registers, arrays where the kernel keeps them in LDS
+struct MbSynDev {
+    int slice_type, type, partition, i16mode, chroma_mode, cbp_luma, cbp_chroma, t8, qp, n_ref, pps_t8, t8_allowed;
+    int type_left, type_top, cbp_left, cbp_top, cpm_left, cpm_top, nb_t8, last_qp, last_dqp, prev_coded;
+    signed char *sub, *i4c, *cref;
+    i16 (*cmv)[2], (*cmvd)[2];
+    u8 *nnz, *nz_l, *nz_t;
+    u8 (*nz_lc)[2], (*nz_tc)[2];
+    i16 (*lv4)[16], (*lv8)[64], *lv_dc, (*lv_cdc)[4], (*lv_cac)[16];
+};
+// trellis context handed to the quantising helpers: on = 0 -> plain dead-zone quantisation
+struct SwTq { int on; SwLdsRd *r; };
+// x264_dct4_weight2_zigzag[0] / x264_dct8_weight2_zigzag[0] (R/common/dct.c:476-483) and x264_zigzag_scan4[0]
+static __device__ const int d_w4z[16] = {800, 320, 320, 800, 128, 800, 320, 320, 320, 320, 128, 800, 128, 320, 320, 128};
+static __device__ const u8 d_zz4[16] = {0, 4, 1, 2, 5, 8, 12, 9, 6, 3, 7, 10, 13, 14, 11, 15};
+static __device__ const u8 d_zz2[4] = {0, 1, 2, 3};
+static __device__ const u16 d_w8k[6] = {256, 201, 656, 227, 410, 363};
+static __device__ const u8 d_w8cls[16] = {0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1};
+__device__ __forceinline__ int sw_w8z(int pos) { const int r = c_scan8[0][pos]; return d_w8k[d_w8cls[((r >> 1) & 12) | (r & 3)]]; }
+struct SwW8 { __device__ __forceinline__ int operator[](int pos) const { return sw_w8z(pos); } };
 
 // lanes exchange data through LDS only: order LDS traffic (lgkmcnt) and leave global loads / stores in flight
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_wave_barrier(); \
@@ -330,8 +385,9 @@ __device__ __forceinline__ int sw_denoise(int v, int off, int &la)
     level -= off;
     return level < 0 ? 0 : (level ^ sign) - sign;
 }
-__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
+__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
 {
+    i16 c[16], lv[16];
     if (lane < 16) {
         int bx, by, r[16];
         sw_blk_xy(lane, bx, by);
@@ -340,7 +396,6 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int ca
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 r[4 * j + i] = (int)s.fe[(by + j) * 16 + bx + i] - (int)s.fd[FDY + (by + j) * FD + bx + i];
-        i16 c[16], lv[16];
         fwd4x4(c, r);
         if (nr_acc4 && nr_on) {
             // --nr: every coefficient but the first of every block, and the sum of magnitudes per coefficient index over the 16
@@ -354,11 +409,31 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, int ca
             }
         }
         if (dc_out) { s.dc16[(by >> 2) * 4 + (bx >> 2)] = c[0]; c[0] = 0; }
+        if (tq.on) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s.coef[lane][i] = c[i];
+        }
+    }
+    if (tq.on) {
+        // x264_quant_4x4_trellis (R/encoder/rdo.c:641-650): a serial dynamic programme per block, walked by one lane
+        WAVE_SYNC();
+        if (lane == 0)
+            for (int b = 0; b < 16; b++)
+                td_trellis_quant(tq.r->ts, &s.coef[b][0], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz4, tq.r->cabac, dc_out ? 1 : 2,
+                                 d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16);
+        WAVE_SYNC();
+    }
+    if (lane < 16) {
         const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
         const int *dq = s.qdq[cat];
-        int nz = 0, bits = a.qp / 6 - 4;
+        int nz = 0, bits = Q.qp / 6 - 4;
+        if (tq.on) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+            for (int i = 0; i < 16; i++) { c[i] = s.coef[lane][i]; nz |= c[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+        }
         SCAN4_FRAME(lv, c);
         u32 nzm, big;
         LEVEL_MASKS(lv, nzm, big);
@@ -389,10 +464,10 @@ __device__ __forceinline__ void sw_ll_i8x8(SwLds &s, int idx, int &cbp_luma, int
 __device__ __forceinline__ int sw_ll_luma16(SwLds &s, bool dc_out, int lane);
 __device__ __forceinline__ int sw_ll_chroma(SwLds &s, int lane);
 // x264_macroblock_encode's inter 4x4-transform branch; returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
+__device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
 {
     if (a.lossless) return sw_ll_luma16(s, false, lane);
-    sw_luma4x4_fwd(s, a, 1, false, lane, nr_acc4, nr_on);
+    sw_luma4x4_fwd(s, a, Q, tq, 1, false, lane, nr_acc4, nr_on);
     if (lane == 0) {
         int cbp = 0, dec_mb = 0;
         for (int i8 = 0; i8 < 4; i8++) {
@@ -417,10 +492,10 @@ __device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, i
     return keep;
 }
 // x264_mb_encode_i16x16 (prediction already in s.fd); returns cbp_luma, fills s.nnz[0..15], s.nnz[24]
-__device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int lane)
+__device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int lane)
 {
     if (a.lossless) return sw_ll_luma16(s, true, lane);
-    sw_luma4x4_fwd(s, a, 0, true, lane);
+    sw_luma4x4_fwd(s, a, Q, tq, 0, true, lane);
     if (lane == 0) {
         const int b_decimate = a.dct_decimate && a.slice_type == 0;
         int score = b_decimate ? 0 : 9, cbp = 0;
@@ -446,7 +521,14 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
         }
         const int mf = (int)s.qmf[0][0] >> 1, bias = (int)s.qbias[0][0] << 1;
         int nz = 0;
-        for (int i = 0; i < 16; i++) { int q = quant_one(d[i], mf, bias); d[i] = (i16)q; nz |= q; }
+        if (tq.on) {                                   // x264_quant_dc_trellis( .., DCT_LUMA_DC, 1 ), macroblock.c:247-248
+#pragma unroll
+            for (int i = 0; i < 16; i++) s.dc16[i] = d[i];
+            nz = td_trellis_quant(tq.r->ts, &s.dc16[0], s.qmf[0], tq.r->unq4[0], d_w4z, d_zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16);
+#pragma unroll
+            for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
+        } else
+            for (int i = 0; i < 16; i++) { int q = quant_one(d[i], mf, bias); d[i] = (i16)q; nz |= q; }
         s.nnz[24] = (u8)(nz != 0);
         if (nz) {
             { i16 lvd[16]; SCAN4_FRAME(lvd, d);
@@ -460,7 +542,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
                 int p = t[4 * r] + t[4 * r + 1], q = t[4 * r] - t[4 * r + 1], u = t[4 * r + 2] + t[4 * r + 3], w = t[4 * r + 2] - t[4 * r + 3];
                 d[4 * r] = (i16)(p + u); d[4 * r + 1] = (i16)(p - u); d[4 * r + 2] = (i16)(q - w); d[4 * r + 3] = (i16)(q + w);
             }
-            const int m = s.qdq[0][0], bits = a.qp / 6 - 6;
+            const int m = s.qdq[0][0], bits = Q.qp / 6 - 6;
             for (int i = 0; i < 16; i++) s.dc16[i] = (i16)dequant_one(d[i], m, bits);
         }
         s.keep8 = cbp; s.nzdc16 = nz != 0;
@@ -486,11 +568,12 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, int l
     return keep;
 }
 // x264_mb_encode_8x8_chroma; returns cbp_chroma, fills s.nnz[16..23], s.nnz[25..26]
-__device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b_inter, int lane)
+__device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int b_inter, int lane)
 {
     if (a.lossless) return sw_ll_chroma(s, lane);
     const int cat = 2 + b_inter, b_decimate = b_inter && a.dct_decimate;
     const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
+    i16 c[16], lv[16];
     if (lane < 8) {
         int ch = lane >> 2, i4 = lane & 3, bx = (i4 & 1) * 4, by = (i4 >> 1) * 4, r[16];
         const u8 *fe = s.fe + 256 + 64 * ch, *pr = s.fd + (ch ? FDV : FDU);
@@ -499,14 +582,31 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 r[4 * j + i] = (int)fe[(by + j) * 8 + bx + i] - (int)pr[(by + j) * FD + bx + i];
-        i16 c[16], lv[16];
         fwd4x4(c, r);
         s.cdc[lane] = c[0];
         c[0] = 0;                                     // dct2x2dc takes the DCs out (macroblock.c:73-85)
-        const int *dq = s.qdq[cat];
-        int nz = 0, bits = a.qpc / 6 - 4;
+        if (tq.on) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+            for (int i = 0; i < 16; i++) s.ccoef[lane][i] = c[i];
+        }
+    }
+    if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_CHROMA_AC, !b_inter, 0 ), macroblock.c:310-311
+        WAVE_SYNC();
+        if (lane == 0)
+            for (int b = 0; b < 8; b++)
+                td_trellis_quant(tq.r->ts, &s.ccoef[b][0], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16);
+        WAVE_SYNC();
+    }
+    if (lane < 8) {
+        const int *dq = s.qdq[cat];
+        int nz = 0, bits = Q.qpc / 6 - 4;
+        if (tq.on) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { c[i] = s.ccoef[lane][i]; nz |= c[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { int q = quant_one(c[i], mf[i], bs[i]); c[i] = (i16)q; nz |= q; }
+        }
         SCAN4_FRAME(lv, c);
         u32 nzm, big;
         LEVEL_MASKS(lv, nzm, big);
@@ -515,18 +615,31 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
         s.cscore[lane] = (nz ? decimate_masks(nzm >> 1, big >> 1) : 0) | ((nz != 0) << 8);
     }
     WAVE_SYNC();
+    i16 d2[4] = {0, 0, 0, 0};                          // [0][0] [0][1] [1][0] [1][1]
     if (lane < 2) {
         const int ch = lane;
         int b0 = s.cdc[4 * ch], b1 = s.cdc[4 * ch + 1], b2 = s.cdc[4 * ch + 2], b3 = s.cdc[4 * ch + 3];
         int a0 = b0 + b1, a1 = b2 + b3, a2 = b0 - b1, a3 = b2 - b3;
-        i16 d2[4] = {(i16)(a0 + a1), (i16)(a0 - a1), (i16)(a2 + a3), (i16)(a2 - a3)};   // [0][0] [0][1] [1][0] [1][1]
+        d2[0] = (i16)(a0 + a1); d2[1] = (i16)(a0 - a1); d2[2] = (i16)(a2 + a3); d2[3] = (i16)(a2 - a3);
+        if (tq.on) { s.cdcout[4 * ch] = d2[0]; s.cdcout[4 * ch + 1] = d2[1]; s.cdcout[4 * ch + 2] = d2[2]; s.cdcout[4 * ch + 3] = d2[3]; }
+    }
+    if (tq.on) {                                      // x264_quant_dc_trellis( .., DCT_CHROMA_DC, !b_inter ), macroblock.c:325-326
+        WAVE_SYNC();
+        if (lane == 0)
+            for (int ch = 0; ch < 2; ch++)
+                td_trellis_quant(tq.r->ts, &s.cdcout[4 * ch], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4);
+        WAVE_SYNC();
+    }
+    if (lane < 2) {
+        const int ch = lane;
         int nz_dc = 0;
-        for (int i = 0; i < 4; i++) { int q = quant_one(d2[i], (int)mf[0] >> 1, (int)bs[0] << 1); d2[i] = (i16)q; nz_dc |= q; }
+        if (tq.on) { for (int i = 0; i < 4; i++) { d2[i] = s.cdcout[4 * ch + i]; nz_dc |= d2[i]; } }
+        else for (int i = 0; i < 4; i++) { int q = quant_one(d2[i], (int)mf[0] >> 1, (int)bs[0] << 1); d2[i] = (i16)q; nz_dc |= q; }
         int score = 0, nz_ac = 0;
         u8 nzf[4];
         for (int i = 0; i < 4; i++) { int v = s.cscore[4 * ch + i]; nzf[i] = (u8)(v >> 8); if (v >> 8) { nz_ac = 1; if (b_decimate) score += v & 255; } }
         int e0 = d2[0] + d2[1], e1 = d2[2] + d2[3], e2 = d2[0] - d2[1], e3 = d2[2] - d2[3];
-        int dmf = s.qdq[cat][0], qbits = a.qpc / 6 - 5;
+        int dmf = s.qdq[cat][0], qbits = Q.qpc / 6 - 5;
         if (qbits > 0) { dmf <<= qbits; qbits = 0; }
         int mode;
         if ((b_decimate && score < 7) || !nz_ac) { nzf[0] = nzf[1] = nzf[2] = nzf[3] = 0; mode = nz_dc ? 1 : 0; }
@@ -564,7 +677,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, int b
     return ((m0 & 15) == 2 || (m1 & 15) == 2) ? 2 : (((m0 | m1) & 16) ? 1 : 0);
 }
 // x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883); leaves the P-skip prediction in s.fd
-__device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, const SwArgs &a, int pmx, int pmy, int mbx, int mby,
+__device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, const SwArgs &a, const SwQp &Q, int pmx, int pmy, int mbx, int mby,
                                               ptrdiff_t oy, ptrdiff_t oc, size_t by_, size_t bc_, int lane)
 {
     const int vx = clip3(pmx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
@@ -610,7 +723,7 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
     int ok = luma_sum < 6;
     const u16 *mf = s.qmf[3], *bs = s.qbias[3];
     for (int ch = 0; ch < 2 && ok; ch++) {
-        if (c_ssd[ch] < a.chroma_skip_thresh) continue;
+        if (c_ssd[ch] < Q.skip_thresh) continue;
         int b0 = c_dc[ch][0], b1 = c_dc[ch][1], b2 = c_dc[ch][2], b3 = c_dc[ch][3];
         int a0 = b0 + b1, a1 = b2 + b3, a2 = b0 - b1, a3 = b2 - b3;
         int d2[4] = {(i16)(a0 + a1), (i16)(a0 - a1), (i16)(a2 + a3), (i16)(a2 - a3)};
@@ -626,7 +739,7 @@ __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, cons
 // for the two 1-D passes (32 lanes), then 64 lanes x one coefficient per block.  Leaves the quantised
 // coefficients (transposed storage) in s.coef[4*b..][..] = [4][64], levels in s.lv_y8, per block
 // s.score[b] = decimate_score64 | nz << 8.  cat: 0 intra, 1 inter.
-__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
+__device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, const SwQp &Q, SwTq tq, int cat, int mask, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
 {
     i16 *tmp = s.t8, *coef = &s.coef[0][0];
     const int b = lane >> 3, k8 = lane & 7;
@@ -660,11 +773,23 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, int cat, int mask, int 
                 coef[64 * j + lane] = (i16)sw_denoise(coef[64 * j + lane], s.nr_off8[lane], la);
                 *nr_acc8 += la;
             }
-            int q = quant_one(coef[64 * j + lane], mfl, bsl);
-            coef[64 * j + lane] = (i16)q;
-            nzmask[j] = __ballot(q != 0);
+            if (!tq.on) {
+                int q = quant_one(coef[64 * j + lane], mfl, bsl);
+                coef[64 * j + lane] = (i16)q;
+                nzmask[j] = __ballot(q != 0);
+            }
         }
     WAVE_SYNC();
+    if (tq.on) {                                      // x264_quant_8x8_trellis (R/encoder/rdo.c:652-660), one lane
+        if (lane == 0)
+            for (int j = 0; j < 4; j++)
+                if ((mask >> j) & 1)
+                    td_trellis_quant(tq.r->ts, coef + 64 * j, s.q8mf[cat], tq.r->unq8[cat], SwW8(), c_scan8[0], tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64);
+        WAVE_SYNC();
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((mask >> j) & 1) nzmask[j] = __ballot(coef[64 * j + lane] != 0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((mask >> j) & 1) {
@@ -726,33 +851,34 @@ __device__ __forceinline__ void sw_luma8x8_add(SwLds &s, int cat, int qp, int ke
     WAVE_SYNC();
 }
 // inter, 8x8 transform (R/encoder/macroblock.c:627-669); returns cbp_luma, fills s.nnz[0..15]
-__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
+__device__ __forceinline__ int sw_encode_inter_luma8(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int lane, int *nr_acc8 = nullptr, int nr_on = 0)
 {
-    sw_luma8x8_fwd(s, 1, 0xf, lane, nr_acc8, nr_on);
+    sw_luma8x8_fwd(s, Q, tq, 1, 0xf, lane, nr_acc8, nr_on);
+    const int b_decimate = a.dct_decimate && !tq.on;           // "8x8 trellis is inherently optimal decimation", macroblock.c:630
     int cbp = 0, dec_mb = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int v = __builtin_amdgcn_readfirstlane(s.score[i]);
         if (v >> 8) {
-            if (a.dct_decimate) { dec_mb += v & 255; if ((v & 255) >= 4) cbp |= 1 << i; }
+            if (b_decimate) { dec_mb += v & 255; if ((v & 255) >= 4) cbp |= 1 << i; }
             else cbp |= 1 << i;
         }
     }
-    if (a.dct_decimate && dec_mb < 6) cbp = 0;
+    if (b_decimate && dec_mb < 6) cbp = 0;
     if (lane < 16) s.nnz[lane] = (u8)((cbp >> (lane >> 2)) & 1);
     WAVE_SYNC();
-    sw_luma8x8_add(s, 1, a.qp, cbp, lane);
+    sw_luma8x8_add(s, 1, Q.qp, cbp, lane);
     return cbp;
 }
 // x264_mb_encode_i8x8 for block idx (prediction already in s.fd)
-__device__ __forceinline__ void sw_encode_i8x8(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
+__device__ __forceinline__ void sw_encode_i8x8(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int idx, int &cbp_luma, int lane)
 {
     if (a.lossless) { sw_ll_i8x8(s, idx, cbp_luma, lane); return; }
-    sw_luma8x8_fwd(s, 0, 1 << idx, lane);
+    sw_luma8x8_fwd(s, Q, tq, 0, 1 << idx, lane);
     const int nz = (__builtin_amdgcn_readfirstlane(s.score[idx]) >> 8) & 1;
     if (lane < 4) s.nnz[4 * idx + lane] = (u8)nz;
     WAVE_SYNC();
-    if (nz) { cbp_luma |= 1 << idx; sw_luma8x8_add(s, 0, a.qp, 1 << idx, lane); }
+    if (nz) { cbp_luma |= 1 << idx; sw_luma8x8_add(s, 0, Q.qp, 1 << idx, lane); }
 }
 // x264_mb_encode_i4x4 for block idx (prediction already in s.fd): one lane per coefficient (the four 16-lane rows of the
 // wave run the same block; only the first stores).  The 1-D transforms work on the four values of a quad (DPP
@@ -778,7 +904,7 @@ __device__ __forceinline__ int sw_inv4_quad(int v, int k, int last)   // dct.c:1
     const int r = k == 0 ? e + g : k == 1 ? f + h : k == 2 ? f - h : e - g;
     return (int)(i16)(last ? (r + 32) >> 6 : r);
 }
-__device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int idx, int &cbp_luma, int lane)
+__device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int idx, int &cbp_luma, int lane)
 {
     if (a.lossless) { sw_ll_i4x4(s, idx, cbp_luma, lane); return; }
     int bx, by;
@@ -788,12 +914,20 @@ __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, int id
     v = sw_fwd4_quad(v, x);
     v = __shfl(v, tl, 64);
     v = sw_fwd4_quad(v, x);                                        // dct[l16]
-    const int q = quant_one(v, s.qmf[0][l16], s.qbias[0][l16]);
+    int q;
+    if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_LUMA_4x4, 1, idx ), macroblock.c:134
+        if (lane < 16) s.coef[idx][l16] = (i16)v;
+        WAVE_SYNC();
+        if (lane == 0) td_trellis_quant(tq.r->ts, &s.coef[idx][0], s.qmf[0], tq.r->unq4[0], d_w4z, d_zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16);
+        WAVE_SYNC();
+        q = s.coef[idx][l16];
+    } else
+        q = quant_one(v, s.qmf[0][l16], s.qbias[0][l16]);
     const int nz = (__ballot(q != 0) & 0xffffull) != 0;
     if (lane == 0) s.nnz[idx] = (u8)nz;
     if (nz) {
         if (lane < 16) s.lv_y[16 * idx + (int)((0xFDC6EB75A8419320ull >> (4 * l16)) & 15)] = (i16)q;      // zigzag position of dct[l16]
-        int d = dequant_one(q, s.qdq[0][l16], a.qp / 6 - 4);
+        int d = dequant_one(q, s.qdq[0][l16], Q.qp / 6 - 4);
         d = __shfl(d, tl, 64);                                     // lane (c = l16 >> 2, p = l16 & 3) holds dct[4p + c]
         d = sw_inv4_quad(d, x, 0);                                 // ... now mid[l16]
         d = __shfl(d, tl, 64);
@@ -1070,14 +1204,29 @@ __device__ __forceinline__ int sw_load_acq(const int *p) { return __hip_atomic_l
 // on dependent LDS / L2 round trips, so throughput comes from other chains' waves filling those gaps:
 // fewer registers per wave (some spilled) and more waves resident beats one fat wave per SIMD.
 // LL: lossless, as a compile-time constant (its branches cost the usual path nothing)
-template <int WPE, bool LL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs)
+// RD: the raster-order variant.  With the RD levels (the trial encodes are priced against the live CABAC contexts), trellis
+// (same) or adaptive quantisation (a macroblock's QP follows from the previous one's, R/encoder/ratecontrol.c:263-264) a slice is
+// one serial chain of macroblocks; one wavefront then owns a whole frame of one chain and walks it in raster order, rows and all,
+// and the entropy coder (cabac_dev.h) runs inside the loop exactly where x264_slice_write has it.  Throughput comes from the
+// number of frames in flight (grid = batch), not from a wavefront schedule inside the frame.
+static __device__ const u8 d_lambda_tab[52] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+                                               6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+static __device__ const int d_lambda2_tab[52] = {14, 18, 22, 28, 36, 45, 57, 72, 91, 115, 145, 182, 230, 290, 365, 460, 580, 731, 921, 1161, 1462, 1843, 2322, 2925,
+    3686, 4644, 5851, 7372, 9289, 11703, 14745, 18578, 23407, 29491, 37156, 46814, 58982, 74313, 93628, 117964,
+    148626, 187257, 235929, 297252, 374514, 471859, 594505, 749029, 943718, 1189010, 1498059, 1887436};
+static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                                              29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+template <int WPE, bool LL = false, bool RD = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
 {
     __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
                                                         // kernel argument is copied to scratch memory whole)
     __shared__ SwLds s;
+    __shared__ typename std::conditional<RD, SwLdsRd, SwLdsNone>::type sr_;
+    SwLdsRd &sr = *(SwLdsRd *)&sr_;                     // only touched when RD
     const int lane_id = threadIdx.x, lane = lane_id;
-    const int bz = blockIdx.x % a.batch_pad, mby = blockIdx.x / a.batch_pad;
+    const int bz = RD ? (int)blockIdx.x : (int)(blockIdx.x % a.batch_pad), mby0 = RD ? 0 : (int)(blockIdx.x / a.batch_pad);
     if (bz >= a.batch) return;
     const size_t nmb = (size_t)a.mb_w * a.mb_h, cb = nmb * bz, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
     // batch element
@@ -1090,28 +1239,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     int *prog = a.progress + (size_t)bz * a.mb_h;
     const int satd = a.subme > 1 && !a.lossless, is_p = a.slice_type == 0;
     const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me, a.lossless};
-    {   // tables that every macroblock of the row reads: into LDS once
-        const int cat = lane >> 4, i = lane & 15, q = cat < 2 ? a.qp : a.qpc;
+    SwQp Q = {a.qp, a.qpc, a.lambda, d_lambda2_tab[a.qp], a.chroma_skip_thresh};
+    const i16 *cost_g = a.cost_mv + a.cost_center;     // p_cost_mv of the current QP, centred
+    // tables of the current QP: into LDS (once per slice; again whenever adaptive quantisation changes the macroblock's QP)
+    auto load_qp_tables = [&](int lane) {
+        const int cat = lane >> 4, i = lane & 15, q = cat < 2 ? Q.qp : Q.qpc;
         s.qmf[cat][i] = a.q4mf[(cat * 52 + q) * 16 + i]; s.qbias[cat][i] = a.q4bias[(cat * 52 + q) * 16 + i];
         s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
         if (is_p)
-            for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = a.cost_mv[a.cost_center - MX_COST_LDS + k];
+            for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = cost_g[k - MX_COST_LDS];
+        if (a.transform8x8)
+            for (int c8 = 0; c8 < 2; c8++) {
+                s.q8mf[c8][lane] = a.q8mf[(c8 * 52 + Q.qp) * 64 + lane]; s.q8bias[c8][lane] = a.q8bias[(c8 * 52 + Q.qp) * 64 + lane];
+                s.q8dq[c8][lane] = a.dq8[c8 * 384 + (Q.qp % 6) * 64 + lane];
+            }
+        if constexpr (RD) {
+            if (rd.trellis) {
+                sr.unq4[cat][i] = rd.unq4[(cat * 52 + q) * 16 + i];
+                if (a.transform8x8) for (int c8 = 0; c8 < 2; c8++) sr.unq8[c8][lane] = rd.unq8[(c8 * 52 + Q.qp) * 64 + lane];
+            }
+        }
+    };
+    load_qp_tables(lane);
+    {
         if (a.nr) { s.nr_off8[lane] = a.nr_offset[(size_t)bz * 128 + 64 + lane]; if (lane < 16) s.nr_off4[lane] = a.nr_offset[(size_t)bz * 128 + lane]; }
         if (lane < 48) s.p4lut[lane] = ((const u32 *)&c_plut4)[lane];
         for (int k = lane; k < 192; k += 64) s.p8lut[k] = ((const u32 *)&c_plut8)[k];
-        if (a.transform8x8)
-            for (int c8 = 0; c8 < 2; c8++) {
-                s.q8mf[c8][lane] = a.q8mf[(c8 * 52 + a.qp) * 64 + lane]; s.q8bias[c8][lane] = a.q8bias[(c8 * 52 + a.qp) * 64 + lane];
-                s.q8dq[c8][lane] = a.dq8[c8 * 384 + (a.qp % 6) * 64 + lane];
-            }
+    }
+    // the entropy coder of this chain's slice (x264_slice_write, R/encoder/encoder.c:1155-1165)
+    DCabac cab = {0, 0x1FE, -1, 0, nullptr, 0};
+    u8 *payload0 = nullptr;
+    int last_qp = a.qp, last_dqp = 0, prev_coded = 0, intra_before = 0;      // h->mb.i_last_qp / i_last_dqp; the previous macroblock "has coefficients"
+    if constexpr (RD) {
+        if (rd.write) {
+            payload0 = rd.payload + (size_t)bz * rd.payload_cap + 64;
+            cab.p = payload0;
+            for (int k = lane; k < 460; k += 64) sr.cabac[k] = (u8)cd_context_init_one(k, a.slice_type, a.qp, rd.cabac_init_idc);
+        }
     }
     WAVE_SYNC();
 
     int nr_acc4 = 0, nr_acc8 = 0, nr_n4 = 0, nr_n8 = 0;      // --nr: this row's additions to nr_residual_sum (lane = coefficient index) / nr_count
     long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptime = a.prof ? (long long)wall_clock64() : 0;
 #define PROF(k_) do { if (a.prof) { long long now_ = (long long)wall_clock64(); pacc[k_] += now_ - ptime; ptime = now_; } } while (0)
+  for (int mby = mby0; mby < (RD ? a.mb_h : mby0 + 1); mby++) {
+    if constexpr (RD) {
+        // this wave's own stores of the row above (pixels, types, vectors ...) must be what its loads see
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // the left neighbour = this wave's previous macroblock
     int left_type = -1, left_ref = -2, left_mvx = 0, left_mvy = 0, row_intra = 0;
+    int left_cbp = -1, left_cpm = 0, left_t8 = 0;          // (RD) h->mb.cbp / chroma_pred_mode / mb_transform_size of the left macroblock
     u32 pre_y;
     u8 pre_u, pre_v;
     {
@@ -1130,7 +1309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         LAUNDER();
         const int mb = mby * a.mb_w + mbx;
         // ---- wait for the row above: left-top, top and top-right neighbours finished ----
-        if (mby > 0) {
+        if (!RD && mby > 0) {
             const int need = min(mbx + 2, a.mb_w);
             int spins = 0;
             // Poll with relaxed loads: an acquire load invalidates this CU's vector L1 on every poll, for every wave
@@ -1182,6 +1361,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (mbx > 0) nb |= NB_LEFT;
         if (mbx < a.mb_w - 1 && mby > 0) { nb |= NB_TOPRIGHT; type_topright = UNI(a.mb_type[mb - a.mb_w + 1]); }
         if (mbx > 0 && mby > 0) { nb |= NB_TOPLEFT; type_topleft = UNI(a.mb_type[mb - a.mb_w - 1]); }
+        int cbp_top = -1, cpm_top = 0, t8_top = 0;
+        if constexpr (RD) {
+            // ---- x264_ratecontrol_qp + x264_adaptive_quant (R/encoder/analyse.c:2162-2164, ratecontrol.c:257-265) ----
+            int qp = a.qp;
+            if (rd.aq) {
+                const float off = __builtin_bit_cast(float, UNI(__builtin_bit_cast(int, rd.aq_offset[cb + mb])));
+                qp = clip3((int)((double)(rd.f_qpm + off) + .5), rd.qp_min, rd.qp_max);
+                if (iabs(qp - last_qp) == 1) qp = last_qp;
+            }
+            if (qp != Q.qp) {
+                Q.qp = qp; Q.qpc = d_chroma_qp[clip3(qp + rd.chroma_qp_offset, 0, 51)];
+                Q.lambda = d_lambda_tab[qp]; Q.lambda2 = d_lambda2_tab[qp]; Q.skip_thresh = (d_lambda2_tab[Q.qpc] + 32) >> 6;
+                cost_g = rd.cost_mv_all + (size_t)qp * (2 * a.cost_center + 1) + a.cost_center;
+                WAVE_SYNC();
+                load_qp_tables(lane);
+                WAVE_SYNC();
+            }
+            // ---- what the entropy coder reads of the neighbours (R/common/macroblock.c:896-1010,1129-1160) ----
+            if (lane < 48) { sr.cmvd[lane][0] = 0; sr.cmvd[lane][1] = 0; }
+            WAVE_SYNC();
+            if (nb & NB_TOP) {
+                const int top = mb - a.mb_w;
+                const u8 *nz = (a.nnz + 27 * cb) + (size_t)top * 27;
+                cbp_top = UNI((a.cbp + cb)[top]); t8_top = UNI((a.t8 + cb)[top]);
+                { const int ct = UNI((a.chroma_mode + cb)[top]); cpm_top = type_top == T_I_PCM ? 0 : sw_fix8c(ct); }
+                if (lane < 4) sr.nz_t[lane] = nz[lane == 0 ? 10 : lane == 1 ? 11 : lane == 2 ? 14 : 15];
+                else if (lane < 8) sr.nz_tc[(lane - 4) >> 1][lane & 1] = nz[16 + 4 * ((lane - 4) >> 1) + 2 + (lane & 1)];
+                else if (lane < 12) {
+                    const i16 *mvd = rd.mvd + ((cb + top) * 16 + 12 + (lane - 8)) * 2;
+                    sr.cmvd[4 + lane - 8][0] = mvd[0]; sr.cmvd[4 + lane - 8][1] = mvd[1];
+                }
+            } else if (lane < 4) sr.nz_t[lane] = 0x80;
+            else if (lane < 8) sr.nz_tc[(lane - 4) >> 1][lane & 1] = 0x80;
+            if (nb & NB_LEFT) {
+                if (lane >= 16 && lane < 20) sr.nz_l[lane - 16] = sr.left_nz[lane - 16];
+                else if (lane >= 20 && lane < 24) sr.nz_lc[(lane - 20) >> 1][lane & 1] = sr.left_nz[4 + lane - 20];
+                else if (lane >= 24 && lane < 28) { sr.cmvd[11 + 8 * (lane - 24)][0] = sr.left_mvd[lane - 24][0]; sr.cmvd[11 + 8 * (lane - 24)][1] = sr.left_mvd[lane - 24][1]; }
+            } else if (lane >= 16 && lane < 20) sr.nz_l[lane - 16] = 0x80;
+            else if (lane >= 20 && lane < 24) sr.nz_lc[(lane - 20) >> 1][lane & 1] = 0x80;
+            WAVE_SYNC();
+        }
 
         int type = T_I_16x16, mvx = 0, mvy = 0, ref = 0, skip_mc = 0, pred16 = 0, predc = 0, part = 16;
         int sub_t_mb = 3;                    // lanes 0..3: h->mb.i_sub_partition[] (D_L0_4x4 0, 8x4 1, 4x8 2, 8x8 3)
@@ -1198,6 +1418,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             WAVE_SYNC();
         }
         int stat_intra = 0, stat_inter = 0, analysed = 0;
+        // x264_mb_analyse_init (R/encoder/analyse.c:235-252): h->mb.b_trellis while analysing, i_skip_intra
+        const int mbrd = RD ? rd.mbrd : 0;
+        SwTq tq = {RD && rd.trellis > 1 && mbrd, &sr};
+        int skip_intra = a.lossless ? 0 : mbrd ? 2 : (RD ? (!rd.trellis && !a.nr) : 1);
+        (void)skip_intra;
 
         // x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610
         auto analyse_chroma = [&]() {
@@ -1207,7 +1432,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             for (int i = 0; i < n; i++) {
                 const int m = (int)((list >> (4 * i)) & 15);
                 sw_pred8c(s, m, lane, a.lossless);
-                int c = sw_cmp_chroma(s, satd, lane) + a.lambda * sw_ue_size(sw_fix8c(m));
+                int c = sw_cmp_chroma(s, satd, lane) + Q.lambda * sw_ue_size(sw_fix8c(m));
                 if (c < satd_chroma) { satd_chroma = c; predc = m; }
             }
         };
@@ -1220,6 +1445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (!is_p || mb <= 4) return 0;
             if (IS_INTRA_T(left_type) || IS_INTRA_T(type_top) || IS_INTRA_T(type_topleft) || IS_INTRA_T(type_topright)) return 0;
             if (a.l0_type && IS_INTRA_T(UNI(a.l0_type[mb]))) return 0;
+            if constexpr (RD) return mb < 3 * intra_before ? 0 : 1;        // raster order: every earlier macroblock is done
             for (int spins = 0;; spins++) {
                 int known = row_intra, pending = 0;
                 for (int r0 = 0; r0 < mby; r0 += 64) {
@@ -1244,7 +1470,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 for (int i = 0; i < n; i++) {
                     const int m = (int)((list >> (4 * i)) & 15);
                     sw_pred16(s, m, lane, a.lossless);
-                    int c = sw_cmp_luma16(s, satd, lane) + a.lambda * sw_ue_size(sw_fix16(m));
+                    int c = sw_cmp_luma16(s, satd, lane) + Q.lambda * sw_ue_size(sw_fix16(m));
                     if (c < satd_i16) { satd_i16 = c; pred16 = m; }
                 }
             }
@@ -1258,7 +1484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 fi_open = fi == 2;
             }
             if (a.flags_intra & 2) {                                   // X264_ANALYSE_I8x8
-                const int thresh = min(satd_inter, satd_i16);
+                const int thresh = mbrd ? MX_COST_MAX : min(satd_inter, satd_i16);
                 int cost = 0, idx, acbp = 0;
                 for (idx = 0;; idx++) {
                     const int bx = 8 * (idx & 1), by = 8 * (idx >> 1), pm = sw_pred_i4mode(s, 4 * idx), nb8 = sw_nb8(idx, nb);
@@ -1295,7 +1521,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 for (int x = 0; x < 8; x++) sd += iabs(d[x]);
                                 c = half_sum8(sd);
                             }
-                            key = ((u32)(c + a.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
+                            key = ((u32)(c + Q.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
                         }
                         // the reference's in-order strict '<' over the modes = the smallest (cost, slot) key
 #pragma unroll
@@ -1313,10 +1539,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         if (lane < 4) s.i4c[sw_scan8(4 * idx) + (lane & 1) + 8 * (lane >> 1)] = (signed char)bmode;
                         WAVE_SYNC();
                     }
-                    sw_encode_i8x8(s, a, idx, acbp, lane);
+                    sw_encode_i8x8(s, a, Q, tq, idx, acbp, lane);
                 }
                 if (idx == 3) {
                     satd_i8 = cost; i8_cbp = acbp;
+                    if constexpr (RD) { if (skip_intra == 2) for (int k = lane; k < 256; k += 64) sr.i8_dct[k] = s.lv_y8[k]; }
                     *(u32 *)(s.i8_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
                     if (lane < 16) s.i8_nnz[lane] = s.nnz[lane];
                     WAVE_SYNC();
@@ -1324,11 +1551,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     satd_i8 = MX_COST_MAX;
                     cost = (cost * (idx == 0 ? 1024 : idx == 1 ? 512 : 341)) >> 8;
                 }
-                if (min(cost, satd_i16) > satd_inter * 5 / 4) return;
+                if (min(cost, satd_i16) > satd_inter * (5 + !!mbrd) / 4) return;
             }
             if (a.flags_intra & 1) {                                   // X264_ANALYSE_I4x4
-                const int thresh = min(min(satd_inter, satd_i16), satd_i8);
-                int cost = a.lambda * 24, idx, acbp = 0;
+                int thresh = min(min(satd_inter, satd_i16), satd_i8);
+                if (mbrd) thresh = thresh * (10 - fast_intra_now(0)) / 8;
+                int cost = Q.lambda * 24, idx, acbp = 0;
                 for (idx = 0;; idx++) {
                     int bx, by, n;
                     sw_blk_xy(idx, bx, by);
@@ -1352,7 +1580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 d2 = (int)((fw >> 16) & 255) - sw_ll_px(s, 0, mode, bx + 2, by + r); d3 = (int)(fw >> 24) - sw_ll_px(s, 0, mode, bx + 3, by + r);
                             }
                             const int c = sw_cost4x4_rows(d0, d1, d2, d3, satd, lane);
-                            key = ((u32)(c + a.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
+                            key = ((u32)(c + Q.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
                         }
                     }
                     u32 kb = (u32)__builtin_amdgcn_readlane((int)key, 0);
@@ -1366,10 +1594,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                                                          : s.pt4[(s.p4lut[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
                     if (lane == 0) s.i4c[sw_scan8(idx)] = (signed char)bmode;
                     WAVE_SYNC();
-                    sw_encode_i4x4(s, a, idx, acbp, lane);
+                    sw_encode_i4x4(s, a, Q, tq, idx, acbp, lane);
                 }
                 if (idx == 15) {
                     satd_i4 = cost; i4_cbp = acbp;
+                    if constexpr (RD) { if (skip_intra == 2) for (int k = lane; k < 256; k += 64) sr.i4_dct[k] = s.lv_y[k]; }
                     *(u32 *)(s.i4_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
                     if (lane < 16) s.i4_nnz[lane] = s.nnz[lane];
                     WAVE_SYNC();
@@ -1378,12 +1607,242 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             }
         };
 
+        // ---- x264_macroblock_encode (R/encoder/macroblock.c:475-790) of the macroblock as type / part / t8 / the intra modes / s.mv4 /
+        // s.ref8 describe it now.  The final encode, and with the RD levels every trial encode of x264_rd_cost_mb (final_pass = 0).
+        int cbp_luma = 0, cbp_chroma = 0;
+        bool encoded = false;               // (RD) the final encode has run inside the candidate loop
+        auto encode_pskip = [&]() {         // x264_macroblock_encode_pskip, macroblock.c:378-402
+            cbp_luma = 0; cbp_chroma = 0;
+            if (lane < 32) s.nnz[lane] = 0;
+            mvx = pskx; mvy = psky; ref = 0;
+            if (lane < 16) { s.mv4[lane][0] = (i16)pskx; s.mv4[lane][1] = (i16)psky; }
+            if (lane < 4) s.ref8[lane] = 0;
+            WAVE_SYNC();
+            if (!skip_mc) {
+                const int vx = clip3(mvx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
+                const int vy = clip3(mvy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
+                sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
+                WAVE_SYNC();
+            }
+        };
+        auto encode_mb = [&](int final_pass) {
+            if (type == T_P_SKIP) { encode_pskip(); return; }
+            cbp_luma = 0; cbp_chroma = 0;
+            if (lane < 32) s.nnz[lane] = 0;
+            WAVE_SYNC();
+            if (type == T_I_16x16) {
+                t8 = 0;
+                analyse_chroma();
+                sw_pred16(s, pred16, lane, a.lossless);
+                cbp_luma = sw_encode_i16x16(s, a, Q, tq, lane);
+                sw_pred8c(s, predc, lane, a.lossless);
+                cbp_chroma = sw_encode_chroma(s, a, Q, tq, 0, lane);
+            } else if (type == T_I_8x8 || type == T_I_4x4) {
+                // x264_analyse_update_cache: the winner's modes into the cache; then macroblock.c:527-590.  With i_skip_intra the
+                // analysis already encoded all blocks but the last: take its state and finish; without it (trellis 1, --nr,
+                // lossless) every block is predicted and coded again.
+                const bool i8 = type == T_I_8x8;
+                if (lane < 16) s.i4c[sw_scan8(lane)] = i8 ? s.pred8[lane >> 2] : s.pred4[lane];
+                analyse_chroma();
+                if (skip_intra) {
+                    *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)((i8 ? s.i8_fdec : s.i4_fdec) + lane * 4);
+                    if (lane < 16) s.nnz[lane] = i8 ? s.i8_nnz[lane] : s.i4_nnz[lane];
+                    cbp_luma = i8 ? i8_cbp : i4_cbp;
+                    if constexpr (RD) {                  // "In RD mode, restore the now-overwritten DCT data", macroblock.c:543
+                        if (skip_intra == 2) for (int k = lane; k < 256; k += 64) { if (i8) s.lv_y8[k] = sr.i8_dct[k]; else s.lv_y[k] = sr.i4_dct[k]; }
+                    }
+                }
+                WAVE_SYNC();
+                if (i8) {
+                    t8 = 1;
+                    for (int idx = skip_intra ? 3 : 0; idx < 4; idx++) {
+                        const int bx = 8 * (idx & 1), by = 8 * (idx >> 1);
+                        const int mode = __builtin_amdgcn_readfirstlane((int)s.pred8[idx]), nb8 = sw_nb8(idx, nb);
+                        // x264_pred_i4x4_neighbors (R/common/macroblock.h:40-54)
+                        const int need = mode == 0 || mode == 10 ? NB_TOP : mode == 1 || mode == 8 || mode == 9 ? NB_LEFT : mode == 2 ? NB_LEFT | NB_TOP
+                                       : mode == 3 || mode == 7 ? NB_TOP | NB_TOPRIGHT : mode == 11 ? 0 : NB_LEFT | NB_TOPLEFT | NB_TOP;
+                        if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + by * FD + bx, FD, nb8, need);
+                        WAVE_SYNC();
+                        const int v = a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, bx + (lane & 7), by + (lane >> 3)) : pred8_px(mode, s.edge8, lane & 7, lane >> 3);
+                        WAVE_SYNC();
+                        s.fd[FDY + (by + (lane >> 3)) * FD + bx + (lane & 7)] = (u8)v;
+                        WAVE_SYNC();
+                        sw_encode_i8x8(s, a, Q, tq, idx, cbp_luma, lane);
+                    }
+                } else {
+                    t8 = 0;
+                    for (int idx = skip_intra ? 15 : 0; idx < 16; idx++) {
+                        int bx, by;
+                        sw_blk_xy(idx, bx, by);
+                        u8 *dst = s.fd + FDY + by * FD + bx;
+                        const int mode = __builtin_amdgcn_readfirstlane((int)s.pred4[idx]);
+                        if ((sw_nb4(idx, nb) & (NB_TOPRIGHT | NB_TOP)) == NB_TOP && lane < 4) dst[4 - FD + lane] = dst[3 - FD];
+                        WAVE_SYNC();
+                        if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
+                        WAVE_SYNC();
+                        if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)(a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, bx + (lane & 3), by + (lane >> 2))
+                                                                                                       : pred4_px(mode, s.e4, lane & 3, lane >> 2));
+                        WAVE_SYNC();
+                        sw_encode_i4x4(s, a, Q, tq, idx, cbp_luma, lane);
+                    }
+                }
+                sw_pred8c(s, predc, lane, a.lossless);
+                cbp_chroma = sw_encode_chroma(s, a, Q, tq, 0, lane);
+            } else {
+                sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
+                WAVE_SYNC();
+                // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
+                if (!mbrd && a.transform8x8 && !a.lossless && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
+                    // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
+                    int raw = 0;
+                    if (lane < 32) {
+                        const int blk = lane >> 3, r = lane & 7;
+                        raw = sw_sa8d_rows(s.fe + ((blk >> 1) * 8 + r) * 16 + (blk & 1) * 8, s.fd + FDY + ((blk >> 1) * 8 + r) * FD + (blk & 1) * 8, lane);
+                    }
+                    const int c8 = (__builtin_amdgcn_readlane(raw, 0) + __builtin_amdgcn_readlane(raw, 8) + __builtin_amdgcn_readlane(raw, 16)
+                                    + __builtin_amdgcn_readlane(raw, 24) + 2) >> 2;
+                    const int c4 = sw_cmp_luma16(s, 1, lane);
+                    t8 = c8 < c4;
+                }
+                const int nr_on = a.nr && final_pass;        // h->mb.b_noise_reduction is off while analysing (analyse.c:237,2769)
+                if (nr_on) { if (t8) nr_n8 += 4; else nr_n4 += 16; }
+                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, Q, tq, lane, &nr_acc8, nr_on) : sw_encode_inter_luma(s, a, Q, tq, lane, &nr_acc4, nr_on);   // never a conditional pointer: that pins the counter in scratch memory
+                cbp_chroma = sw_encode_chroma(s, a, Q, tq, 1, lane);
+                if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
+            }
+        };
+
+        // ---- the RD levels: x264_mb_cache_fenc_satd, ssd_mb, x264_macroblock_size_cabac, x264_rd_cost_mb ----
+        int fenc_satd_sum = 0, fenc_sa8d_sum = 0;
+        auto cache_fenc_satd = [&]() {     // R/encoder/analyse.c:509-537 (the 16x16 sums; sub-partition RD is not built)
+            if (!rd.psy_rd) return;
+            int v4 = 0, v8 = 0;
+            if (lane < 16) {
+                const u8 *fe = s.fe + (lane >> 2) * 64 + (lane & 3) * 4;
+                int sad = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sad += fe[j * 16 + i];
+                v4 = satd_4x4(sr.zero16, 0, fe, 16) - (sad >> 1);
+            } else if (lane < 20) {
+                const int b = lane - 16;
+                const u8 *fe = s.fe + (b >> 1) * 128 + (b & 1) * 8;
+                int sad = 0;
+                for (int j = 0; j < 8; j++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sad += fe[j * 16 + i];
+                v8 = ((sa8d_8x8_raw(sr.zero16, 0, fe, 16) + 2) >> 2) - (sad >> 2);
+            }
+            fenc_satd_sum = wave_sum(v4); fenc_sa8d_sum = wave_sum(v8);
+        };
+        auto ssd_mb = [&]() -> int {       // ssd_mb / ssd_plane, R/encoder/rdo.c:106-137
+            int acc = 0;
+            {
+                const int r = lane >> 2, x = (lane & 3) * 4, cx = lane & 7, cy = lane >> 3;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const int d = (int)s.fe[r * 16 + x + i] - (int)s.fd[FDY + r * FD + x + i]; acc += d * d; }
+                const int du = (int)s.fe[256 + cy * 8 + cx] - (int)s.fd[FDU + cy * FD + cx], dv = (int)s.fe[320 + cy * 8 + cx] - (int)s.fd[FDV + cy * FD + cx];
+                acc += du * du + dv * dv;
+            }
+            int ssd = wave_sum(acc);
+            if (rd.psy_rd) {
+                unsigned long long h = 0;
+                if (lane < 4) h = hadamard_ac_8x8(s.fd + FDY + (lane >> 1) * 8 * FD + (lane & 1) * 8, FD);
+                const u32 lo = (u32)h, hi = (u32)(h >> 32);
+                unsigned long long sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum += ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)hi, k) << 32) + (u32)__builtin_amdgcn_readlane((int)lo, k);
+                const int s4 = (int)((u32)sum >> 1), s8 = (int)(sum >> 34);
+                const int satd = (iabs(s4 - fenc_satd_sum) + iabs(s8 - fenc_sa8d_sum)) >> 1;
+                ssd += (satd * rd.psy_rd * Q.lambda + 128) >> 8;
+            }
+            return ssd;
+        };
+        // what the entropy coder reads of this macroblock: the interior of the motion cache from s.mv4 / s.ref8 (all lanes) ...
+        auto syn_prepare = [&]() {
+            if (is_p && lane < 16) {
+                const int k = 12 + (lane & 3) + 8 * (lane >> 2);
+                sr.cref[k] = s.ref8[(lane >> 3) * 2 + ((lane & 3) >> 1)]; sr.cmv[k][0] = s.mv4[lane][0]; sr.cmv[k][1] = s.mv4[lane][1];
+            }
+            if (lane < 4) sr.sub[lane] = (signed char)sub_t_mb;
+            WAVE_SYNC();
+        };
+        // ... and the record the writer walks (scalars: wave-uniform registers)
+        auto make_syn = [&]() -> MbSynDev {
+            MbSynDev y;
+            y.slice_type = a.slice_type; y.type = type; y.partition = part; y.i16mode = pred16; y.chroma_mode = predc;
+            y.cbp_luma = cbp_luma; y.cbp_chroma = cbp_chroma; y.t8 = t8; y.qp = Q.qp; y.n_ref = a.n_refs; y.pps_t8 = a.transform8x8;
+            y.t8_allowed = a.transform8x8 && (type == T_P_L0 || (type == T_P_8x8 && __ballot(lane < 4 && sub_t_mb != 3) == 0));
+            y.type_left = left_type; y.type_top = type_top; y.cbp_left = left_cbp; y.cbp_top = cbp_top; y.cpm_left = left_cpm; y.cpm_top = cpm_top;
+            y.nb_t8 = (left_type >= 0 && left_t8) + (type_top >= 0 && t8_top);
+            y.last_qp = last_qp; y.last_dqp = last_dqp; y.prev_coded = prev_coded;
+            y.sub = sr.sub; y.i4c = s.i4c; y.cref = sr.cref; y.cmv = sr.cmv; y.cmvd = sr.cmvd;
+            y.nnz = s.nnz; y.nz_l = sr.nz_l; y.nz_t = sr.nz_t; y.nz_lc = sr.nz_lc; y.nz_tc = sr.nz_tc;
+            y.lv4 = (i16 (*)[16])s.lv_y; y.lv8 = (i16 (*)[64])s.lv_y8; y.lv_dc = s.lv_dc; y.lv_cdc = (i16 (*)[4])s.lv_cdc; y.lv_cac = (i16 (*)[16])s.lv_cac;
+            return y;
+        };
+        // x264_rd_cost_mb (R/encoder/rdo.c:139-171): trial encode, distortion, the syntax priced against a copy of the live contexts.
+        // Like the reference it leaves `type` as the encode left it (P_SKIP when nothing was left to code on the skip vector).
+        auto rd_cost_mb = [&]() -> int {
+            const int t8_bak = t8;
+            encode_mb(0);
+            int cost = ssd_mb();
+            if (type == T_P_SKIP) cost += (Q.lambda2 + 128) >> 8;
+            else {
+                syn_prepare();
+                for (int k = lane; k < 460; k += 64) sr.cabac_tmp[k] = sr.cabac[k];
+                const MbSynDev y0 = make_syn();
+                WAVE_SYNC();
+                if (lane == 0) {
+                    DCabac tcb = {0, 0x1FE, -1, 0, nullptr, 0};
+                    MbSynDev y = y0;
+                    cw_macroblock(tcb, sr.cabac_tmp, 1, y, s.fe, 0);
+                    sr.tmp_i[0] = tcb.f8;
+                }
+                WAVE_SYNC();
+                const int f8 = UNI(sr.tmp_i[0]);
+                cost += (int)(((unsigned long long)(u32)f8 * (u32)Q.lambda2 + 32768) >> 16);
+            }
+            t8 = t8_bak;
+            return cost;
+        };
+        (void)cache_fenc_satd; (void)rd_cost_mb;
+        // a->i_satd_pcm, analyse.c:246
+        const int satd_pcm = RD && !rd.psy_rd && mbrd ? (int)(((unsigned long long)(386 * 8) * (u32)Q.lambda2 + 128) >> 8) : MX_COST_MAX;
+
         if (!is_p) {
+          if constexpr (RD) {
+            // x264_macroblock_analyse, I slice (analyse.c:2169-2186), the RD candidates and the final encode through ONE copy of the encoder
+            if (mbrd) cache_fenc_satd();
+            analyse_intra(MX_COST_MAX);
+#pragma nounroll
+            for (int step = mbrd ? 0 : 3; step < 4; step++) {
+                if (step == 0) { if (!(satd_i16 <= MX_COST_MAX)) continue; type = T_I_16x16; }                                  // x264_intra_rd, :845-874
+                else if (step == 1) { if (!(satd_i4 < MX_COST_MAX)) { satd_i4 = MX_COST_MAX; continue; } type = T_I_4x4; }
+                else if (step == 2) { if (!(satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; } type = T_I_8x8; }
+                else {
+                    type = T_I_16x16;
+                    int i_cost = satd_i16;
+                    if (satd_i4 < i_cost) { i_cost = satd_i4; type = T_I_4x4; }
+                    if (satd_i8 < i_cost) { i_cost = satd_i8; type = T_I_8x8; }
+                    if (satd_pcm < i_cost) type = T_I_PCM;
+                    tq.on = rd.trellis != 0;                                      // analyse.c:2768-2773
+                    if (rd.trellis == 1 || a.nr) skip_intra = 0;
+                    if (type != T_I_PCM) encode_mb(1);
+                    encoded = true;
+                    break;
+                }
+                const int c = rd_cost_mb();
+                if (step == 0) satd_i16 = c; else if (step == 1) satd_i4 = c; else satd_i8 = c;
+            }
+          } else {
             analyse_intra(MX_COST_MAX);
             type = T_I_16x16;
             int i_cost = satd_i16;
             if (satd_i4 < i_cost) { i_cost = satd_i4; type = T_I_4x4; }
             if (satd_i8 < i_cost) { i_cost = satd_i8; type = T_I_8x8; }
+          }
         } else {
             // ---- motion neighbours: what cache_load puts around the block (R/common/macroblock.c:1040-1128) ----
             int ra = left_ref, ax = left_mvx, ay = left_mvy;                 // A
@@ -1396,7 +1855,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             // by the lane itself or with v_writelane -- no LDS round trip, no barrier.
             int cref_v = -2, cmvx_v = 0, cmvy_v = 0, pme_v = 0;
             int sub_mx = 0, sub_my = 0, sub_cost = 0, sub_px = 0, sub_py = 0, sub_t = 3;      // sub-8x8 records (lanes 0..31) and chosen type (lanes 0..3)
-            if (a.flags_inter & 0x10) {
+            if (RD || (a.flags_inter & 0x10)) {
                 // the full motion cache for x264_mb_predict_mv on partitions: -2 = not available, neighbours as cache_load leaves them
                 if ((nb & NB_TOP) && lane >= 4 && lane < 8) {
                     const int o = mb - a.mb_w, k = lane - 4;
@@ -1415,6 +1874,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     cref_v = s.left_r8[i >> 1]; cmvx_v = s.left_mv4[i][0]; cmvy_v = s.left_mv4[i][1];
                 }
             }
+            if constexpr (RD) {     // the neighbours' part of the motion cache, for the entropy coder's x264_mb_predict_mv / ref contexts
+                if (lane < 48) { sr.cref[lane] = (signed char)cref_v; sr.cmv[lane][0] = (i16)cmvx_v; sr.cmv[lane][1] = (i16)cmvy_v; }
+                WAVE_SYNC();
+            }
             // x264_mb_predict_mv_16x16, :90-128
             auto predict16 = [&](int i_ref, int &px, int &py) {
                 const int cnt = (ra == i_ref) + (rb == i_ref) + (rc == i_ref);
@@ -1431,7 +1894,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (a.fast_pskip) {
                 if (a.subme >= 3) try_pskip = 1;
                 else if (left_type == T_P_SKIP || type_top == T_P_SKIP || type_topleft == T_P_SKIP || type_topright == T_P_SKIP) {
-                    b_skip = sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane);
+                    b_skip = sw_probe_pskip(s, refs, a, Q, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane);
                     skip_mc = b_skip;
                 }
             }
@@ -1478,16 +1941,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     for (int k = 0; k < 4; k++) c.pl[k] = (MX_GLB(u8))(refs.y[r][k] + by_ + oy);
                     c.cu = (MX_GLB(u8))(refs.u[r] + bc_ + oc); c.cv = (MX_GLB(u8))(refs.v[r] + bc_ + oc);
                     c.mvpx = mvpx; c.mvpy = mvpy;
-                    thresh -= refs.ref_cost[r];
+                    thresh -= (Q.lambda * refs.ref_bits[r]);
                     int smx, smy, cost_mv;
                     LAUNDER(); c.lane = lane;
                     int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], n_mvc, &thresh, smx, smy, cost_mv);   // with one reference the threshold never bites (it starts at COST_MAX); a conditional
                                                                                         // pointer would pin it in scratch memory
-                    if (r == 0 && try_pskip && cost - cost_mv < 300 * a.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
-                        if (sw_probe_pskip(s, refs, a, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
+                    if (r == 0 && try_pskip && cost - cost_mv < 300 * Q.lambda && iabs(smx - pskx) + iabs(smy - psky) <= 1) {
+                        if (sw_probe_pskip(s, refs, a, Q, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane)) { early_skip = true; break; }
                     }
-                    cost += refs.ref_cost[r];
-                    thresh += refs.ref_cost[r];
+                    cost += (Q.lambda * refs.ref_bits[r]);
+                    thresh += (Q.lambda * refs.ref_bits[r]);
                     if (cost < best) { best = cost; mvx = smx; mvy = smy; ref = r; bmvpx = mvpx; bmvpy = mvpy; }
                     if (lane == 0) {
                         a.mvr[((size_t)r * nmb + mb) * 2] = (i16)smx; a.mvr[((size_t)r * nmb + mb) * 2 + 1] = (i16)smy;
@@ -1541,6 +2004,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         else { px = sw_median(ax, bx, cx); py = sw_median(ay, byv, cy); }
                     };
                     int i_cost = best;
+                    int c8x8 = MX_COST_MAX, c16x8 = MX_COST_MAX, c8x16 = MX_COST_MAX;   // a->l0.i_cost8x8 / i_cost16x8 / i_cost8x16
+                    auto search_partitions = [&]() {
                     part = 16;                                       // D_16x16
                     if (a.flags_inter & 0x10) {
                         // ---- X264_ANALYSE_PSUB16x16: p8x8, then p16x8 / p8x16 (R/encoder/analyse.c:2222-2265) ----
@@ -1563,18 +2028,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     aim(r, 8, 8, 8 * (i & 1), 8 * (i >> 1));
                                     c.mvpx = px; c.mvpy = py;
                                     LAUNDER(); c.lane = lane;
-                                    int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + refs.ref_cost[r];
+                                    int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm) + (Q.lambda * refs.ref_bits[r]);
                                     if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
                                     WAVE_SYNC();
                                     if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
                                 }
                                 cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, br, bvx, bvy, 1);
-                                pme_put(i, bvx, bvy, bcost + a.lambda, bcm, br, refs.ref_cost[br], bpx, bpy);      // + lambda * i_sub_mb_p_cost_table[D_L0_8x8]
+                                pme_put(i, bvx, bvy, bcost + Q.lambda, bcm, br, (Q.lambda * refs.ref_bits[br]), bpx, bpy);      // + lambda * i_sub_mb_p_cost_table[D_L0_8x8]
                             }
                             cost8x8 = pme(0, 2) + pme(1, 2) + pme(2, 2) + pme(3, 2);
-                            if (!a.cabac && !(pme(0, 4) | pme(1, 4) | pme(2, 4) | pme(3, 4))) cost8x8 -= refs.ref_cost[0] * 4;
+                            if (!a.cabac && !(pme(0, 4) | pme(1, 4) | pme(2, 4) | pme(3, 4))) cost8x8 -= (Q.lambda * refs.ref_bits[0]) * 4;
                         } else {                                     // x264_mb_analyse_inter_p8x8, :1221-1272
-                            const int r = ref, ref_cost = a.cabac || r ? refs.ref_cost[r] : 0;
+                            const int r = ref, ref_cost = a.cabac || r ? (Q.lambda * refs.ref_bits[r]) : 0;
                             if (lane == 0) { s.l0mvc[r][0][0] = (i16)mvx; s.l0mvc[r][0][1] = (i16)mvy; }
                             WAVE_SYNC();
                             for (int i = 0; i < 4; i++) {
@@ -1586,7 +2051,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 const int cost = me_search_ref16(c, L, mo, &s.l0mvc[r][0][0], i + 1, nullptr, vx, vy, cm);
                                 cache_set(2 * (i & 1), 2 * (i >> 1), 2, 2, r, vx, vy, 1);
                                 if (lane == 0) { s.l0mvc[r][i + 1][0] = (i16)vx; s.l0mvc[r][i + 1][1] = (i16)vy; }
-                                pme_put(i, vx, vy, cost + ref_cost + a.lambda, cm, r, ref_cost, px, py);
+                                pme_put(i, vx, vy, cost + ref_cost + Q.lambda, cm, r, ref_cost, px, py);
                             }
                             cost8x8 = pme(0, 2) + pme(1, 2) + pme(2, 2) + pme(3, 2);
                             if (a.cabac) cost8x8 -= ref_cost;
@@ -1620,7 +2085,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                         cache_set(x4, y4, sw, sh, r, vx, vy, 1);
                                         sum += cost;
                                     }
-                                    int cst = sum + refs.ref_cost[r] + a.lambda * (t == 0 ? 5 : 3);          // i_sub_mb_p_cost_table
+                                    int cst = sum + (Q.lambda * refs.ref_bits[r]) + Q.lambda * (t == 0 ? 5 : 3);          // i_sub_mb_p_cost_table
                                     if (a.chroma_me && a.subme >= 5) cst += sw_sub_chroma(s, refs, a, r, i, t, rec0, sub_mx, sub_my, satd, oc, bc_, lane);
                                     if (t == 0) {
                                         if (!(cst < pme(i, 2))) break;
@@ -1660,21 +2125,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                         aim(r, dir ? 8 : 16, dir ? 16 : 8, dir ? 8 * i : 0, dir ? 0 : 8 * i);
                                         c.mvpx = px; c.mvpy = py;
                                         LAUNDER(); c.lane = lane;
-                                        const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + refs.ref_cost[r];
+                                        const int cost = me_search_ref16(c, L, mo, &s.mvc[0][0], 3, nullptr, vx, vy, cm) + (Q.lambda * refs.ref_bits[r]);
                                         if (cost < bcost) { bcost = cost; bvx = vx; bvy = vy; bcm = cm; br = r; bpx = px; bpy = py; }
                                     }
                                     if (dir) cache_set(2 * i, 0, 2, 4, br, bvx, bvy, 1); else cache_set(0, 2 * i, 4, 2, br, bvx, bvy, 1);
-                                    pme_put(4 + 2 * dir + i, bvx, bvy, bcost, bcm, br, refs.ref_cost[br], bpx, bpy);
+                                    pme_put(4 + 2 * dir + i, bvx, bvy, bcost, bcm, br, (Q.lambda * refs.ref_bits[br]), bpx, bpy);
                                     sum += bcost;
                                 }
+                                if (dir) c8x16 = sum; else c16x8 = sum;
                                 if (sum < i_cost) { i_cost = sum; type = T_P_L0; part = dir ? 15 : 14; }
                             }
+                        c8x8 = cost8x8;
                     }
+                    };
                     // x264_me_refine_qpel on the winning partition (analyse.c:2289-2352); the reference cost leaves every block's sum (me.c:639-640)
+                    auto refine_winner = [&]() {
                     if (part == 16) {
                         aim(ref, 16, 16, 0, 0);
                         c.mvpx = bmvpx; c.mvpy = bmvpy;
-                        best -= refs.ref_cost[ref];
+                        best -= (Q.lambda * refs.ref_bits[ref]);
                         LAUNDER(); c.lane = lane;
                         best = me_refine_qpel16(c, L, mo, best, mvx, mvy);
                         i_cost = best;
@@ -1717,6 +2186,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             }
                         }
                     }
+                    };
+                    if constexpr (!RD) {
+                    search_partitions();
+                    refine_winner();
                     WAVE_SYNC();
                     if (part == 13) sub_t_mb = sub_t;
                     PROF(2);
@@ -1741,6 +2214,123 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (icost < i_cost) { i_cost = icost; type = itype; }
                     stat_intra = icost; analysed = 1;
                     stat_inter = i_cost;
+                    } else {
+                        // ---- the raster variant's P macroblock (analyse.c:2228-2405): the rest of the analysis, the RD candidates of
+                        // x264_mb_analyse_p_rd / x264_mb_analyse_transform_rd / x264_intra_rd, and the final encode, through ONE copy of
+                        // x264_rd_cost_mb: step 0 the early 16x16 trial (:1134-1143), 1 the analysis, 2-5 p_rd, 6 the transform, 7-9 intra, 10 final.
+                        const int me16x = mvx, me16y = mvy, me16r = ref;
+                        int rd16 = MX_COST_MAX, satd_inter = 0, satd_intra = 0, final_type = T_P_L0, final_part = 16, rd_thresh = 0, rd_isat = 0;
+                        bool rd_skip = false;
+                        // x264_analyse_update_cache for a P candidate (analyse.c:2803-2846): type / part -> s.mv4 / s.ref8 (and the 16x16 scalars)
+                        auto update_cache_p = [&]() {
+                            if (type == T_P_SKIP) return;                        // encode_pskip sets the skip vector itself
+                            const int bx4 = lane & 3, by4 = (lane >> 2) & 3, bx8 = lane & 1, by8 = (lane >> 1) & 1;
+                            const int slot = part == 14 ? 4 + (by4 >> 1) : part == 15 ? 6 + (bx4 >> 1) : (by4 >> 1) * 2 + (bx4 >> 1);
+                            const int slot8 = part == 14 ? 4 + by8 : part == 15 ? 6 + bx8 : by8 * 2 + bx8;
+                            int vx = __shfl(pme_v, slot * 8 + 0, 64), vy = __shfl(pme_v, slot * 8 + 1, 64), vr = __shfl(pme_v, slot8 * 8 + 4, 64);
+                            if (part == 16) { vx = me16x; vy = me16y; vr = me16r; }
+                            if (lane < 16) { s.mv4[lane][0] = (i16)vx; s.mv4[lane][1] = (i16)vy; }
+                            if (lane < 4) s.ref8[lane] = (signed char)vr;
+                            mvx = me16x; mvy = me16y; ref = me16r;
+                            WAVE_SYNC();
+                        };
+#pragma nounroll
+                        for (int step = 0; step < 11; step++) {
+                            if (step == 0) {
+                                if (!mbrd) continue;
+                                cache_fenc_satd();
+                                if (!(me16r == 0 && me16x == pskx && me16y == psky)) continue;
+                                type = T_P_L0; part = 16;
+                            } else if (step == 1) {
+                                if (rd_skip) { step = 9; continue; }
+                                type = T_P_L0;
+                                search_partitions();
+                                if (!mbrd) refine_winner();
+                                WAVE_SYNC();
+                                if (part == 13) sub_t_mb = sub_t;
+                                PROF(2);
+                                LAUNDER();
+                                final_type = type; final_part = part;
+                                if (a.chroma_me) {
+                                    analyse_chroma();
+                                    analyse_intra(i_cost - satd_chroma);
+                                    satd_i16 += satd_chroma; satd_i8 += satd_chroma; satd_i4 += satd_chroma;
+                                } else
+                                    analyse_intra(i_cost);
+                                satd_inter = i_cost; satd_intra = min(min(satd_i16, satd_i8), satd_i4);
+                                if (!mbrd) { step = 9; continue; }
+                                rd_isat = min(satd_inter, satd_intra); rd_thresh = rd_isat * 5 / 4;
+                                type = T_P_L0;
+                                continue;
+                            } else if (step == 2) {
+                                if (!(rd16 == MX_COST_MAX && best <= rd_isat * 3 / 2)) continue;
+                                part = 16;
+                            } else if (step == 3) {
+                                if (!(c16x8 <= rd_thresh)) { c16x8 = MX_COST_MAX; continue; }
+                                part = 14;
+                            } else if (step == 4) {
+                                if (!(c8x16 <= rd_thresh)) { c8x16 = MX_COST_MAX; continue; }
+                                part = 15;
+                            } else if (step == 5) {
+                                if (!(c8x8 <= rd_thresh)) { c8x8 = MX_COST_MAX; continue; }
+                                type = T_P_8x8; part = 13;
+                            } else if (step == 6) {
+                                final_type = T_P_L0; final_part = 16; i_cost = rd16;
+                                if (c16x8 < i_cost) { i_cost = c16x8; final_part = 14; }
+                                if (c8x16 < i_cost) { i_cost = c8x16; final_part = 15; }
+                                if (c8x8 < i_cost) { i_cost = c8x8; final_part = 13; final_type = T_P_8x8; }
+                                type = final_type; part = final_part;
+                                if (!(i_cost < MX_COST_MAX) || !a.transform8x8) continue;        // x264_mb_analyse_transform_rd, :2127-2150
+                                t8 = !t8;
+                            } else if (step == 7) {                                                // x264_intra_rd, :845-874
+                                if (!(satd_i16 <= satd_inter * 5 / 4)) { satd_i16 = MX_COST_MAX; continue; }
+                                type = T_I_16x16;
+                            } else if (step == 8) {
+                                if (!(satd_i4 <= satd_inter * 5 / 4 && satd_i4 < MX_COST_MAX)) { satd_i4 = MX_COST_MAX; continue; }
+                                type = T_I_4x4;
+                            } else if (step == 9) {
+                                if (!(satd_i8 <= satd_inter * 5 / 4 && satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; }
+                                type = T_I_8x8;
+                            } else {
+                                if (rd_skip) type = T_P_SKIP;
+                                else {
+                                    // analyse.c:2391-2404: best intra type (16x16, then 8x8, then 4x4, then PCM on strict improvement) against inter
+                                    int itype = T_I_16x16, icost = satd_i16;
+                                    if (satd_i8 < icost) { icost = satd_i8; itype = T_I_8x8; }
+                                    if (satd_i4 < icost) { icost = satd_i4; itype = T_I_4x4; }
+                                    if (satd_pcm < icost) { icost = satd_pcm; itype = T_I_PCM; }
+                                    type = final_type; part = final_part;
+                                    if (icost < i_cost) { i_cost = icost; type = itype; }
+                                    if (icost == MX_COST_MAX) icost = i_cost * satd_intra / satd_inter + 1;
+                                    stat_intra = icost; analysed = 1;
+                                    stat_inter = i_cost;
+                                    if (mbrd && !IS_INTRA_T(type)) update_cache_p();              // x264_analyse_update_cache, :2763
+                                }
+                                tq.on = rd.trellis != 0;                                          // :2768-2773
+                                if (rd.trellis == 1 || a.nr) skip_intra = 0;
+                                if (type != T_I_PCM) encode_mb(1);
+                                encoded = true;
+                                break;
+                            }
+                            if (!IS_INTRA_T(type)) update_cache_p();
+                            const int c = rd_cost_mb();
+                            if (step == 0) { rd16 = c; if (type == T_P_SKIP) rd_skip = true; }
+                            else if (step == 2) rd16 = c;
+                            else if (step == 3) c16x8 = c;
+                            else if (step == 4) c8x16 = c;
+                            else if (step == 5) c8x8 = c;
+                            else if (step == 6) {
+                                if (i_cost >= c) {
+                                    if (i_cost > 0) satd_inter = (int)((long long)satd_inter * c / i_cost);
+                                    if (satd_inter == 0) satd_inter = 1;
+                                    i_cost = c;
+                                } else
+                                    t8 = !t8;
+                            } else if (step == 7) satd_i16 = c;
+                            else if (step == 8) satd_i4 = c;
+                            else satd_i8 = c;
+                        }
+                    }
                 }
             }
         }
@@ -1749,87 +2339,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         LAUNDER();
 
         // ---- x264_analyse_update_cache + x264_macroblock_encode ----
-        int cbp_luma = 0, cbp_chroma = 0;
-        if (lane < 32) s.nnz[lane] = 0;
-        WAVE_SYNC();
-        if (type == T_P_SKIP) {
-            mvx = pskx; mvy = psky; ref = 0;
-            if (lane < 16) { s.mv4[lane][0] = (i16)pskx; s.mv4[lane][1] = (i16)psky; }
-            if (lane < 4) s.ref8[lane] = 0;
-            WAVE_SYNC();
-            if (!skip_mc) {
-                const int vx = clip3(mvx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
-                const int vy = clip3(mvy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
-                sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
+        if constexpr (!RD) encode_mb(1);
+        else if (!encoded) encode_pskip();                     // the fast / early P_SKIP exits of the analysis
+        const int intra = IS_INTRA_T(type);
+        int mb_qp = Q.qp, cbp_store = 0;
+        if constexpr (RD) {
+            if (type == T_I_PCM) {          // the samples themselves are sent: the reconstruction is the source (R/encoder/cabac.c:801-818)
+                *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)(s.fe + (lane >> 2) * 16 + (lane & 3) * 4);
+                s.fd[FDU + (lane >> 3) * FD + (lane & 7)] = s.fe[256 + lane]; s.fd[FDV + (lane >> 3) * FD + (lane & 7)] = s.fe[320 + lane];
+                cbp_luma = 0xf; cbp_chroma = 2; t8 = 0;
                 WAVE_SYNC();
             }
-        } else {
-            if (type == T_I_16x16) {
-                analyse_chroma();
-                sw_pred16(s, pred16, lane, a.lossless);
-                cbp_luma = sw_encode_i16x16(s, a, lane);
-                sw_pred8c(s, predc, lane, a.lossless);
-                cbp_chroma = sw_encode_chroma(s, a, 0, lane);
-            } else if (type == T_I_8x8 || type == T_I_4x4) {
-                // x264_analyse_update_cache: the winner's modes into the cache; then macroblock.c:527-590 with i_skip_intra:
-                // the analysis already encoded all blocks but the last, take its state and finish
-                const bool i8 = type == T_I_8x8;
-                if (lane < 16) s.i4c[sw_scan8(lane)] = i8 ? s.pred8[lane >> 2] : s.pred4[lane];
-                analyse_chroma();
-                *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)((i8 ? s.i8_fdec : s.i4_fdec) + lane * 4);
-                if (lane < 16) s.nnz[lane] = i8 ? s.i8_nnz[lane] : s.i4_nnz[lane];
-                cbp_luma = i8 ? i8_cbp : i4_cbp;
-                WAVE_SYNC();
-                if (i8) {
-                    t8 = 1;
-                    const int mode = __builtin_amdgcn_readfirstlane((int)s.pred8[3]), nb8 = sw_nb8(3, nb);
-                    // x264_pred_i4x4_neighbors (R/common/macroblock.h:40-54)
-                    const int need = mode == 0 || mode == 10 ? NB_TOP : mode == 1 || mode == 8 || mode == 9 ? NB_LEFT : mode == 2 ? NB_LEFT | NB_TOP
-                                   : mode == 3 || mode == 7 ? NB_TOP | NB_TOPRIGHT : mode == 11 ? 0 : NB_LEFT | NB_TOPLEFT | NB_TOP;
-                    if (lane == 0) pred8_filter(s.edge8, s.fd + FDY + 8 * FD + 8, FD, nb8, need);
-                    WAVE_SYNC();
-                    const int v = a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, 8 + (lane & 7), 8 + (lane >> 3)) : pred8_px(mode, s.edge8, lane & 7, lane >> 3);
-                    WAVE_SYNC();
-                    s.fd[FDY + (8 + (lane >> 3)) * FD + 8 + (lane & 7)] = (u8)v;
-                    WAVE_SYNC();
-                    sw_encode_i8x8(s, a, 3, cbp_luma, lane);
-                } else {
-                    u8 *dst = s.fd + FDY + 12 * FD + 12;
-                    const int mode = __builtin_amdgcn_readfirstlane((int)s.pred4[15]);
-                    if ((sw_nb4(15, nb) & (NB_TOPRIGHT | NB_TOP)) == NB_TOP && lane < 4) dst[4 - FD + lane] = dst[3 - FD];
-                    WAVE_SYNC();
-                    if (lane < 13) pred4_edges(s.e4, dst, FD, lane);
-                    WAVE_SYNC();
-                    if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = (u8)(a.lossless && mode < 2 ? sw_ll_px(s, 0, mode, 12 + (lane & 3), 12 + (lane >> 2))
-                                                                                                   : pred4_px(mode, s.e4, lane & 3, lane >> 2));
-                    WAVE_SYNC();
-                    sw_encode_i4x4(s, a, 15, cbp_luma, lane);
-                }
-                sw_pred8c(s, predc, lane, a.lossless);
-                cbp_chroma = sw_encode_chroma(s, a, 0, lane);
-            } else {
-                sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
-                WAVE_SYNC();
-                // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
-                if (a.transform8x8 && !a.lossless && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
-                    // x264_mb_analyse_transform (R/encoder/analyse.c:2109-2126): SA8D against SATD of the 16x16 prediction error
-                    int raw = 0;
-                    if (lane < 32) {
-                        const int blk = lane >> 3, r = lane & 7;
-                        raw = sw_sa8d_rows(s.fe + ((blk >> 1) * 8 + r) * 16 + (blk & 1) * 8, s.fd + FDY + ((blk >> 1) * 8 + r) * FD + (blk & 1) * 8, lane);
+            // ---- the entropy coder, where x264_slice_write has it (R/encoder/encoder.c:1192-1205) ----
+            if (rd.write) {
+                syn_prepare();
+                const MbSynDev y0 = make_syn();
+                if (lane == 0) {
+                    if (mb > 0) cd_encode_terminal(cab);
+                    if (type == T_P_SKIP) cw_mb_skip(cab, sr.cabac, left_type, type_top, 1);
+                    else {
+                        if (is_p) cw_mb_skip(cab, sr.cabac, left_type, type_top, 0);
+                        MbSynDev y = y0;
+                        cw_macroblock(cab, sr.cabac, 0, y, s.fe, rd.i_frame);
+                        sr.tmp_i[1] = y.qp;
                     }
-                    const int c8 = (__builtin_amdgcn_readlane(raw, 0) + __builtin_amdgcn_readlane(raw, 8) + __builtin_amdgcn_readlane(raw, 16)
-                                    + __builtin_amdgcn_readlane(raw, 24) + 2) >> 2;
-                    const int c4 = sw_cmp_luma16(s, 1, lane);
-                    t8 = c8 < c4;
+                    if (rd.mb_bits) rd.mb_bits[cb + mb] = cd_pos(cab, payload0);
                 }
-                if (a.nr) { if (t8) nr_n8 += 4; else nr_n4 += 16; }
-                cbp_luma = t8 ? sw_encode_inter_luma8(s, a, lane, &nr_acc8, a.nr) : sw_encode_inter_luma(s, a, lane, &nr_acc4, a.nr);   // never a conditional pointer: that pins the counter in scratch memory
-                cbp_chroma = sw_encode_chroma(s, a, 1, lane);
-                if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
+                WAVE_SYNC();
+                if (type != T_P_SKIP) mb_qp = UNI(sr.tmp_i[1]);
+            }
+            // x264_macroblock_cache_save's QP rules (R/common/macroblock.c:1244-1272): a macroblock without coefficients has no QP of its own
+            if (type == T_I_PCM) { mb_qp = 0; last_dqp = 0; if (lane < 27) s.nnz[lane] = 16; WAVE_SYNC(); }
+            else {
+                if (type != T_I_16x16 && cbp_luma == 0 && cbp_chroma == 0) mb_qp = last_qp;
+                last_dqp = mb_qp - last_qp; last_qp = mb_qp;
             }
         }
-        const int intra = IS_INTRA_T(type);
         if (cbp_luma == 0 && type != T_I_8x8) t8 = 0;           // x264_macroblock_cache_save, R/common/macroblock.c:1273-1275
         PROF(3);
         LAUNDER();
@@ -1865,13 +2410,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             (a.partition + cb)[mb] = (signed char)(intra || type == T_P_SKIP ? 16 : part);
             (a.i16mode + cb)[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
             (a.chroma_mode + cb)[mb] = (signed char)(intra ? predc : 0);
-            (a.qp_out + cb)[mb] = (signed char)a.qp;
+            (a.qp_out + cb)[mb] = (signed char)mb_qp;
             (a.t8 + cb)[mb] = (signed char)t8;
-            (a.cbp + cb)[mb] = (i16)(type == T_P_SKIP ? 0 : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
+            (a.cbp + cb)[mb] = (i16)(type == T_P_SKIP ? 0 : type == T_I_PCM ? 0x72f : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
             (a.cost_intra + cb)[mb] = stat_intra; (a.cost_inter + cb)[mb] = stat_inter; (a.cost_alt + cb)[mb] = stat_alt;
         }
         {   // coefficient levels, masked by what the entropy coder reads (cbp, then nnz)
-            const bool coded = type != T_P_SKIP;
+            const bool coded = type != T_P_SKIP && type != T_I_PCM;
             i16 *ly = (a.luma + 256 * cb) + (size_t)mb * 256, *cac = (a.chroma_ac + 128 * cb) + (size_t)mb * 128;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1886,25 +2431,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (lane < 16) (a.luma_dc + 16 * cb)[(size_t)mb * 16 + lane] = (coded && type == T_I_16x16 && s.nnz[24]) ? s.lv_dc[lane] : (i16)0;
             if (lane < 8) (a.chroma_dc + 8 * cb)[(size_t)mb * 8 + lane] = (coded && cbp_chroma && s.nnz[25 + (lane >> 2)]) ? s.lv_cdc[lane] : (i16)0;
         }
+        if constexpr (RD) {     // what the next macroblock's entropy coding reads of this one (kept in LDS / registers), and mvd for the row below
+            const int cbp_dc = s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2;
+            cbp_store = type == T_P_SKIP ? 0 : type == T_I_PCM ? 0x72f : (UNI(cbp_dc) << 8) | (cbp_chroma << 4) | cbp_luma;
+            const bool keep = !intra && type != T_P_SKIP;
+            if (lane < 16) {
+                const int k = 12 + (lane & 3) + 8 * (lane >> 2);
+                i16 *mvd = rd.mvd + ((cb + mb) * 16 + lane) * 2;
+                mvd[0] = keep ? sr.cmvd[k][0] : (i16)0; mvd[1] = keep ? sr.cmvd[k][1] : (i16)0;
+                if ((lane & 3) == 3) { sr.left_mvd[lane >> 2][0] = mvd[0]; sr.left_mvd[lane >> 2][1] = mvd[1]; }
+            } else if (lane < 24) {
+                const int j = lane - 16;
+                const int idx = j < 4 ? (j == 0 ? 5 : j == 1 ? 7 : j == 2 ? 13 : 15) : 16 + 4 * ((j - 4) >> 1) + 1 + 2 * (j & 1);
+                sr.left_nz[j] = type == T_P_SKIP ? (u8)0 : s.nnz[idx];
+            }
+            left_cbp = cbp_store; left_cpm = intra && type != T_I_PCM ? sw_fix8c(predc) : 0; left_t8 = t8;
+            prev_coded = type == T_I_16x16 || (cbp_store & 0x3f);
+            intra_before += intra;
+            WAVE_SYNC();
+        }
         left_type = type;
         left_ref = is_p ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);
         PROF(4);
         LAUNDER();
+        if constexpr (!RD) {
         // ---- publish: everything this macroblock wrote is visible before the count moves ----
         __threadfence();
         __builtin_amdgcn_wave_barrier();
         row_intra += intra;
         if (lane == 0) __hip_atomic_store(prog + mby, (mbx + 1) | (row_intra << 16), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         PROF(5);
+    }
+    if (a.prof && lane < 8) {
+        long long v = lane == 0 ? pacc[0] : lane == 1 ? pacc[1] : lane == 2 ? pacc[2] : lane == 3 ? pacc[3] : lane == 4 ? pacc[4] : lane == 5 ? pacc[5] : lane == 6 ? pacc[6] : pacc[7];
+        a.prof[((size_t)bz * a.mb_h + mby) * 8 + lane] = v;
+    }
+  }   // rows
+    if constexpr (RD) {     // x264_slice_write's end (R/encoder/encoder.c:1269-1273)
+        if (rd.write && lane == 0) { cd_encode_flush(cab, rd.i_frame); rd.payload_len[bz] = (int)(cab.p - payload0); }
     }
     if (a.nr) {
         if (lane >= 1 && lane < 16 && nr_acc4) atomicAdd(a.nr_sum + (size_t)bz * 128 + lane, (u32)nr_acc4);
         if (lane >= 1 && nr_acc8) atomicAdd(a.nr_sum + (size_t)bz * 128 + 64 + lane, (u32)nr_acc8);
         if (lane == 0 && (nr_n4 | nr_n8)) { atomicAdd(a.nr_count + (size_t)bz * 2, (u32)nr_n4); atomicAdd(a.nr_count + (size_t)bz * 2 + 1, (u32)nr_n8); }
-    }
-    if (a.prof && lane < 8) {
-        long long v = lane == 0 ? pacc[0] : lane == 1 ? pacc[1] : lane == 2 ? pacc[2] : lane == 3 ? pacc[3] : lane == 4 ? pacc[4] : lane == 5 ? pacc[5] : lane == 6 ? pacc[6] : pacc[7];
-        a.prof[((size_t)bz * a.mb_h + mby) * 8 + lane] = v;
     }
 #undef PROF
 #undef LAUNDER
@@ -1953,7 +2523,7 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
         {(void **)&st->mv, 64 * n}, {(void **)&st->mvr, 4 * SW_MAX_REFS * n}, {(void **)&st->cbp, 2 * n}, {(void **)&st->nnz, 27 * n},
         {(void **)&st->luma, 512 * n}, {(void **)&st->luma_dc, 32 * n}, {(void **)&st->chroma_dc, 16 * n}, {(void **)&st->chroma_ac, 256 * n},
         {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n}, {(void **)&st->cost_intra_alt, 4 * n},
-        {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}};
+        {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}, {(void **)&st->mvd, 64 * n}};
     for (auto &it : items) {
         HIPCHK(hipMalloc(it.p, it.bytes));
         HIPCHK(hipMemsetAsync(*it.p, 0, it.bytes, c->stream));
@@ -1964,7 +2534,7 @@ extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st
 {
     (void)c;
     void *ps[] = {st->mb_type, st->partition, st->sub_partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
-                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress};
+                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress, st->mvd};
     for (void *p : ps) if (p) (void)hipFree(p);
     memset(st, 0, sizeof(*st));
 }
@@ -2019,7 +2589,20 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (p->slice_type != 0 && p->slice_type != 2) { set_error("slice_sweep: slice type %d not built (0 P, 2 I)", p->slice_type); return -1; }
     if (is_p && (n_refs < 1 || n_refs > SW_MAX_REFS)) { set_error("slice_sweep: %d references (1..%d)", n_refs, SW_MAX_REFS); return -1; }
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
-    if (p->subme < 0 || p->subme > 5) { set_error("slice_sweep: subme %d needs RD, not built", p->subme); return -1; }
+    const x264hip_slice_rd *prd = p->rd;
+    const int mbrd = (p->subme >= 6) + (p->subme >= 8);
+    if (p->subme < 0 || p->subme > 7) { set_error("slice_sweep: subme %d (RD refinement of vectors and intra modes) not built", p->subme); return -1; }
+    if (mbrd && (!prd || !prd->write || !p->cabac)) { set_error("slice_sweep: subme %d prices its trial encodes against the live CABAC contexts: it needs x264hip_slice_params.rd with write = 1 and cabac = 1", p->subme); return -1; }
+    if (prd) {
+        if (prd->write && !p->cabac) { set_error("slice_sweep: the in-loop entropy coder is CABAC only"); return -1; }
+        if (prd->write && (!prd->payload || !prd->payload_len || prd->payload_cap < 4096)) { set_error("slice_sweep: payload buffers missing"); return -1; }
+        if (prd->trellis && (!prd->write || !prd->unquant4_mf || (p->transform8x8 && !prd->unquant8_mf))) { set_error("slice_sweep: trellis needs write = 1 and the unquant tables"); return -1; }
+        if (prd->trellis < 0 || prd->trellis > 2) { set_error("slice_sweep: trellis %d", prd->trellis); return -1; }
+        if (prd->aq_offset && !prd->cost_mv_all) { set_error("slice_sweep: adaptive quantisation needs cost_mv_all"); return -1; }
+        if (p->lossless) { set_error("slice_sweep: lossless is not built in the raster variant"); return -1; }
+        if (mbrd && (p->analyse_inter & 0x20)) { set_error("slice_sweep: sub-8x8 partitions with the RD levels (x264_rd_cost_part) not built"); return -1; }
+        if (!out->mvd) { set_error("slice_sweep: mb_state without mvd"); return -1; }
+    }
     if (p->me_method < 0 || p->me_method > 3) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX, 2 UMH, 3 ESA)", p->me_method); return -1; }
     if (p->me_method == 3 && p->subme < 1) { set_error("slice_sweep: ESA at subme 0 is undefined in the reference (it never fills the integral plane there, encoder.c:1009 / mc.c:431)"); return -1; }
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
@@ -2040,7 +2623,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         int x = (n_refs <= 0 ? 1 : n_refs) - 1; x = x > 2 ? 2 : x;
         // REF_COST: lambda * bs_size_te(x, i), R/encoder/analyse.c:195-197
         int bits = x == 1 ? 1 : x > 1 ? (i == 0 ? 1 : i < 3 ? 3 : i < 7 ? 5 : 7) : 0;
-        t.ref_cost[i] = a.lambda * bits;
+        t.ref_bits[i] = bits;
         t.poc_delta[i] = i < n_refs ? p->poc - p->ref_poc[i] : 0;
         t.l0_inv_ref_poc[i] = l0 ? l0->inv_ref_poc[i] : 0;
     }
@@ -2084,14 +2667,27 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         wpe = e ? atoi(e) : 3;                                       // 3 waves/SIMD (168 VGPRs, 12 waves per CU with 13 KB of LDS each): measured best
         if (wpe < 1 || wpe > 3) wpe = 3;
     }
+    SwRd r;
+    memset(&r, 0, sizeof(r));
+    if (prd) {
+        r.on = 1; r.mbrd = mbrd; r.trellis = p->cabac ? prd->trellis : 0; r.psy_rd = mbrd ? prd->psy_rd : 0;
+        r.write = prd->write; r.cabac_init_idc = prd->cabac_init_idc; r.i_frame = prd->i_frame;
+        r.aq = prd->aq_offset != nullptr; r.qp_min = prd->qp_min; r.qp_max = prd->qp_max; r.chroma_qp_offset = p->chroma_qp_offset;
+        r.f_qpm = prd->f_qpm; r.aq_offset = prd->aq_offset; r.cost_mv_all = prd->cost_mv_all;
+        r.unq4 = prd->unquant4_mf; r.unq8 = prd->unquant8_mf;
+        r.payload = prd->payload; r.payload_cap = prd->payload_cap; r.payload_len = prd->payload_len; r.mb_bits = prd->mb_bits;
+        r.mvd = out->mvd;
+        hipLaunchKernelGGL((k_slice_sweep<2, false, true>), dim3((unsigned)a.batch), dim3(64), 0, c->stream, a, t, r);
+    } else {
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
     switch (a.lossless ? 0 : wpe) {
-    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t); break;
-    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t); break;
-    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t); break;
-    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t); break;
+    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t, r); break;
+    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t, r); break;
+    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t, r); break;
+    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t, r); break;
     }
-    if (is_p && a.flags_intra)
+    }
+    if (!prd && is_p && a.flags_intra)
         hipLaunchKernelGGL(k_resolve_fast_intra, dim3(c->batch), dim3(64), 0, c->stream, (const signed char *)out->mb_type, out->cost_intra,
                            (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
     HIPCHK(hipGetLastError());

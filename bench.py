@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the per-macroblock hot loop on 1..N MI355X.
 
-A "step" advances B independent GOP chains by one 1920x1080 frame each; the source frames are
-already resident in HBM.  Per step and chain the GPU does what x264_slice_write +
-x264_fdec_filter_row do for one frame (R/encoder/encoder.c:1141-1291, 983-1056):
+A "step" advances B independent closed-GOP chains by one 1920x1080 frame each; the source frames are already resident in HBM.
+Per step and chain the GPU does what x264_slice_write + x264_fdec_filter_row do for one frame (R/encoder/encoder.c:1141-1291,
+983-1056):
 
-  x264hip_slice_sweep_frame  cache_load -> x264_macroblock_analyse -> x264_macroblock_encode ->
-                             cache_save for all 8160 macroblocks (one wavefront per macroblock row,
-                             2:1 wavefront order), all B chains in one launch
-  x264hip_deblock_frame      x264_frame_deblock_row for every row
-  x264hip_expand_border, x264hip_hpel_filter_frame   the frame becomes a reference
+  x264hip_adaptive_quant_frame   x264_adaptive_quant_frame: per-macroblock QP offsets from the source's AC energy
+  x264hip_slice_sweep_frame      raster-order variant (x264hip_slice_rd): cache_load -> x264_macroblock_analyse (RD mode decision,
+                                 subme 7) -> x264_macroblock_encode (trellis 1) -> x264_macroblock_write_cabac -> cache_save for all
+                                 8160 macroblocks, one wavefront per chain; the slice's CABAC payload comes out of the same launch
+  x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   the frame becomes a reference
 
-with the analysis options named in config.workload (the part of the medium preset built so far:
-hex ME (or --me 0/2: dia / umh), subme 5, 3 references, mixed refs, P 16x16/16x8/8x16/8x8, I 16x16/8x8/4x4, 8x8 transform,
-chroma ME, fast P-skip, decimation, CABAC-side cbp; every frame I or P; CQP).  Every decision, level and pixel of this loop is bit-exact against the reference's own
-functions (tests/test_gpu_slice.py); entropy coding stays on the host and is not timed.
+Default options = BASELINE.md's MED flag set as far as it is built: --ref 3 --me hex --subme 7 --8x8dct --partitions p8x8,i8x8,i4x4
+--trellis 1 --mixed-refs, psy-rd 1.0, aq-mode 1, CABAC, deblock -- at CONSTANT QP (CRF needs the lookahead) and with I/P slices
+only (B slices are not built yet): config.matches_baseline is false and config.missing lists what is left.  Every decision, level,
+pixel and payload byte of this loop is bit-exact against the reference's own functions (tests/test_gpu_slice_rd.py).
+--wavefront 1 selects round 1's configuration instead (subme 5, no RD / trellis / AQ / entropy coding; one wavefront per macroblock row).
 
 Chains shard across ranks with no data-path collective (closed GOPs); scaling is weak.
 One JSON line on stdout (rank 0).  Launch for N > 1:
@@ -50,51 +51,92 @@ def analysis_options(args):
                 mixed_refs=args.mixed_refs)
 
 
-def cpu_baseline(args):
-    """The same loop on one host core: the REFERENCE's own x264_macroblock_cache_load / _analyse /
-    _encode / _cache_save + x264_frame_deblock_row + x264_frame_filter, compiled from the reference's
-    sources where they lie (oracle/_ref/libx264ref.so via oracle/ref_slice.c); our restatement
-    (liboracle.so) when that library is not there.  A bounded chain of whole frames."""
+def rd_options(args):
+    """What the raster-order variant adds (x264hip_slice_rd)."""
+    return dict(trellis=args.trellis, psy_rd=args.psy_rd, aq_mode=args.aq_mode, aq_strength=1.0)
+
+
+def _cpu_chain(job):
+    """One chain through the reference's loop on one core (own process: the reference keeps process-global tables)."""
+    import time as _t
     from oracle import refslice as rs
+    width, height, n, kw, ekw, raster, seed = job
+    y, u, v = rs.clip(width, height, n, t0=seed)
+    p = rs.make_params(width, height, n, **kw)
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
-    n = args.cpu_frames
-    y, u, v = rs.clip(args.width, args.height, n)
-    p = rs.make_params(args.width, args.height, n, **analysis_options(args))
+    t0 = _t.perf_counter()
     if os.path.exists(ref_so):
-        lib, fn, kind = rs.reference_lib(), "refslice_encode_chain", "reference"
+        if raster:
+            rs.run_reference2(p, rs.make_ext(**ekw), y, u, v)
+        else:
+            rs.run_reference(p, y, u, v)
+        kind = "reference"
     else:
-        lib, fn, kind = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so")), "x264o_encode_chain", "port"
-    t0 = time.perf_counter()
-    rs.run(lib, fn, p, y, u, v)
-    spent = time.perf_counter() - t0
-    return {"value": round(n / spent, 4), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "one chain of %d %dx%d frames through the same per-macroblock loop, same options (%.1f s of CPU; C compiled -O3, "
-                      "no asm, no entropy coding on either side)" % (n, args.width, args.height, spent)}
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        if raster:
+            rs.run2(lib, "x264o_encode_chain2", p, rs.make_ext(**ekw), y, u, v)
+        else:
+            rs.run(lib, "x264o_encode_chain", p, y, u, v)
+        kind = "port"
+    return _t.perf_counter() - t0, kind
+
+
+def cpu_baseline(args):
+    """The same loop on the host cores: the REFERENCE's own x264_macroblock_cache_load / _analyse / _encode / _write_cabac /
+    _cache_save + x264_frame_deblock_row + x264_frame_filter, compiled from the reference's sources where they lie
+    (oracle/_ref/libx264ref.so via oracle/ref_slice.c); our restatement (liboracle.so) when that library is not there.  Measured
+    twice on a bounded chain of whole frames: one process on one core, and one process per host core (each its own chain)."""
+    import multiprocessing as mp
+    n = args.cpu_frames
+    kw, ekw, raster = analysis_options(args), rd_options(args), not args.wavefront
+    spent1, kind = _cpu_chain((args.width, args.height, n, kw, ekw, raster, 0))
+    cores = max(1, min(os.cpu_count() or 1, args.cpu_procs or (os.cpu_count() or 1)))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_chain, [(args.width, args.height, n, kw, ekw, raster, 11 * i) for i in range(cores)], chunksize=1)
+    spent_all = max(r[0] for r in res)                # the chains run side by side: the slowest one's encode time (clip synthesis is not counted)
+    return {"value": round(cores * n / spent_all, 4), "unit": "frames/s", "cores": cores, "kind": kind,
+            "one_core": round(n / spent1, 4),
+            "sample": "the same per-macroblock loop with the same options on chains of %d %dx%d frames: one chain on one core (%.1f s), "
+                      "then %d processes, one chain each, on the %d host cores (%.1f s); C compiled -O3, no asm%s"
+                      % (n, args.width, args.height, spent1, cores, cores, spent_all, ", entropy coding included" if raster else ", no entropy coding on either side")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=240, help="independent GOP chains advanced per step on each GPU "
-                    "(240 x 68 macroblock rows = 16320 row waves for 2048 wave slots at 2 waves/SIMD: 8.5 slots per chain, so the "
-                    "68 rows of a frame go through in 8 full generations; later rows take the slots of finished ones)")
+    ap.add_argument("--steps", type=int, default=0, help="0: 12 (raster variant) / 24 (--wavefront 1)")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1: 2 (raster variant) / 3 (--wavefront 1)")
+    ap.add_argument("--batch", type=int, default=0, help="independent GOP chains advanced per step on each GPU; 0: 1792 for the raster "
+                    "variant (one wavefront per chain: 7 per CU, what its LDS footprint allows), 240 with --wavefront 1")
+    ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
+    ap.add_argument("--trellis", type=int, default=1)
+    ap.add_argument("--psy-rd", type=float, default=1.0)
+    ap.add_argument("--aq-mode", type=int, default=1)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0: one per host core)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=26)
     ap.add_argument("--refs", type=int, default=3)
-    ap.add_argument("--subme", type=int, default=5)
+    ap.add_argument("--subme", type=int, default=0, help="0: 7 (raster variant) / 5 (--wavefront 1)")
     ap.add_argument("--me", type=int, default=1, help="param.analyse.i_me_method: 0 dia, 1 hex (the medium preset), 2 umh")
-    ap.add_argument("--keyint", type=int, default=24)
+    ap.add_argument("--keyint", type=int, default=0, help="0: 12 (raster variant) / 24 (--wavefront 1)")
     ap.add_argument("--inter", type=lambda v: int(v, 0), default=0x13, help="param.analyse.inter: X264_ANALYSE_I4x4 0x1 | I8x8 0x2 | PSUB16x16 0x10 | "
                     "PSUB8x8 0x20 (the medium preset's p8x8 = 0x10; 0x33 adds p4x4 / p8x4 / p4x8)")
     ap.add_argument("--mixed-refs", type=int, default=1, help="param.analyse.b_mixed_references")
     ap.add_argument("--intra", type=lambda v: int(v, 0), default=0x3, help="param.analyse.intra")
     ap.add_argument("--dct8", type=int, default=1, help="param.analyse.b_transform_8x8")
-    ap.add_argument("--cpu-frames", type=int, default=40)
+    ap.add_argument("--cpu-frames", type=int, default=0, help="0: 12 (raster variant) / 40 (--wavefront 1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    wf = bool(args.wavefront)
+    args.steps = args.steps or (24 if wf else 12)
+    args.warmup = args.warmup if args.warmup >= 0 else (3 if wf else 2)
+    args.batch = args.batch or (240 if wf else 1792)
+    args.subme = args.subme or (5 if wf else 7)
+    args.keyint = args.keyint or (24 if wf else 12)
+    args.cpu_frames = args.cpu_frames or (40 if wf else 12)
+    if wf:
+        args.trellis, args.psy_rd, args.aq_mode = 0, 0.0, 0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,14 +156,15 @@ def main():
         raise SystemExit("bench.py: no MI355X visible to libx264hip.so (there is no CPU fallback)")
     hip = L.load(local % ndev)                       # one rank per GPU; wraps only when rehearsing on fewer GPUs
     B = args.batch
-    enc = sl.ChainEncoder(hip, args.width, args.height, load_cqm(), batch=B, **analysis_options(args))
+    ropt = {} if wf else dict(write=1, **rd_options(args))
+    enc = sl.ChainEncoder(hip, args.width, args.height, load_cqm(), batch=B, **analysis_options(args), **ropt)
     ctx = enc.ctx
     d = ctx.dims
     px = d.mb_w * 16 * d.lines_y
 
     # resident working set: a ring of source pictures, each holding one frame of every chain.  Chains and
     # steps see different frames of the synthetic clip (rank-dependent offset).
-    n_src, pool_n = 8, 16
+    n_src, pool_n = (8, 16) if wf else (3, 8)
     pool = [synth.frame(args.width, args.height, rank * 97 + i) for i in range(pool_n)]
     srcs = []
     for i in range(n_src):
@@ -174,9 +217,10 @@ def main():
     # HBM-side traffic of one P sweep launch: not measurable from inside this process (PMC counters need rocprofv3), so the
     # figure is the committed rocprofv3 measurement of this very configuration, and null for any other configuration
     traffic, traffic_note = None, "no rocprofv3 PMC measurement committed for this configuration"
-    tpath = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
-    defaults = (args.width, args.height, args.qp, args.subme, args.me, args.keyint, args.inter, args.intra, args.dct8, args.mixed_refs) == \
-               (1920, 1080, 26, 5, 1, 24, 0x13, 0x3, 1, 1)
+    tname = "r01_sweep_traffic.json" if wf else "r02_raster_traffic.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    defaults = (args.width, args.height, args.qp, args.me, args.inter, args.intra, args.dct8, args.mixed_refs) == (1920, 1080, 26, 1, 0x13, 0x3, 1, 1) and \
+               (args.subme, args.keyint) == ((5, 24) if wf else (7, 12)) and (wf or (args.trellis, args.psy_rd, args.aq_mode) == (1, 1.0, 1))
     if defaults and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
@@ -184,34 +228,51 @@ def main():
         if hit and tj["batch"] == B:
             traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
             traffic_note = ("FETCH_SIZE + WRITE_SIZE of one P launch with %d references (the most frequent launch of the timed region), rocprofv3 --pmc, "
-                            "separate passes, raw request-granular counters (profiles/r01_sweep_traffic.json)" % args.refs)
+                            "separate passes, raw request-granular counters (profiles/%s)" % (args.refs, tname))
 
     if rank == 0:
         fps = world * B * args.steps / dt
         frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)       # + deblock read/write + hpel planes
         n_i = sum(1 for e in enc.events if e[2] == sl.SLICE_I)
+        if wf:
+            metric = "I/P macroblock-loop frames/sec, 1080p, medium minus {B-frames, RD (subme 7 -> 5), trellis, AQ, entropy coding} (round-1 configuration, bit-exact)"
+            what = ("%dx%d I/P chains through the reference's per-macroblock loop on the GPU, wavefront schedule (one wavefront per macroblock row): "
+                    "%s ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; analyse.inter 0x%x intra 0x%x 8x8dct %d "
+                    "mixed-refs %d; no RD, no trellis, no AQ; entropy coding not done" % (args.width, args.height, ME_NAMES[args.me], args.subme, args.refs,
+                                                                                       args.qp, args.keyint, args.inter, args.intra, args.dct8, args.mixed_refs))
+            missing = ["B slices (--bframes 3 --b-adapt 1 --weightb --direct spatial)", "RD mode decision (subme 7)", "trellis 1", "psy-rd", "aq-mode 1",
+                       "CRF rate control", "lookahead / scenecut", "entropy coding"]
+            par = "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); chains shard across GPUs with no data-path collective"
+        else:
+            metric = ("encoded frames/sec, 1080p, I/P slices with preset=medium's analysis (subme 7 RD, trellis 1, psy-rd, aq-mode 1, CABAC payload on the GPU) "
+                      "at constant QP; B slices, CRF and lookahead not built yet; 1/2/4/8 MI355X (bit-exact)")
+            what = ("%dx%d I/P chains through the reference's per-macroblock loop on the GPU, raster order (one wavefront per chain): cache_load, "
+                    "x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, x264_macroblock_write_cabac (the slice payload is produced "
+                    "by the same launch), cache_save, then deblock, borders, half-pel planes; --ref %d --me %s --subme %d --trellis %d --psy-rd %.1f "
+                    "--aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x, chroma ME, fast P-skip, dct-decimate, CABAC, CQP %d, keyint %d"
+                    % (args.width, args.height, args.refs, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs,
+                       args.inter, args.intra, args.qp, args.keyint))
+            missing = ["B slices (--bframes 3 --b-adapt 1 --weightb --direct spatial): about 3/4 of a medium encode's frames",
+                       "CRF rate control (--crf 23): constant QP %d + adaptive quantisation here" % args.qp, "lookahead (b-adapt, scenecut, lowres motion candidates)",
+                       "slice / NAL headers around the payload"]
+            par = ("B closed-GOP chains per GPU in every launch, one wavefront per chain walking its frame in raster order (the RD levels, trellis and AQ "
+                   "make a slice one serial chain of macroblocks); chains shard across GPUs with no data-path collective")
         line = {
-            "metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
+            "metric": metric,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d I/P chains through the reference's per-macroblock loop on the GPU (cache_load, "
-                                   "x264_macroblock_analyse, x264_macroblock_encode, cache_save, deblock, borders, half-pel planes): "
-                                   "%s ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; "
-                                   "analyse.inter 0x%x intra 0x%x 8x8dct %d mixed-refs %d; macroblock types built so far: I_16x16 / "
-                                   "I_8x8 / I_4x4 / P_L0 16x16, 16x8, 8x16 / P_8x8 / P_SKIP (the medium preset minus B-frames, RD "
-                                   "(subme 7 -> 5) and trellis); entropy coding on the host, not timed"
-                                   % (args.width, args.height, ME_NAMES[args.me], args.subme, args.refs, args.qp, args.keyint, args.inter, args.intra, args.dct8,
-                                      args.mixed_refs),
-                       "frames_per_step": B, "i_frames_in_timed_steps": n_i,
-                       "parallelism": "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); "
-                                      "chains shard across GPUs with no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_slice_sweep", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "config": {"workload": what, "matches_baseline": False, "missing": missing,
+                       "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
+                       "frames_per_step": B, "i_frames_in_timed_steps": n_i, "parallelism": par},
+            "roofline": {"bound": "hbm", "kernel": "k_slice_sweep" + ("" if wf else "<raster>"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
-                         "note": "mean over the timed launches (P with 1..R references and the I launch at the keyint); the sweep is bound by dependent memory round trips along the macroblock "
-                                 "dependency chain (mb_w + 2*mb_h = %d serial macroblock steps per frame; PMC: waves wait ~69%% of their "
-                                 "cycles), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w + 2 * d.mb_h - 2, frame_bytes, frame_bytes * (fps / world) / 1e9)},
+                         "note": "mean over the timed launches (P with 1..R references and the I launch at the keyint); the sweep is bound by the serial "
+                                 "macroblock chain of a slice (%s), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps"
+                                 % ("mb_w + 2*mb_h = %d dependent steps per frame" % (d.mb_w + 2 * d.mb_h - 2) if wf else
+                                    "%d macroblocks one after the other per frame, %d frames in flight" % (d.mb_w * d.mb_h, B),
+                                    frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(args)

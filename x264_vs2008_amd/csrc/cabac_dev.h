@@ -26,6 +26,26 @@ typedef uint8_t u8; typedef int16_t i16; typedef uint16_t u16; typedef uint32_t 
 
 #include "mbsyn.h"
 
+// The coder's tables are read once or twice per bin by a single lane: from global memory that is two dependent ~500-cycle round trips
+// per bin.  On the device they therefore live in LDS (cd_load_tables fills them once per kernel): entropy and next state of
+// (state, bin) packed in one word, the four LPS ranges of a state in another.
+#ifdef X264HIP_HOST_TEST
+#define CD_ENT(s_, b_) ((int)d_cabac_entropy[s_][b_])
+#define CD_TRANS(s_, b_) ((int)d_cabac_transition[s_][b_])
+#define CD_LPS(s_, i_) ((int)d_cabac_range_lps[s_][i_])
+#define CD_SIG8(i_) ((int)d_cw_sig8[i_])
+#define CD_LAST8(i_) ((int)d_cw_last8[i_])
+#else
+static __shared__ u32 cd_lds_et[256];        // [state * 2 + bin]: entropy | next state << 16
+static __shared__ u32 cd_lds_lps[128];       // [state]: range_lps[0..3], one byte each
+static __shared__ u8 cd_lds_sig8[64], cd_lds_last8[64];
+#define CD_ENT(s_, b_) ((int)(cd_lds_et[(s_) * 2 + (b_)] & 0xffffu))
+#define CD_TRANS(s_, b_) ((int)(cd_lds_et[(s_) * 2 + (b_)] >> 16))
+#define CD_LPS(s_, i_) ((int)((cd_lds_lps[s_] >> (8 * (i_))) & 255u))
+#define CD_SIG8(i_) ((int)cd_lds_sig8[i_])
+#define CD_LAST8(i_) ((int)cd_lds_last8[i_])
+#endif
+
 enum { CD_I_4x4 = 0, CD_I_8x8 = 1, CD_I_16x16 = 2, CD_I_PCM = 3, CD_P_L0 = 4, CD_P_8x8 = 5, CD_P_SKIP = 6 };
 enum { CD_D_L0_4x4 = 0, CD_D_L0_8x4 = 1, CD_D_L0_4x8 = 2, CD_D_L0_8x8 = 3, CD_D_8x8 = 13, CD_D_16x8 = 14, CD_D_8x16 = 15, CD_D_16x16 = 16 };
 
@@ -62,16 +82,16 @@ CD_FN void cd_putbyte(DCabac &cb)
 }
 CD_FN void cd_renorm(DCabac &cb)
 {
-    const int shift = d_cabac_renorm_shift[cb.range >> 3];
+    const int shift = __builtin_clz((unsigned)(((cb.range >> 3) << 1) | 1)) - 25;     // x264_cabac_renorm_shift[range >> 3], as arithmetic
     cb.range <<= shift; cb.low <<= shift; cb.queue += shift;
     cd_putbyte(cb);
 }
 template <class ST> CD_FN void cd_encode_decision(DCabac &cb, ST st, int ctx, int b)
 {   // x264_cabac_encode_decision_c, :861-873
-    const int s = st[ctx], lps = d_cabac_range_lps[s][(cb.range >> 6) & 3];
+    const int s = st[ctx], lps = CD_LPS(s, (cb.range >> 6) & 3);
     cb.range -= lps;
     if (b != (s >> 6)) { cb.low += cb.range; cb.range = lps; }
-    st[ctx] = d_cabac_transition[s][b];
+    st[ctx] = CD_TRANS(s, b);
     cd_renorm(cb);
 }
 CD_FN void cd_encode_bypass(DCabac &cb, int b) { cb.low <<= 1; cb.low += -b & cb.range; cb.queue += 1; cd_putbyte(cb); }
@@ -106,13 +126,13 @@ template <class ST> CD_FN void cdd(DCabac &cb, ST st, int rd, int ctx, int b)
 {
     if (!rd) { cd_encode_decision(cb, st, ctx, b); return; }
     const int s = st[ctx];
-    st[ctx] = d_cabac_transition[s][b];
-    cb.f8 += d_cabac_entropy[s][b];
+    st[ctx] = CD_TRANS(s, b);
+    cb.f8 += CD_ENT(s, b);
 }
 template <class ST> CD_FN void cdd_noup(DCabac &cb, ST st, int rd, int ctx, int b)
 {
     if (!rd) cd_encode_decision(cb, st, ctx, b);
-    else cb.f8 += d_cabac_entropy[st[ctx]][b];
+    else cb.f8 += CD_ENT(st[ctx], b);
 }
 CD_FN void cdb(DCabac &cb, int rd, int b) { if (!rd) cd_encode_bypass(cb, b); else cb.f8 += 256; }
 CD_FN void cd_ue(DCabac &cb, int rd, int e, int v)
@@ -125,8 +145,8 @@ CD_FN void cd_ue(DCabac &cb, int rd, int e, int v)
 template <class ST> CD_FN int cd_unary(ST st, int ctx, int prefix)
 {
     int bits = 0, s = st[ctx];
-    for (int i = 1; i < prefix; i++) { bits += d_cabac_entropy[s][1]; s = d_cabac_transition[s][1]; }
-    if (prefix > 0 && prefix < 14) { bits += d_cabac_entropy[s][0]; s = d_cabac_transition[s][0]; }
+    for (int i = 1; i < prefix; i++) { bits += CD_ENT(s, 1); s = CD_TRANS(s, 1); }
+    if (prefix > 0 && prefix < 14) { bits += CD_ENT(s, 0); s = CD_TRANS(s, 0); }
     st[ctx] = (u8)s;
     return bits + 256;
 }
@@ -166,7 +186,7 @@ template <class ST, class MS> CD_FN void cw_mb_type_intra(DCabac &cb, ST st, int
     else {
         const int pred = m.i16mode < 4 ? m.i16mode : 2;          // x264_mb_pred_mode16x16_fix
         cdd_noup(cb, st, rd, c0, 1);
-        if (!rd) cd_encode_terminal(cb); else cb.f8 += d_cabac_entropy[st[276]][0];
+        if (!rd) cd_encode_terminal(cb); else cb.f8 += CD_ENT(st[276], 0);
         cdd_noup(cb, st, rd, c1, !!m.cbp_luma);
         if (m.cbp_chroma == 0) cdd_noup(cb, st, rd, c2, 0);
         else { cdd(cb, st, rd, c2, 1); cdd_noup(cb, st, rd, c3, m.cbp_chroma != 1); }
@@ -343,6 +363,16 @@ static __device__ const u8 d_cw_sig8[63] = {     // significant_coeff_flag_offse
 static __device__ const u8 d_cw_last8[63] = {
     0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2,
     3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8};
+#ifndef X264HIP_HOST_TEST
+// all 64 lanes, once per kernel (followed by a barrier of the caller's)
+CD_FN void cd_load_tables(int lane)
+{
+    for (int k = lane; k < 256; k += 64) cd_lds_et[k] = (u32)d_cabac_entropy[k >> 1][k & 1] | ((u32)d_cabac_transition[k >> 1][k & 1] << 16);
+    for (int k = lane; k < 128; k += 64)
+        cd_lds_lps[k] = (u32)d_cabac_range_lps[k][0] | ((u32)d_cabac_range_lps[k][1] << 8) | ((u32)d_cabac_range_lps[k][2] << 16) | ((u32)d_cabac_range_lps[k][3] << 24);
+    if (lane < 63) { cd_lds_sig8[lane] = d_cw_sig8[lane]; cd_lds_last8[lane] = d_cw_last8[lane]; }
+}
+#endif
 // node -> context of "level is 1" / "level > 1" and the node after either (cabac.c:570-581), as nibble lists
 #define CD_LVL1_CTX(n_) ((int)((0x00004321u >> (4 * (n_))) & 15))
 #define CD_LVLGT1_CTX(n_) ((int)((0x98765555u >> (4 * (n_))) & 15))
@@ -366,7 +396,7 @@ template <class ST, class MS, class LV> CD_FN void cw_residual(DCabac &cb, ST st
         // significance map forwards, then the levels backwards (they are re-read from l instead of being parked in an array)
         const int sigmap = last + 1 < count - 1 ? last + 1 : count - 1;
         for (int i = 0; i < sigmap; i++) {
-            const int cs = c_sig + (b8 ? d_cw_sig8[i] : i), cl = c_last + (b8 ? d_cw_last8[i] : i);
+            const int cs = c_sig + (b8 ? CD_SIG8(i) : i), cl = c_last + (b8 ? CD_LAST8(i) : i);
             if (l[i]) { cd_encode_decision(cb, st, cs, 1); cd_encode_decision(cb, st, cl, i == last); }
             else cd_encode_decision(cb, st, cs, 0);
         }
@@ -391,7 +421,7 @@ template <class ST, class MS, class LV> CD_FN void cw_residual(DCabac &cb, ST st
         return;
     }
     for (int i = last; i >= 0; i--) {
-        const int cs = c_sig + (b8 ? d_cw_sig8[i < 63 ? i : 62] : i), cl = c_last + (b8 ? d_cw_last8[i < 63 ? i : 62] : i);
+        const int cs = c_sig + (b8 ? CD_SIG8(i < 63 ? i : 62) : i), cl = c_last + (b8 ? CD_LAST8(i < 63 ? i : 62) : i);
         const int v = l[i];
         if (i == last) {
             if (last != count - 1) { cdd(cb, st, 1, cs, 1); cdd(cb, st, 1, cl, 1); }

@@ -151,6 +151,8 @@ struct SwLdsRd {
     int unq4[4][16], unq8[2][64];   // unquant rows of the current QPs
     i16 left_mvd[4][2];             // the left macroblock's mvd of blocks 3, 7, 11, 15
     u8 left_nz[8];                  // its non_zero_count of blocks 5 7 13 15 | U 1 3 | V 1 3
+    u8 zz2[4], zz4[16], zz8[64];    // scan position -> raster index; the trellis weights in scan order (x264_dct4/8_weight2_zigzag[0])
+    int w4z[16], w8z[64];
     u8 zero16[16];                  // sixteen zeros (SATD / SA8D of the source against nothing)
     int tmp_i[4];                   // lane 0 -> wave: bit count / QP after the writer
     TrellisScratch ts;
@@ -420,7 +422,7 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const 
         WAVE_SYNC();
         if (lane == 0)
             for (int b = 0; b < 16; b++)
-                td_trellis_quant(tq.r->ts, &s.coef[b][0], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz4, tq.r->cabac, dc_out ? 1 : 2,
+                td_trellis_quant(tq.r->ts, &s.coef[b][0], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
                                  d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16);
         WAVE_SYNC();
     }
@@ -525,7 +527,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const
         if (tq.on) {                                   // x264_quant_dc_trellis( .., DCT_LUMA_DC, 1 ), macroblock.c:247-248
 #pragma unroll
             for (int i = 0; i < 16; i++) s.dc16[i] = d[i];
-            nz = td_trellis_quant(tq.r->ts, &s.dc16[0], s.qmf[0], tq.r->unq4[0], d_w4z, d_zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16);
+            nz = td_trellis_quant(tq.r->ts, &s.dc16[0], s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16);
 #pragma unroll
             for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
         } else
@@ -595,7 +597,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
         WAVE_SYNC();
         if (lane == 0)
             for (int b = 0; b < 8; b++)
-                td_trellis_quant(tq.r->ts, &s.ccoef[b][0], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16);
+                td_trellis_quant(tq.r->ts, &s.ccoef[b][0], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16);
         WAVE_SYNC();
     }
     if (lane < 8) {
@@ -628,7 +630,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
         WAVE_SYNC();
         if (lane == 0)
             for (int ch = 0; ch < 2; ch++)
-                td_trellis_quant(tq.r->ts, &s.cdcout[4 * ch], s.qmf[cat], tq.r->unq4[cat], d_w4z, d_zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4);
+                td_trellis_quant(tq.r->ts, &s.cdcout[4 * ch], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4);
         WAVE_SYNC();
     }
     if (lane < 2) {
@@ -785,7 +787,7 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, const SwQp &Q, SwTq tq,
         if (lane == 0)
             for (int j = 0; j < 4; j++)
                 if ((mask >> j) & 1)
-                    td_trellis_quant(tq.r->ts, coef + 64 * j, s.q8mf[cat], tq.r->unq8[cat], SwW8(), c_scan8[0], tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64);
+                    td_trellis_quant(tq.r->ts, coef + 64 * j, s.q8mf[cat], tq.r->unq8[cat], tq.r->w8z, tq.r->zz8, tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64);
         WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -919,7 +921,7 @@ __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, const 
     if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_LUMA_4x4, 1, idx ), macroblock.c:134
         if (lane < 16) s.coef[idx][l16] = (i16)v;
         WAVE_SYNC();
-        if (lane == 0) td_trellis_quant(tq.r->ts, &s.coef[idx][0], s.qmf[0], tq.r->unq4[0], d_w4z, d_zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16);
+        if (lane == 0) td_trellis_quant(tq.r->ts, &s.coef[idx][0], s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16);
         WAVE_SYNC();
         q = s.coef[idx][l16];
     } else
@@ -1277,7 +1279,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             cab.p = payload0;
             for (int k = lane; k < 460; k += 64) sr.cabac[k] = (u8)cd_context_init_one(k, a.slice_type, a.qp, rd.cabac_init_idc);
         }
-        if (lane < 16) sr.zero16[lane] = 0;
+        if (lane < 16) { sr.zero16[lane] = 0; sr.zz4[lane] = d_zz4[lane]; sr.w4z[lane] = d_w4z[lane]; }
+        if (lane < 4) sr.zz2[lane] = (u8)lane;
+        sr.zz8[lane] = c_scan8[0][lane]; sr.w8z[lane] = sw_w8z(lane);
+        cd_load_tables(lane);
     }
     WAVE_SYNC();
 
@@ -1789,7 +1794,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // Like the reference it leaves `type` as the encode left it (P_SKIP when nothing was left to code on the skip vector).
         auto rd_cost_mb = [&]() -> int {
             const int t8_bak = t8;
+            PROF(6);
             encode_mb(0);
+            PROF(0);
             int cost = ssd_mb();
             if (type == T_P_SKIP) cost += (Q.lambda2 + 128) >> 8;
             else {
@@ -1808,6 +1815,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 cost += (int)(((unsigned long long)(u32)f8 * (u32)Q.lambda2 + 32768) >> 16);
             }
             t8 = t8_bak;
+            PROF(7);
             return cost;
         };
         (void)cache_fenc_satd; (void)rd_cost_mb;
@@ -1832,6 +1840,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (satd_pcm < i_cost) type = T_I_PCM;
                     tq.on = rd.trellis != 0;                                      // analyse.c:2768-2773
                     if (rd.trellis == 1 || a.nr) skip_intra = 0;
+                    PROF(6);
                     if (type != T_I_PCM) encode_mb(1);
                     encoded = true;
                     break;
@@ -2311,6 +2320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 }
                                 tq.on = rd.trellis != 0;                                          // :2768-2773
                                 if (rd.trellis == 1 || a.nr) skip_intra = 0;
+                                PROF(6);
                                 if (type != T_I_PCM) encode_mb(1);
                                 encoded = true;
                                 break;
@@ -2338,7 +2348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             }
         }
         (void)analysed;
-        PROF(6);
+        if constexpr (!RD) PROF(6);
         LAUNDER();
 
         // ---- x264_analyse_update_cache + x264_macroblock_encode ----
@@ -2347,6 +2357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         const int intra = IS_INTRA_T(type);
         int mb_qp = Q.qp, cbp_store = 0;
         if constexpr (RD) {
+            PROF(3);
             if (type == T_I_PCM) {          // the samples themselves are sent: the reconstruction is the source (R/encoder/cabac.c:801-818)
                 *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)(s.fe + (lane >> 2) * 16 + (lane & 3) * 4);
                 s.fd[FDU + (lane >> 3) * FD + (lane & 7)] = s.fe[256 + lane]; s.fd[FDV + (lane >> 3) * FD + (lane & 7)] = s.fe[320 + lane];
@@ -2379,7 +2390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             }
         }
         if (cbp_luma == 0 && type != T_I_8x8) t8 = 0;           // x264_macroblock_cache_save, R/common/macroblock.c:1273-1275
-        PROF(3);
+        PROF(RD ? 5 : 3);
         LAUNDER();
 
         // ---- x264_macroblock_cache_save: reconstruction, per-macroblock state, levels ----

@@ -9,6 +9,7 @@
 struct TrellisNode { long long score; int lv; u8 st[10]; };
 struct TrellisScratch {
     TrellisNode nodes[2][8];
+    TrellisNode tmp;                                 // the candidate being priced (kept here, not in private memory: its context array is indexed dynamically)
     u16 abs_c[64];
     u8 st_sig[64], st_last[64];
     u16 lvl_abs[64 * 8 * 2], lvl_next[64 * 8 * 2];   // the level tree: (level, previous entry) per accepted candidate
@@ -42,7 +43,8 @@ CD_FN int td_trellis_quant(TS &t, DCT dct, MF mf, UNQ unq, WT weight, ZZ zz, ST 
     t.nodes[0][0].score = 0; t.nodes[0][0].lv = 0;
     t.lvl_abs[0] = 0; t.lvl_next[0] = 0;
     if (n_coef == 64)
-        for (i = 0; i < 63; i++) { t.st_sig[i] = st[CD_SIG_OFF(5) + d_cw_sig8[i]]; t.st_last[i] = st[CD_LAST_OFF(5) + d_cw_last8[i]]; }
+#pragma nounroll
+        for (i = 0; i < 63; i++) { t.st_sig[i] = st[CD_SIG_OFF(5) + CD_SIG8(i)]; t.st_last[i] = st[CD_LAST_OFF(5) + CD_LAST8(i)]; }
     else {
         const int k = (!dc || cat != 3) ? 15 : 3, so = CD_SIG_OFF(cat), lo = CD_LAST_OFF(cat);
         for (i = 0; i < k; i++) { t.st_sig[i] = st[so + i]; t.st_last[i] = st[lo + i]; }
@@ -52,7 +54,7 @@ CD_FN int td_trellis_quant(TS &t, DCT dct, MF mf, UNQ unq, WT weight, ZZ zz, ST 
     for (i = last_nnz; i >= b_ac; i--) {
         const int coef = t.abs_c[i], q = (f + coef * (dc ? (int)mf[0] >> 1 : (int)mf[zz[i]])) >> 16;
         if (q == 0) {                                // only the "not significant" flag to pay, for every live node but 0
-            const u32 c0 = (u32)((unsigned long long)d_cabac_entropy[t.st_sig[i]][0] * (unsigned)lambda2 >> 4);
+            const u32 c0 = (u32)((unsigned long long)CD_ENT(t.st_sig[i], 0) * (unsigned)lambda2 >> 4);
             for (j = 1; j < 8; j++)
                 if (t.nodes[cur][j].score != TD_INF) {
                     t.lvl_abs[n_lvl] = 0; t.lvl_next[n_lvl] = (u16)t.nodes[cur][j].lv; t.nodes[cur][j].lv = n_lvl++;
@@ -65,22 +67,29 @@ CD_FN int td_trellis_quant(TS &t, DCT dct, MF mf, UNQ unq, WT weight, ZZ zz, ST 
         for (j = 0; j < 8; j++) t.nodes[cur][j].score = TD_INF;
         int cost_sig0 = 0, cost_sig1 = 0, cost_last0 = 0, cost_last1 = 0;
         if (i < n_coef - 1) {
-            cost_sig0 = d_cabac_entropy[t.st_sig[i]][0]; cost_sig1 = d_cabac_entropy[t.st_sig[i]][1];
-            cost_last0 = d_cabac_entropy[t.st_last[i]][0]; cost_last1 = d_cabac_entropy[t.st_last[i]][1];
+            cost_sig0 = CD_ENT(t.st_sig[i], 0); cost_sig1 = CD_ENT(t.st_sig[i], 1);
+            cost_last0 = CD_ENT(t.st_last[i], 0); cost_last1 = CD_ENT(t.st_last[i], 1);
         }
+#pragma nounroll
         for (int lvl = q; lvl >= q - 1; lvl--) {
             const int unq_lvl = ((dc ? (int)unq[0] << 1 : (int)unq[zz[i]]) * lvl + 128) >> 8, d = coef - unq_lvl;
             const long long ssd = (long long)d * d * (dc ? 256 : (int)weight[i]);
+#pragma nounroll
             for (j = 0; j < 8; j++) {
                 if (t.nodes[prv][j].score == TD_INF) continue;
                 int node = j;
+#ifdef TD_PRIVATE_NODE
                 TrellisNode n = t.nodes[prv][j];
+#else
+                TrellisNode &n = t.tmp;
+                n = t.nodes[prv][j];
+#endif
                 if (lvl || node) {
                     unsigned bits = lvl ? cost_sig1 : cost_sig0;
                     if (lvl) {
                         const int prefix = lvl - 1 < 14 ? lvl - 1 : 14, c1 = CD_LVL1_CTX(node);
                         bits += node == 0 ? cost_last1 : cost_last0;
-                        bits += d_cabac_entropy[n.st[c1]][prefix > 0]; n.st[c1] = d_cabac_transition[n.st[c1]][prefix > 0];
+                        bits += CD_ENT(n.st[c1], prefix > 0); n.st[c1] = (u8)CD_TRANS(n.st[c1], prefix > 0);
                         if (prefix > 0) {
                             bits += cd_unary(&n.st[0], CD_LVLGT1_CTX(node), prefix);
                             if (lvl >= 15) bits += cd_ue_size((unsigned)(lvl - 15)) << 8;

@@ -90,7 +90,8 @@ def cpu_baseline(args):
     n = args.cpu_frames
     kw, ekw, raster = analysis_options(args), rd_options(args), not args.wavefront
     spent1, kind = _cpu_chain((args.width, args.height, n, kw, ekw, raster, 0))
-    cores = max(1, min(os.cpu_count() or 1, args.cpu_procs or (os.cpu_count() or 1)))
+    avail = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)   # a one-GPU box's CPU share is 16 cores
+    cores = max(1, min(avail, args.cpu_procs or avail))
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_chain, [(args.width, args.height, n, kw, ekw, raster, 11 * i) for i in range(cores)], chunksize=1)
     spent_all = max(r[0] for r in res)                # the chains run side by side: the slowest one's encode time (clip synthesis is not counted)

@@ -120,6 +120,9 @@ static const i16 *s_load_cost_mv(int qp)
     return s_cost_mv[qp];
 }
 
+/* the table of one QP from -span (test access: tests/test_cpu_abi_and_shard.py compares the product's C table with it) */
+const i16 *x264o_cost_mv_row(int qp) { return s_load_cost_mv(qp) - 2 * 4 * 2048; }
+
 typedef struct {
     u8 *alloc[4];
     u8 *plane[3], *filt[4];

@@ -115,3 +115,23 @@ def test_two_rank_gloo_sharding(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_cost_mv_table_built_in_c_matches_twin_and_numpy(oracle_lib):
+    """p_cost_mv feeds every motion-vector decision and is float arithmetic in the reference (R/encoder/analyse.c:182-198).  The
+    product builds it in the library's host C (x264hip_cost_mv_table, the reference's expression, -ffp-contract=off); it must equal
+    the twin's C table (oracle/slice_oracle.c:s_load_cost_mv -- the twin is pinned to the reference's decisions on thousands of
+    chains) and the NumPy restatement in frame.py, for every QP over the full +-2*4*2048 span."""
+    import ctypes as C
+    import numpy as np
+    from x264_vs2008_amd import lib as L
+    from x264_vs2008_amd.frame import cost_mv_table
+    from x264_vs2008_amd.slice import COST_SPAN, LAMBDA_TAB
+    lib = L.open_library()
+    oracle_lib.x264o_cost_mv_row.restype = C.c_void_p
+    for qp in range(52):
+        got = np.zeros(2 * COST_SPAN + 1, np.int16)
+        lib.x264hip_cost_mv_table(C.c_int(LAMBDA_TAB[qp]), C.c_int(COST_SPAN), got.ctypes.data_as(C.c_void_p))
+        twin = np.ctypeslib.as_array((C.c_int16 * (2 * COST_SPAN + 1)).from_address(oracle_lib.x264o_cost_mv_row(qp)))
+        assert np.array_equal(got, twin), qp
+        assert np.array_equal(got.view(np.uint16), cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)), qp

@@ -1,0 +1,59 @@
+"""Parity at BASELINE's frame sizes, pinned by the REFERENCE: sha256 per array per frame of 1920x1080 and 3840x2160 chains the
+reference's own loop produced (oracle/gen_golden_hash.py -> tests/golden/hash_*.json).
+  * CPU: the twin (oracle/slice_oracle.c) reproduces them -- so the twin is pinned to the reference at these sizes too;
+  * GPU: the sweep (wavefront schedule for the round-1 option sets, raster order for the RD ones) reproduces them, payload included."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import refslice as rs
+from oracle.gen_golden_hash import ARRAYS, HASH_CASES, digest, hashes, run_case
+from x264_vs2008_amd import slice as sl
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, "hash_%s.json" % name)) as f:
+        return json.load(f)
+
+
+# the twin at 2160p with the RD levels takes ~20 s: keep the CPU suite short, the GPU test covers that size
+CPU_CASES = [c for c in HASH_CASES if c[0] != "uhd_umh_medium_rd"]
+
+
+@pytest.mark.parametrize("name,size,frames,kw,ekw", CPU_CASES, ids=[c[0] for c in CPU_CASES])
+def test_twin_matches_reference_hashes(oracle_lib, name, size, frames, kw, ekw):
+    want = load(name)
+    got = run_case(lambda p, y, u, v: rs.run(oracle_lib, "x264o_encode_chain", p, y, u, v),
+                   lambda p, e, y, u, v: rs.run2(oracle_lib, "x264o_encode_chain2", p, e, y, u, v), size, frames, kw, ekw)
+    h = hashes(got, frames)
+    for k in ARRAYS + (["payload", "payload_len"] if ekw is not None else []):
+        assert h[k] == want[k], "%s: frames %s differ" % (k, [f for f in range(frames) if h[k][f] != want[k][f]])
+    assert h["stat"] == want["stat"] and h["frame_info"] == want["frame_info"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size,frames,kw,ekw", HASH_CASES, ids=[c[0] for c in HASH_CASES])
+def test_gpu_matches_reference_hashes(hip_lib, cqm, name, size, frames, kw, ekw):
+    from test_gpu_slice import STATE, run_chain
+    from test_gpu_slice_rd import run_chain2
+    want = load(name)
+    y, u, v = rs.clip(size[0], size[1], frames)
+    out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw) if ekw is None else run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw)
+    n_mb = ((size[0] + 15) // 16) * ((size[1] + 15) // 16)
+    shapes = {"sub_partition": (n_mb, 4), "mv": (n_mb, 16, 2), "ref": (n_mb, 4), "nnz": (n_mb, 27), "i4mode": (n_mb, 16), "luma": (n_mb, 256),
+              "luma_dc": (n_mb, 16), "chroma_dc": (n_mb, 8), "chroma_ac": (n_mb, 128)}
+    for f in range(frames):
+        for k in ARRAYS:
+            a = out[f][k][0]
+            if k in STATE:
+                a = a.reshape(shapes.get(k, (n_mb,)))
+            assert digest(a) == want[k][f], "frame %d: %s" % (f, k)
+        assert list(out[f]["info"]) == want["frame_info"][f][:2]
+        assert int(out[f]["cost_intra"][0].sum()) == want["stat"][f][0] and int(out[f]["cost_inter"][0].sum()) == want["stat"][f][1]
+        if ekw is not None:
+            assert len(out[f]["payload"][0]) == want["payload_len"][f]
+            assert hashlib.sha256(out[f]["payload"][0]).hexdigest() == want["payload"][f], "frame %d: payload" % f

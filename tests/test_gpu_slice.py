@@ -250,3 +250,28 @@ def test_sweep_refuses_what_it_does_not_build(hip_lib, cqm, kw, tweak, needle):
         assert needle in str(e.value), str(e.value)
     finally:
         enc.close()
+
+
+def test_abort_path_is_sticky(hip_lib, cqm, monkeypatch):
+    """A wave that exhausts its spin budget aborts the launch, and the context remembers: the status call keeps failing after
+    later frames have been enqueued (their states reuse -- and clear -- the aborted frame's own flag).  Forced here with a spin
+    budget of one poll (X264HIP_SPIN_LIMIT), on a frame tall enough that rows really wait for each other."""
+    monkeypatch.setenv("X264HIP_SPIN_LIMIT", "1")
+    y, u, v = case_inputs((208, 144), 3, "moving")
+    enc = sl.ChainEncoder(hip_lib, 208, 144, cqm, qp=26, subme=2, me_method=1, n_refs=1, cabac=1)
+    try:
+        enc.upload(y[0], u[0], v[0])
+        enc.encode_frame()
+        with pytest.raises(RuntimeError) as e:
+            enc.status()
+        assert "gave up waiting" in str(e.value)
+        monkeypatch.delenv("X264HIP_SPIN_LIMIT")
+        for f in (1, 2):                     # the ring of states wraps: the aborted frame's own flag is cleared
+            enc.finish_frame()
+            enc.upload(y[f], u[f], v[f])
+            enc.encode_frame()
+        with pytest.raises(RuntimeError) as e:
+            enc.status()
+        assert "EARLIER frame" in str(e.value)
+    finally:
+        enc.close()

@@ -253,6 +253,7 @@ extern "C" x264hip_frame_ctx *x264hip_frame_ctx_new(x264hip_frame_dims *d, void 
     else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return nullptr; }
     else c->own_stream = true;
     if (hipMalloc((void **)&c->ssd_dev, 24 * (size_t)c->batch + 64) != hipSuccess) { free(c); return nullptr; }
+    (void)hipMemset(c->ssd_dev, 0, 24 * (size_t)c->batch + 64);   // the tail holds the context's sticky sweep-abort counter (frame_slice.hip)
     return c;
 }
 extern "C" void x264hip_frame_ctx_delete(x264hip_frame_ctx *c)

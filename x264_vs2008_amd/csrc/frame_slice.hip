@@ -39,6 +39,7 @@ static const uint8_t k_chroma_qp[52] = {  // i_chroma_qp_table, R/common/macrobl
     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
     29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
+extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st);
 extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st)
 {
     const size_t n = (size_t)c->d.mb_w * c->d.mb_h * c->batch;
@@ -51,8 +52,11 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
         {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n}, {(void **)&st->cost_intra_alt, 4 * n},
         {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}, {(void **)&st->mvd, 64 * n}};
     for (auto &it : items) {
-        HIPCHK(hipMalloc(it.p, it.bytes));
-        HIPCHK(hipMemsetAsync(*it.p, 0, it.bytes, c->stream));
+        if (hipMalloc(it.p, it.bytes) != hipSuccess || hipMemsetAsync(*it.p, 0, it.bytes, c->stream) != hipSuccess) {
+            set_error("mb_state_alloc: %zu bytes", it.bytes);
+            x264hip_mb_state_free(c, st);              // what was allocated so far
+            return -1;
+        }
     }
     return 0;
 }
@@ -175,6 +179,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     a.luma = out->luma; a.luma_dc = out->luma_dc; a.chroma_dc = out->chroma_dc; a.chroma_ac = out->chroma_ac;
     a.cost_intra = out->cost_intra; a.cost_inter = out->cost_inter; a.cost_alt = out->cost_intra_alt;
     a.progress = out->progress; a.abort_flag = out->progress + (size_t)c->d.mb_h * c->batch;
+    a.abort_total = (int *)((char *)c->ssd_dev + 24 * (size_t)c->batch + 32);
+    { const char *e = getenv("X264HIP_SPIN_LIMIT"); a.spin_limit = e && atoi(e) > 0 ? atoi(e) : SW_SPIN_LIMIT; }
     a.prof = (long long *)p->profile;
     a.nr = p->noise_reduction != 0;
     a.lossless = p->lossless != 0;
@@ -228,9 +234,12 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
 
 extern "C" int x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st)
 {
-    int flag = 0;
+    int flag = 0, total = 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(&flag, st->progress + (size_t)c->d.mb_h * c->batch, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&total, (char *)c->ssd_dev + 24 * (size_t)c->batch + 32, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) { set_error("slice_sweep: a wavefront gave up waiting for its neighbours (aborted frame)"); return -1; }
+    // sticky: an aborted frame may have been used as a reference since, and its own flag is cleared when its state is reused
+    if (total) { set_error("slice_sweep: %d wavefront(s) of an EARLIER frame of this context gave up waiting (aborted frame): everything coded since is invalid", total); return -1; }
     return 0;
 }

@@ -16,7 +16,11 @@
 // neighbour is the wave's own previous iteration: its state stays in LDS / registers.  Workgroup
 // ids are laid out so that all rows of a chain land on the same XCD (id % 8 == chain % 8): the
 // cross-row traffic stays inside one L2.  Every wait is bounded: a wave that spins too long raises
-// the abort flag and every wave leaves, so the grid always drains.
+// the abort flag and every wave leaves, so the grid always drains.  FORWARD PROGRESS ASSUMPTION: the grid is oversubscribed
+// (more row waves than wave slots), so a waiting wave relies on the waves of the rows above being resident or dispatched before it:
+// workgroups are dispatched in increasing blockIdx order on this hardware (ids are laid out row-major for exactly that reason).
+// HIP does not promise the order; if it ever changed, waves would exhaust their spin budget and the launch would be reported as
+// aborted (never silently wrong): the abort count is sticky per context (x264hip_slice_sweep_status).
 //
 // Inside a macroblock all 64 lanes work on the same block and every decision is wave-uniform scalar state: 4 luma pixels
 // per lane for prediction and SAD, one lane per 8x4 block for SATD, one lane per coefficient for the 4x4 transform, a lane
@@ -76,6 +80,8 @@ struct SwArgs {
     i16 *luma, *luma_dc, *chroma_dc, *chroma_ac;
     int *cost_intra, *cost_inter, *cost_alt;
     int *progress, *abort_flag;
+    int *abort_total;           // per context, never reset: waves that gave up waiting, over all launches (x264hip_slice_sweep_status)
+    int spin_limit;             // polls before a waiting wave gives up (SW_SPIN_LIMIT; X264HIP_SPIN_LIMIT overrides it for the abort-path test)
     long long *prof;            // optional [batch][mb_h][8] accumulated wall-clock ticks per phase (developer aid)
     int nr;                     // param.analyse.i_noise_reduction != 0
     int lossless;               // h->mb.b_lossless
@@ -1326,8 +1332,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 if ((v & 0xffff) >= need) break;
                 if (spins < 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(100);
                 int ab = (spins & 15) == 15 ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-                if (ab || ++spins > SW_SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ab || ++spins > a.spin_limit) {
+                    if (lane == 0) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!ab) atomicAdd(a.abort_total, 1); }
                     return;
                 }
             }
@@ -1465,7 +1471,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 if (mb >= 3 * (known + pending)) return 1;
                 if (!wait) return 2;
                 __builtin_amdgcn_s_sleep(100);
-                if (spins > SW_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 0; }
+                if (spins > a.spin_limit) { if (lane == 0) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicAdd(a.abort_total, 1); } return 0; }
             }
         };
         // x264_mb_analyse_intra, R/encoder/analyse.c:612-843

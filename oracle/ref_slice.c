@@ -42,6 +42,11 @@ typedef struct {
     int write;                               /* 1: call the entropy writer after every macroblock (required for subme >= 6) */
     int payload_cap;                         /* bytes per frame available in refslice_out2.payload */
     int cabac_init_idc;                      /* param.i_cabac_init_idc */
+    /* B slices: a fixed pattern of `bframes` non-reference B frames between anchors (what x264_slicetype_decide produces with
+     * --b-adapt 0 and no --b-pyramid); the clip stays in display order, the chain is coded in coding order */
+    int bframes;                             /* param.i_bframe */
+    int weightb;                             /* param.analyse.b_weighted_bipred */
+    int direct_pred;                         /* param.analyse.i_direct_mv_pred: 1 spatial, 2 temporal */
 } refslice_ext;
 
 typedef struct {
@@ -49,6 +54,9 @@ typedef struct {
     int32_t *payload_len;                    /* [F] */
     int32_t *mb_bits;                        /* [F][n]: bits written once this macroblock is out (x264_cabac_pos / bs_pos) */
     float *qp_offset;                        /* [F][n]: fenc->f_qp_offset (0 without AQ) */
+    int16_t *mv1;                            /* [F][n][16][2]: list 1 (B slices) */
+    int8_t *ref1;                            /* [F][n][4] */
+    int32_t *frame_info2;                    /* [F][4]: display index, i_ref1, kept as reference, 0 */
 } refslice_out2;
 
 typedef struct {
@@ -87,6 +95,8 @@ static void filter_row(x264_t *h, int mb_y)        /* x264_fdec_filter_row's seq
         for (i = 0; i < 3; i++)
             memcpy(h->mb.intra_border_backup[0][i], h->fdec->plane[i] + ((mb_y * 16 >> !!i) - 1) * h->fdec->i_stride[i],
                    h->sps->i_mb_width * 16 >> !!i);
+    if (!h->fdec->b_kept_as_ref)                     /* a disposable B frame is neither filtered nor interpolated (encoder.c:986-991,1016) */
+        return;
     if (!h->sh.i_disable_deblocking_filter_idc)
         x264_frame_deblock_row(h, min_y);
     x264_frame_expand_border(h, h->fdec, min_y, b_end);
@@ -135,6 +145,10 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
         h->param.rc.f_aq_strength = x264_clip3f(e->aq_strength, 0, 3);
         h->param.rc.i_aq_mode = h->param.rc.f_aq_strength == 0 ? 0 : x264_clip3(e->aq_mode, 0, 1);
         h->param.i_cabac_init_idc = x264_clip3(e->cabac_init_idc, 0, 2);
+        h->param.i_bframe = x264_clip3(e->bframes, 0, X264_BFRAME_MAX);
+        h->param.analyse.b_weighted_bipred = e->weightb && h->param.i_bframe > 0;
+        h->param.analyse.i_direct_mv_pred = e->direct_pred ? e->direct_pred : X264_DIRECT_PRED_SPATIAL;
+        if (!p->subme && h->param.analyse.i_direct_mv_pred > X264_DIRECT_PRED_SPATIAL) h->param.analyse.i_direct_mv_pred = X264_DIRECT_PRED_SPATIAL;
         if (p->subme >= 6 && !b_write) return -4;        /* the RD levels read the live entropy-coder state */
         x264_rdo_init();                                 /* R/encoder/encoder.c:728 */
     }
@@ -149,6 +163,7 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     h->sps = &h->sps_array[0]; h->pps = &h->pps_array[0];
     mb_w = h->sps->i_mb_width = (p->width + 15) / 16; mb_h = h->sps->i_mb_height = (p->height + 15) / 16;
     h->sps->b_frame_mbs_only = 1;
+    h->sps->b_direct8x8_inference = 1;                   /* x264_sps_init, R/encoder/set.c:136 */
     n = h->mb.i_mb_count = mb_w * mb_h;
     h->pps->b_cabac = p->cabac; h->pps->b_transform_8x8_mode = h->param.analyse.b_transform_8x8;
     for (i = 0; i < 6; i++) h->pps->scaling_list[i] = p->cqm_preset ? x264_cqm_jvt[i] : flat16;   /* x264_pps_init, R/encoder/set.c */
@@ -168,40 +183,69 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     if (x264_macroblock_cache_init(h) < 0 || x264_ratecontrol_new(h) < 0) return -2;
     if (b_write) bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
 
+    /* coding order (what x264_slicetype_decide + the frame reordering of x264_encoder_encode give for a fixed B pattern):
+     * anchors every bframes + 1 frames from the last IDR, the last frame before an IDR / the end of the clip is an anchor too;
+     * each anchor is coded before the B frames that precede it in display order */
+    const int nb = e ? h->param.i_bframe : 0, dpb = X264_MAX(p->n_refs, nb ? 2 : 1);   /* sps->vui.i_max_dec_frame_buffering, set.c */
+    int *order = malloc(sizeof(int) * p->n_frames), *ftype = malloc(sizeof(int) * p->n_frames), n_order = 0;
+    for (int t = 0; t < p->n_frames;) {
+        int is_idr = p->keyint > 0 ? t % p->keyint == 0 : t == 0;
+        if (is_idr) { order[n_order] = t; ftype[n_order++] = X264_TYPE_IDR; t++; continue; }
+        int next_idr = p->keyint > 0 ? (t / p->keyint + 1) * p->keyint : p->n_frames, lim = X264_MIN(next_idr, p->n_frames);
+        int anchor = X264_MIN(t + nb, lim - 1);
+        order[n_order] = anchor; ftype[n_order++] = X264_TYPE_P;
+        for (int b = t; b < anchor; b++) { order[n_order] = b; ftype[n_order++] = X264_TYPE_B; }
+        t = anchor + 1;
+    }
     for (f = 0; f < p->n_frames; f++) {
-        int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
-        size_t F = f;
+        const int disp = order[f], is_b = ftype[f] == X264_TYPE_B;
+        int idr = ftype[f] == X264_TYPE_IDR;
+        size_t F = f, D = disp;
         if (idr) {
             for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
-            n_avail = 0; last_idr = f;
+            n_avail = 0; last_idr = disp;
         }
         /* x264_frame_copy_picture + x264_frame_expand_border_mod16 (R/encoder/encoder.c:1406-1413) */
         for (y = 0; y < p->height; y++)
-            memcpy(h->fenc->plane[0] + y * h->fenc->i_stride[0], src_y + (F * p->height + y) * p->width, p->width);
+            memcpy(h->fenc->plane[0] + y * h->fenc->i_stride[0], src_y + (D * p->height + y) * p->width, p->width);
         for (y = 0; y < ch; y++) {
-            memcpy(h->fenc->plane[1] + y * h->fenc->i_stride[1], src_u + (F * ch + y) * cw, cw);
-            memcpy(h->fenc->plane[2] + y * h->fenc->i_stride[2], src_v + (F * ch + y) * cw, cw);
+            memcpy(h->fenc->plane[1] + y * h->fenc->i_stride[1], src_u + (D * ch + y) * cw, cw);
+            memcpy(h->fenc->plane[2] + y * h->fenc->i_stride[2], src_v + (D * ch + y) * cw, cw);
         }
         x264_frame_expand_border_mod16(h, h->fenc);
-        h->fenc->i_frame = f; h->fenc->i_poc = 2 * (f - last_idr);
-        h->fenc->i_type = idr ? X264_TYPE_IDR : X264_TYPE_P;
-        h->fdec->i_frame = f; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type; h->fdec->b_kept_as_ref = 1;
+        h->fenc->i_frame = disp; h->fenc->i_poc = 2 * (disp - last_idr);
+        h->fenc->i_type = ftype[f];
+        h->fdec->i_frame = disp; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type;
+        h->fenc->b_kept_as_ref = h->fdec->b_kept_as_ref = !is_b;
         h->i_frame = f;                                   /* frames coded so far (x264_reference_update, encoder.c:1063) */
         if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, h->fenc);   /* encoder.c:1421 */
-        h->i_ref0 = n_avail < p->n_refs ? n_avail : p->n_refs;
-        for (i = 0; i < h->i_ref0; i++) h->fref0[i] = refs[i];
-        h->i_ref1 = 0;
-        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = 0;
+        /* x264_reference_build_list, R/encoder/encoder.c:911-981: by POC, list 0 downwards from the frame, list 1 upwards */
+        h->i_ref0 = h->i_ref1 = 0;
+        for (i = 0; i < n_avail; i++) {
+            if (refs[i]->i_poc < h->fdec->i_poc) h->fref0[h->i_ref0++] = refs[i];
+            else if (refs[i]->i_poc > h->fdec->i_poc) h->fref1[h->i_ref1++] = refs[i];
+        }
+        for (i = 0; i < h->i_ref0; i++)
+            for (k = i + 1; k < h->i_ref0; k++)
+                if (h->fref0[k]->i_poc > h->fref0[i]->i_poc) { x264_frame_t *t_ = h->fref0[i]; h->fref0[i] = h->fref0[k]; h->fref0[k] = t_; }
+        for (i = 0; i < h->i_ref1; i++)
+            for (k = i + 1; k < h->i_ref1; k++)
+                if (h->fref1[k]->i_poc < h->fref1[i]->i_poc) { x264_frame_t *t_ = h->fref1[i]; h->fref1[i] = h->fref1[k]; h->fref1[k] = t_; }
+        h->i_ref1 = X264_MIN(h->i_ref1, nb ? 1 : 0);                /* h->frames.i_max_ref1 = sps->vui.i_num_reorder_frames */
+        h->i_ref0 = X264_MIN(h->i_ref0, p->n_refs);
+        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = h->i_ref1;
         memset(&h->sh, 0, sizeof(h->sh));
-        h->sh.i_type = idr ? SLICE_TYPE_I : SLICE_TYPE_P;
+        h->sh.i_type = idr ? SLICE_TYPE_I : is_b ? SLICE_TYPE_B : SLICE_TYPE_P;
+        h->sh.b_direct_spatial_mv_pred = h->param.analyse.i_direct_mv_pred == X264_DIRECT_PRED_SPATIAL;   /* x264_slice_header_init, encoder.c:116-122 */
         h->sh.i_first_mb = 0; h->sh.i_last_mb = n;
         h->sh.i_num_ref_idx_l0_active = h->i_ref0 <= 0 ? 1 : h->i_ref0;
-        h->sh.i_num_ref_idx_l1_active = 1;
+        h->sh.i_num_ref_idx_l1_active = h->i_ref1 <= 0 ? 1 : h->i_ref1;
         h->sh.i_disable_deblocking_filter_idc = !p->deblock;
         h->sh.i_alpha_c0_offset = p->alpha_c0; h->sh.i_beta_offset = p->beta;
         h->sh.i_cabac_init_idc = h->param.i_cabac_init_idc;
         x264_ratecontrol_start(h, 0);
         h->sh.i_qp = x264_ratecontrol_qp(h);
+        if (is_b) x264_macroblock_bipred_init(h);            /* encoder.c:1534-1535 */
         x264_macroblock_slice_init(h);
         memset(&h->stat.frame, 0, sizeof(h->stat.frame));
         int i_skip = 0;
@@ -216,6 +260,7 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
         h->mb.i_last_qp = h->sh.i_qp; h->mb.i_last_dqp = 0;
         o->frame_info[4 * F] = h->sh.i_type; o->frame_info[4 * F + 1] = h->sh.i_qp;
         o->frame_info[4 * F + 2] = h->i_ref0; o->frame_info[4 * F + 3] = h->fdec->i_poc;
+        if (o2 && o2->frame_info2) { o2->frame_info2[4 * F] = disp; o2->frame_info2[4 * F + 1] = h->i_ref1; o2->frame_info2[4 * F + 2] = !is_b; o2->frame_info2[4 * F + 3] = 0; }
 
         for (int mb = 0; mb < n; mb++) {
             int mx = mb % mb_w, my = mb / mb_w;
@@ -257,8 +302,8 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
             if (o2) o2->qp_offset[M] = h->param.rc.i_aq_mode ? h->fenc->f_qp_offset[mb] : 0;
 
             o->mb_type[M] = h->mb.i_type;
-            o->partition[M] = IS_INTRA(h->mb.i_type) || h->mb.i_type == P_SKIP ? D_16x16 : h->mb.i_partition;
-            for (i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = h->mb.i_type == P_8x8 ? h->mb.i_sub_partition[i] : 0;
+            o->partition[M] = IS_INTRA(h->mb.i_type) || IS_SKIP(h->mb.i_type) || h->mb.i_type == B_DIRECT ? D_16x16 : h->mb.i_partition;
+            for (i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = h->mb.i_type == P_8x8 || h->mb.i_type == B_8x8 ? h->mb.i_sub_partition[i] : 0;
             for (i = 0; i < 27; i++) nz[i] = h->mb.cache.non_zero_count[x264_scan8[i]];
             if (h->mb.i_type == I_PCM) memset(nz, 16, 27);
             o->qp[M] = h->mb.qp[mb]; o->cbp[M] = h->mb.cbp[mb]; o->t8[M] = h->mb.mb_transform_size[mb];
@@ -272,12 +317,22 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
                     o->mv[(M * 16 + i) * 2] = h->mb.mv[0][o4][0]; o->mv[(M * 16 + i) * 2 + 1] = h->mb.mv[0][o4][1];
                 }
                 for (i = 0; i < 4; i++) o->ref[M * 4 + i] = h->mb.ref[0][h->mb.i_b8_xy + (i & 1) + (i >> 1) * h->mb.i_b8_stride];
+                if (o2 && o2->mv1) {
+                    const int l1 = h->sh.i_type == SLICE_TYPE_B;
+                    for (i = 0; i < 16; i++) {
+                        int o4 = h->mb.i_b4_xy + (i & 3) + (i >> 2) * h->mb.i_b4_stride;
+                        o2->mv1[(M * 16 + i) * 2] = l1 ? h->mb.mv[1][o4][0] : 0; o2->mv1[(M * 16 + i) * 2 + 1] = l1 ? h->mb.mv[1][o4][1] : 0;
+                    }
+                    for (i = 0; i < 4; i++) o2->ref1[M * 4 + i] = l1 ? h->mb.ref[1][h->mb.i_b8_xy + (i & 1) + (i >> 1) * h->mb.i_b8_stride] : -1;
+                }
                 for (k = 0; k < h->i_ref0; k++) {
                     o->mvr[((F * p->n_refs + k) * n + mb) * 2] = h->mb.mvr[0][k][mb][0];
                     o->mvr[((F * p->n_refs + k) * n + mb) * 2 + 1] = h->mb.mvr[0][k][mb][1];
                 }
-            } else
+            } else {
                 for (i = 0; i < 4; i++) o->ref[M * 4 + i] = -1;
+                if (o2 && o2->ref1) for (i = 0; i < 4; i++) o2->ref1[M * 4 + i] = -1;
+            }
             /* coefficient levels, masked by what the entropy coder would read (cbp, then nnz) */
             memset(ly, 0, 512); memset(ldc, 0, 32); memset(cdc, 0, 16); memset(cac, 0, 256);
             if (!IS_SKIP(h->mb.i_type) && h->mb.i_type != I_PCM) {
@@ -312,19 +367,21 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
             memcpy(o->fin_u + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[1] + y * h->fdec->i_stride[1], 8 * mb_w);
             memcpy(o->fin_v + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[2] + y * h->fdec->i_stride[2], 8 * mb_w);
         }
-        /* x264_reference_update: newest first */
-        if (n_avail == 16) x264_frame_delete(refs[--n_avail]);
-        for (i = n_avail; i > 0; i--) refs[i] = refs[i - 1];
-        refs[0] = h->fdec; n_avail++;
-        if (n_avail > p->n_refs) x264_frame_delete(refs[--n_avail]);
-        h->fdec = x264_frame_new(h);
+        /* x264_reference_update, encoder.c:1060-1093: a disposable frame is dropped, a kept one pushes the oldest out of the DPB */
+        if (!is_b) {
+            if (n_avail == 16) x264_frame_delete(refs[--n_avail]);
+            for (i = n_avail; i > 0; i--) refs[i] = refs[i - 1];
+            refs[0] = h->fdec; n_avail++;
+            if (n_avail > dpb) x264_frame_delete(refs[--n_avail]);
+            h->fdec = x264_frame_new(h);
+        }
     }
     for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
     x264_frame_delete(h->fdec); x264_frame_delete(h->fenc);
     x264_ratecontrol_delete(h);
     x264_macroblock_cache_end(h);
     x264_cqm_delete(h);
-    free(bsbuf);
+    free(bsbuf); free(order); free(ftype);
     free(h);
     return 0;
 }

@@ -13,6 +13,7 @@ ANALYSE_I4x4, ANALYSE_I8x8, ANALYSE_PSUB16x16, ANALYSE_PSUB8x8 = 0x0001, 0x0002,
 ME_DIA, ME_HEX, ME_UMH, ME_ESA = 0, 1, 2, 3
 # R/common/macroblock.h:78-102 (mb types), :55-76 (partitions)
 I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = 0, 1, 2, 3, 4, 5, 6
+B_DIRECT, B_L0_L0, B_8x8, B_SKIP = 7, 8, 17, 18
 SLICE_P, SLICE_B, SLICE_I = 0, 1, 2
 
 
@@ -63,17 +64,25 @@ OUT_FIELDS = [("mb_type", np.int8, lambda F, n, R, w, h: (F, n)),
 class Ext(C.Structure):
     """refslice_ext (oracle/ref_slice.c): what refslice_encode_chain2 takes on top of Params."""
     _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_float), ("psy_trellis", C.c_float), ("aq_mode", C.c_int),
-                ("aq_strength", C.c_float), ("write", C.c_int), ("payload_cap", C.c_int), ("cabac_init_idc", C.c_int)]
+                ("aq_strength", C.c_float), ("write", C.c_int), ("payload_cap", C.c_int), ("cabac_init_idc", C.c_int),
+                ("bframes", C.c_int), ("weightb", C.c_int), ("direct_pred", C.c_int)]
 
 
-def make_ext(trellis=0, psy_rd=0.0, psy_trellis=0.0, aq_mode=0, aq_strength=1.0, write=1, payload_cap=0, cabac_init_idc=0):
-    return Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc)
+DIRECT_SPATIAL, DIRECT_TEMPORAL = 1, 2       # R/x264.h:93-96
+
+
+def make_ext(trellis=0, psy_rd=0.0, psy_trellis=0.0, aq_mode=0, aq_strength=1.0, write=1, payload_cap=0, cabac_init_idc=0,
+             bframes=0, weightb=0, direct_pred=DIRECT_SPATIAL):
+    return Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc, bframes, weightb, direct_pred)
 
 
 OUT2_FIELDS = [("payload", np.uint8, lambda F, n, cap: (F, cap)),
                ("payload_len", np.int32, lambda F, n, cap: (F,)),
                ("mb_bits", np.int32, lambda F, n, cap: (F, n)),
-               ("qp_offset", np.float32, lambda F, n, cap: (F, n))]
+               ("qp_offset", np.float32, lambda F, n, cap: (F, n)),
+               ("mv1", np.int16, lambda F, n, cap: (F, n, 16, 2)),
+               ("ref1", np.int8, lambda F, n, cap: (F, n, 4)),
+               ("frame_info2", np.int32, lambda F, n, cap: (F, 4))]
 
 
 class Out2(C.Structure):

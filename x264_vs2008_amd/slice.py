@@ -244,6 +244,8 @@ class ChainEncoder:
 
     def status(self):
         c = self.ctx
+        if getattr(self, "last", None) is None:          # nothing launched yet
+            return
         c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(self.last[1].st)), "slice_sweep_status")
 
     def close(self):

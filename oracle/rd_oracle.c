@@ -68,7 +68,7 @@ static int rd_cost_mb(ssl *S, smb *m, int lambda2)
     int bits;
     encode_mb(S, m);
     const int ssd = ssd_mb(S, m);
-    if (m->type == S_P_SKIP) bits = (1 * lambda2 + 128) >> 8;
+    if (S_IS_SKIP(m->type)) bits = (1 * lambda2 + 128) >> 8;
     else {
         o_cabac tmp;
         tmp.f8 = 0;

@@ -47,17 +47,25 @@ typedef struct {
     float psy_rd, psy_trellis;
     int aq_mode; float aq_strength;
     int write, payload_cap, cabac_init_idc;
+    int bframes, weightb, direct_pred;       /* B slices: param.i_bframe (fixed pattern, no pyramid), b_weighted_bipred, i_direct_mv_pred (1 spatial, 2 temporal) */
 } slice_ext;
 typedef struct {
     u8 *payload;
     int32_t *payload_len, *mb_bits;
     float *qp_offset;
+    i16 *mv1; int8_t *ref1;                  /* list 1 */
+    int32_t *frame_info2;                    /* [F][4]: display index, i_ref1, kept as reference, 0 */
 } slice_out2;
 
 /* mb types / partitions / slice types with the reference's numbering (R/common/macroblock.h:55-102, R/common/common.h:128-134) */
-enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6 };
-enum { S_D_L0_4x4 = 0, S_D_L0_8x4 = 1, S_D_L0_4x8 = 2, S_D_L0_8x8 = 3, S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
-enum { S_SLICE_P = 0, S_SLICE_I = 2 };
+enum { S_I_4x4 = 0, S_I_8x8 = 1, S_I_16x16 = 2, S_I_PCM = 3, S_P_L0 = 4, S_P_8x8 = 5, S_P_SKIP = 6,
+       S_B_DIRECT = 7, S_B_L0_L0 = 8, S_B_L0_L1 = 9, S_B_L0_BI = 10, S_B_L1_L0 = 11, S_B_L1_L1 = 12, S_B_L1_BI = 13,
+       S_B_BI_L0 = 14, S_B_BI_L1 = 15, S_B_BI_BI = 16, S_B_8x8 = 17, S_B_SKIP = 18 };
+enum { S_D_L0_4x4 = 0, S_D_L0_8x4 = 1, S_D_L0_4x8 = 2, S_D_L0_8x8 = 3, S_D_L1_8x8 = 7, S_D_BI_8x8 = 11, S_D_DIRECT_8x8 = 12,
+       S_D_8x8 = 13, S_D_16x8 = 14, S_D_8x16 = 15, S_D_16x16 = 16 };
+enum { S_SLICE_P = 0, S_SLICE_B = 1, S_SLICE_I = 2 };
+#define S_IS_SKIP(t) ((t) == S_P_SKIP || (t) == S_B_SKIP)
+#define S_IS_DIRECT(t) ((t) == S_B_DIRECT)
 enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
 #define S_COST_MAX (1 << 28)
 #define S_IS_INTRA(t) ((t) >= 0 && (t) <= S_I_PCM)
@@ -129,7 +137,9 @@ typedef struct {
     int8_t *mb_type;          /* as stored by cache_save (x264_mb_type_fix applied: I_8x8 -> I_4x4) */
     i16 *mv;                  /* [n][16][2], 4x4 blocks in raster order inside the macroblock */
     int8_t *ref;              /* [n][4] */
+    i16 *mv1; int8_t *ref1;   /* list 1 (B slices) */
     int poc, n_ref0, ref_poc[16], inv_ref_poc[16];
+    int kept;                 /* b_kept_as_ref */
 } sframe;
 
 typedef struct {                             /* x264_cabac_t, R/common/cabac.h:27-46 */
@@ -174,6 +184,14 @@ typedef struct {
     o_cabac cb;                              /* h->cabac */
     uint32_t nr_sum[2][64], nr_count[2];
     uint16_t nr_offset[2][64];
+    /* B slices */
+    sframe *fref1[2]; int n_ref1;            /* h->fref1 / h->i_ref1 */
+    i16 *mvr1, *mvd1;                        /* h->mb.mvr[1][0], h->mb.mvd[1] */
+    u8 *skipbp;                              /* h->mb.skipbp */
+    int direct_spatial;                      /* sh.b_direct_spatial_mv_pred */
+    int bipred_weight[16][2], dist_scale[16][2];   /* h->mb.bipred_weight / dist_scale_factor (x264_macroblock_bipred_init) */
+    int8_t map_col_store[18];                /* h->mb.map_col_to_list0 with its -1 / -2 entries */
+    int ref_cost1[2];                        /* a->p_cost_ref1 */
 } ssl;
 
 typedef struct {
@@ -205,16 +223,26 @@ typedef struct {
     u8 nz_l[4], nz_t[4], nz_lc[2][2], nz_tc[2][2];      /* neighbours' non_zero_count next to this macroblock (0x80: none) */
     i16 cmvd[48][2];                     /* h->mb.cache.mvd[0], x264_scan8 layout */
     int fenc_satd[4][4], fenc_sa8d[2][2], fenc_satd_sum, fenc_sa8d_sum;   /* h->mb.pic.fenc_satd ... (psy-RD) */
+    /* B slices: list 1 of the caches, the skip flags of direct blocks, the direct prediction, the final list-1 vectors */
+    int8_t cref1[48]; i16 cmv1[48][2], cmvd1[48][2];
+    int8_t cskip[48];                    /* h->mb.cache.skip */
+    int8_t direct_ref[2][4]; i16 direct_mv[2][16][2];   /* h->mb.cache.direct_ref / direct_mv (the 16 blocks in raster order) */
+    i16 mv4_1[16][2]; int8_t ref8_1[4];
 } smb;
+#define CREF(m_, l_) ((l_) ? (m_)->cref1 : (m_)->cref)
+#define CMV(m_, l_) ((l_) ? (m_)->cmv1 : (m_)->cmv)
+#define CMVD(m_, l_) ((l_) ? (m_)->cmvd1 : (m_)->cmvd)
 
 /* what x264_mb_analysis_t keeps of the P analysis (R/encoder/analyse.c:42-137) */
 typedef struct { int mvx, mvy, cost, cost_mv, ref, ref_cost; i16 mvp[2]; } pme;
 typedef struct { int mvx, mvy, cost; i16 mvp[2]; } sub_me;
+struct banalysis;
 typedef struct {
     pme me16, me8[4], me16x8[2], me8x16[2];
     sub_me me4[4][4], me84[4][2], me48[4][2];
     int sub[4];
     int cost8x8, cost16x8, cost8x16, rd16;
+    struct banalysis *B;                 /* the B-slice half of x264_mb_analysis_t (b_oracle.c) */
 } panalysis;
 
 static int s_scan8(int i)
@@ -234,13 +262,14 @@ static sframe *sframe_new(const ssl *S)
     f->plane[0] = f->filt[0];
     f->plane[1] = f->alloc[1] + 16 * S->sc + 16; f->plane[2] = f->alloc[2] + 16 * S->sc + 16;
     f->mb_type = calloc(S->n, 1); f->mv = calloc(S->n * 32, sizeof(i16)); f->ref = calloc(S->n * 4, 1);
+    f->mv1 = calloc(S->n * 32, sizeof(i16)); f->ref1 = calloc(S->n * 4, 1);
     return f;
 }
 static void sframe_free(sframe *f)
 {
     if (!f) return;
     for (int i = 0; i < 3; i++) free(f->alloc[i]);
-    free(f->mb_type); free(f->mv); free(f->ref); free(f);
+    free(f->mb_type); free(f->mv); free(f->ref); free(f->mv1); free(f->ref1); free(f);
 }
 
 /* ------------------------------------------------------------------ neighbour motion state
@@ -428,7 +457,7 @@ static void enc_i8x8(ssl *S, smb *m, int idx)
 static void enc_i16x16(ssl *S, smb *m)
 {
     i16 d[16][4][4], dc[4][4];
-    int b_decimate = S->p->dct_decimate && S->slice_type == S_SLICE_P, score = b_decimate ? 0 : 9, nz;
+    int b_decimate = S->slice_type == S_SLICE_B || (S->p->dct_decimate && S->slice_type == S_SLICE_P), score = b_decimate ? 0 : 9, nz;   /* macroblock.c:193 */
     if (S->lossless) {                                   /* macroblock.c:196-213 */
         for (int i = 0; i < 16; i++) {
             zigf[0].sub_4x4(m->luma4[i], m->fe[0] + blk_x[i] + blk_y[i] * FENC, m->fd[0] + blk_x[i] + blk_y[i] * FDEC);
@@ -472,7 +501,7 @@ static void enc_i16x16(ssl *S, smb *m)
 }
 static void enc_chroma(ssl *S, smb *m, int b_inter)
 {
-    int cat = 2 + b_inter, qpc = S->qpc, b_decimate = b_inter && S->p->dct_decimate;
+    int cat = 2 + b_inter, qpc = S->qpc, b_decimate = b_inter && (S->slice_type == S_SLICE_B || S->p->dct_decimate);   /* macroblock.c:275 */
     int (*dq)[4][4] = (int (*)[4][4])S->dq4[cat];
     m->cbp_chroma = 0;
     for (int ch = 0; ch < 2; ch++) {
@@ -539,7 +568,7 @@ static void enc_chroma(ssl *S, smb *m, int b_inter)
 /* inter luma, R/encoder/macroblock.c:596-768 */
 static void enc_inter_luma(ssl *S, smb *m)
 {
-    int b_decimate = S->p->dct_decimate, decimate_mb = 0;
+    int b_decimate = S->slice_type == S_SLICE_B || S->p->dct_decimate, decimate_mb = 0;   /* macroblock.c:479 */
     if (S->lossless) {                                   /* macroblock.c:602-626 (the 8x8 transform is never chosen for inter here, analyse.c:2111) */
         for (int i = 0; i < 16; i++) {
             zigf[0].sub_4x4(m->luma4[i], m->fe[0] + blk_x[i] + blk_y[i] * FENC, m->fd[0] + blk_x[i] + blk_y[i] * FDEC);
@@ -741,12 +770,14 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
         int c = cmp[X264HIP_PIXEL_16x16](m->fd[0], FDEC, m->fe[0], FENC) + S->lambda * s_ue_size(s_fix16[mode[i]]);
         if (c < m->satd_i16) { m->satd_i16 = c; m->pred16 = mode[i]; }
     }
+    if (S->slice_type == S_SLICE_B) m->satd_i16 += S->lambda * 9;      /* i_mb_b_cost_table[I_16x16], analyse.c:659-661 */
     if (m->fast_intra && m->satd_i16 > 2 * satd_inter) return;
 
     if (flags & 2) {                                           /* X264_ANALYSE_I8x8 */
         u8 edge[40];
         x264hip_pixel_cmp_t sa8d = satd ? pixf.sa8d[X264HIP_PIXEL_8x8] : pixf.sad[X264HIP_PIXEL_8x8];
         int thresh = S->mbrd ? S_COST_MAX : satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = 0, idx;
+        if (S->slice_type == S_SLICE_B) cost += S->lambda * 9;         /* i_mb_b_cost_table[I_8x8], :676-677 */
         m->cbp_luma = 0;
         for (idx = 0;; idx++) {
             int x = idx & 1, y = idx >> 1, best = S_COST_MAX, pm = pred_intra4x4_mode(m, 4 * idx);
@@ -782,6 +813,7 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
         int thresh = satd_inter < m->satd_i16 ? satd_inter : m->satd_i16, cost = S->lambda * 24, idx;
         if (m->satd_i8 < thresh) thresh = m->satd_i8;
         if (S->mbrd) thresh = thresh * (10 - m->fast_intra) / 8;
+        if (S->slice_type == S_SLICE_B) cost += S->lambda * 9;         /* i_mb_b_cost_table[I_4x4], :770-771 */
         m->cbp_luma = 0;
         for (idx = 0;; idx++) {
             u8 *src = m->fe[0] + blk_x[idx] + blk_y[idx] * FENC, *dst = m->fd[0] + blk_x[idx] + blk_y[idx] * FDEC;
@@ -851,14 +883,16 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
     m->nb4[6] = m->nb4[9] = m->nb4[12] = m->nb4[14] = all;
     m->nb4[3] = m->nb4[7] = m->nb4[11] = m->nb4[13] = m->nb4[15] = m->nb8[3] = NB_LEFT | NB_TOP | NB_TOPLEFT;
     m->satd_i16 = m->satd_i8 = m->satd_i4 = m->satd_chroma = S_COST_MAX;
-    if (S->slice_type == S_SLICE_P) {
-        predict_mv_pskip(S, m, m->pskip_mv);
+    if (S->slice_type == S_SLICE_P) predict_mv_pskip(S, m, m->pskip_mv);
+    for (int list = 0; list < (S->slice_type == S_SLICE_B ? 2 : S->slice_type == S_SLICE_P ? 1 : 0); list++) {
         /* h->mb.cache.ref / mv around the macroblock (R/common/macroblock.c:1040-1128): -2 = not available */
-        memset(m->cref, -2, sizeof(m->cref)); memset(m->cmv, 0, sizeof(m->cmv));
-        const i16 *fmv = S->fdec->mv;
-        const int8_t *fref = S->fdec->ref;
-#define NBSET(k_, o_, blk_) do { m->cref[k_] = fref[(o_) * 4 + ((blk_) >> 3) * 2 + (((blk_) & 3) >> 1)]; \
-                                 m->cmv[k_][0] = fmv[((o_) * 16 + (blk_)) * 2]; m->cmv[k_][1] = fmv[((o_) * 16 + (blk_)) * 2 + 1]; } while (0)
+        int8_t *cref = CREF(m, list);
+        i16 (*cmv)[2] = CMV(m, list);
+        memset(cref, -2, 48); memset(cmv, 0, sizeof(m->cmv));
+        const i16 *fmv = list ? S->fdec->mv1 : S->fdec->mv;
+        const int8_t *fref = list ? S->fdec->ref1 : S->fdec->ref;
+#define NBSET(k_, o_, blk_) do { cref[k_] = fref[(o_) * 4 + ((blk_) >> 3) * 2 + (((blk_) & 3) >> 1)]; \
+                                 cmv[k_][0] = fmv[((o_) * 16 + (blk_)) * 2]; cmv[k_][1] = fmv[((o_) * 16 + (blk_)) * 2 + 1]; } while (0)
         if (m->nb & NB_TOPLEFT) NBSET(3, m->mb - S->mb_w - 1, 15);
         if (m->nb & NB_TOP) for (int i = 0; i < 4; i++) NBSET(4 + i, m->mb - S->mb_w, 12 + i);
         if (m->nb & NB_TOPRIGHT) NBSET(8, m->mb - S->mb_w + 1, 12);
@@ -887,14 +921,27 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
             for (int ch = 0; ch < 2; ch++) { m->nz_lc[ch][0] = nz[16 + 4 * ch + 1]; m->nz_lc[ch][1] = nz[16 + 4 * ch + 3]; }
             for (int i = 0; i < 4; i++) { m->cmvd[11 + 8 * i][0] = S->mvd[(l * 16 + 3 + 4 * i) * 2]; m->cmvd[11 + 8 * i][1] = S->mvd[(l * 16 + 3 + 4 * i) * 2 + 1]; }
         }
+        if (S->slice_type == S_SLICE_B) {                /* list 1 of the mvd cache and the skip flags of direct blocks, macroblock.c:1129-1160 */
+            memset(m->cmvd1, 0, sizeof(m->cmvd1)); memset(m->cskip, 0, sizeof(m->cskip));
+            if (m->nb & NB_TOP) {
+                const int t = m->mb - S->mb_w, sb = S->skipbp[t];
+                for (int i = 0; i < 4; i++) { m->cmvd1[4 + i][0] = S->mvd1[(t * 16 + 12 + i) * 2]; m->cmvd1[4 + i][1] = S->mvd1[(t * 16 + 12 + i) * 2 + 1]; }
+                m->cskip[s_scan8(0) - 8] = sb & 4; m->cskip[s_scan8(4) - 8] = sb & 8;
+            }
+            if (m->nb & NB_LEFT) {
+                const int l = m->mb - 1, sb = S->skipbp[l];
+                for (int i = 0; i < 4; i++) { m->cmvd1[11 + 8 * i][0] = S->mvd1[(l * 16 + 3 + 4 * i) * 2]; m->cmvd1[11 + 8 * i][1] = S->mvd1[(l * 16 + 3 + 4 * i) * 2 + 1]; }
+                m->cskip[s_scan8(0) - 1] = sb & 2; m->cskip[s_scan8(8) - 1] = sb & 8;
+            }
+        }
     }
 }
 
-static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by)
+static void set_me_ctx_blk_l(const ssl *S, const smb *m, int list, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by)
 {
     static const u8 bw[7] = {16, 16, 8, 8, 8, 4, 4}, bh[7] = {16, 8, 16, 8, 4, 8, 4};
     int oy = (16 * m->mby + by) * S->sy + 16 * m->mbx + bx, oc = (8 * m->mby + by / 2) * S->sc + 8 * m->mbx + bx / 2, sp[4], fp[4];
-    const sframe *r = S->fref[ref];
+    const sframe *r = list ? S->fref1[ref] : S->fref[ref];
     mv_limits(S->mb_w, S->mb_h, m->mbx, m->mby, S->p->mv_range > 0 ? S->p->mv_range : 512, sp, fp);
     c->fenc = S->fenc->plane[0] + oy; c->fenc_u = S->fenc->plane[1] + oc; c->fenc_v = S->fenc->plane[2] + oc;
     c->sy = S->sy; c->sc = S->sc;
@@ -905,24 +952,28 @@ static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2]
     c->smin[0] = sp[0]; c->smax[0] = sp[1]; c->smin[1] = sp[2]; c->smax[1] = sp[3];
     c->pix = pix; c->bw = bw[pix]; c->bh = bh[pix];
 }
+static void set_me_ctx_blk(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c, int pix, int bx, int by) { set_me_ctx_blk_l(S, m, 0, ref, mvp, c, pix, bx, by); }
 static void set_me_ctx(const ssl *S, const smb *m, int ref, const i16 mvp[2], me_ctx *c) { set_me_ctx_blk(S, m, ref, mvp, c, X264HIP_PIXEL_16x16, 0, 0); }
 /* h->mb.cache.ref / mv helpers: x264_macroblock_cache_ref / _mv (R/common/macroblock.h) on a w x h run of 4x4 blocks */
-static void cache_set(smb *m, int x, int y, int w, int h, int ref, int mvx, int mvy, int set_mv)
+static void cache_set_l(smb *m, int list, int x, int y, int w, int h, int ref, int mvx, int mvy, int set_mv)
 {
     for (int j = 0; j < h; j++)
         for (int i = 0; i < w; i++) {
             int k = 4 + 1 * 8 + x + i + 8 * (y + j);
-            m->cref[k] = (int8_t)ref;
-            if (set_mv) { m->cmv[k][0] = (i16)mvx; m->cmv[k][1] = (i16)mvy; }
+            CREF(m, list)[k] = (int8_t)ref;
+            if (set_mv) { CMV(m, list)[k][0] = (i16)mvx; CMV(m, list)[k][1] = (i16)mvy; }
         }
 }
+static void cache_set(smb *m, int x, int y, int w, int h, int ref, int mvx, int mvy, int set_mv) { cache_set_l(m, 0, x, y, w, h, ref, mvx, mvy, set_mv); }
 /* x264_mb_predict_mv, R/common/macroblock.c:28-88 */
-static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
+static void predict_mv_blk_l(const smb *m, int list, int idx, int width, i16 mvp[2])
 {
-    const int i8 = s_scan8(idx), i_ref = m->cref[i8];
-    int ra = m->cref[i8 - 1], rb = m->cref[i8 - 8], rc = m->cref[i8 - 8 + width], cnt;
-    const i16 *a = m->cmv[i8 - 1], *b = m->cmv[i8 - 8], *c = m->cmv[i8 - 8 + width];
-    if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { rc = m->cref[i8 - 8 - 1]; c = m->cmv[i8 - 8 - 1]; }
+    const int8_t *cref = CREF(m, list);
+    const i16 (*cmv)[2] = CMV(m, list);
+    const int i8 = s_scan8(idx), i_ref = cref[i8];
+    int ra = cref[i8 - 1], rb = cref[i8 - 8], rc = cref[i8 - 8 + width], cnt;
+    const i16 *a = cmv[i8 - 1], *b = cmv[i8 - 8], *c = cmv[i8 - 8 + width];
+    if ((idx & 3) == 3 || (width == 2 && (idx & 3) == 2) || rc == -2) { rc = cref[i8 - 8 - 1]; c = cmv[i8 - 8 - 1]; }
     if (m->partition == S_D_16x8) {
         if (idx == 0 && rb == i_ref) { mvp[0] = b[0]; mvp[1] = b[1]; return; }
         if (idx != 0 && ra == i_ref) { mvp[0] = a[0]; mvp[1] = a[1]; return; }
@@ -936,11 +987,12 @@ static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2])
     else if (rb == -2 && rc == -2 && ra != -2) { mvp[0] = a[0]; mvp[1] = a[1]; }
     else { mvp[0] = s_median(a[0], b[0], c[0]); mvp[1] = s_median(a[1], b[1], c[1]); }
 }
+static void predict_mv_blk(const smb *m, int idx, int width, i16 mvp[2]) { predict_mv_blk_l(m, 0, idx, width, mvp); }
 /* x264_mb_transform_8x8_allowed (R/common/macroblock.h:452-466): large P partitions, P_8x8 only with four 8x8 sub-partitions */
 static int s_t8_allowed(const ssl *S, const smb *m)
 {
     if (!S->p->transform8x8) return 0;
-    if (m->type == S_P_L0) return 1;
+    if (m->type == S_P_L0 || (m->type >= S_B_DIRECT && m->type <= S_B_8x8)) return 1;   /* every B type but B_SKIP (direct_8x8_inference is on) */
     return m->type == S_P_8x8 && m->sub[0] == S_D_L0_8x8 && m->sub[1] == S_D_L0_8x8 && m->sub[2] == S_D_L0_8x8 && m->sub[3] == S_D_L0_8x8;
 }
 #include "cabac_oracle.c"
@@ -979,6 +1031,7 @@ static void mbsyn_fill(const ssl *S, const smb *m, MbSyn *y)
 static void cw_macroblock_chk(ssl *S, o_cabac *cb, int rd, smb *m)
 {
     MbSyn y;
+    if (S->slice_type == S_SLICE_B) { cw_macroblock(S, cb, rd, m); return; }   /* the device code has no B syntax yet */
     DCabac d = {cb->low, cb->range, cb->queue, cb->outstanding, 0, cb->f8};
     u8 st[460], out[64 + 1024], fe[384];
     memcpy(st, cb->state, 460);
@@ -1008,7 +1061,7 @@ static void cw_macroblock_chk(ssl *S, o_cabac *cb, int rd, smb *m)
 static int refine_qpel16(const ssl *S, const me_ctx *c, int cost, int *pmx, int *pmy, const i16 mvp[2])
 {
     int subme = S->p->subme, hpel = me_subpel_iters[subme][0], qpel = me_subpel_iters[subme][1];
-    int satd = subme > 1 && !S->lossless, chroma_me = S->p->chroma_me && subme >= 5 && c->pix <= X264HIP_PIXEL_8x8;   /* b_chroma_me && i_pixel <= PIXEL_8x8, me.c:654 */
+    int satd = subme > 1 && !S->lossless, chroma_me = S->p->chroma_me && S->slice_type == S_SLICE_P && subme >= 5 && c->pix <= X264HIP_PIXEL_8x8;   /* b_chroma_me (P slices only, analyse.c:234) && i_pixel <= PIXEL_8x8, me.c:654 */
     int bx = *pmx, by = *pmy, bc = cost, i, cst;
     if (hpel && subme < 3) {
         int mx = clip3i(mvp[0], c->smin[0], c->smax[0]), my = clip3i(mvp[1], c->smin[1], c->smax[1]);
@@ -1079,6 +1132,8 @@ static void nr_update(ssl *S)
 
 /* x264_analyse_update_cache, R/encoder/analyse.c:2777-2846 (I and P types): the candidate `m->type / m->partition` names becomes
  * the macroblock's vectors, references (h->mb.cache and what cache_save will store) or intra modes.                              */
+struct banalysis;
+static void update_cache_b(ssl *S, smb *m, struct banalysis *B);
 static void fill_part(smb *m, int x, int y, int w, int h, int ref, int mvx, int mvy)
 {
     cache_set(m, x, y, w, h, ref, mvx, mvy, 1);
@@ -1122,7 +1177,10 @@ static void update_cache(ssl *S, smb *m, const panalysis *A)
         fill_part(m, 0, 0, 4, 4, 0, m->pskip_mv[0], m->pskip_mv[1]);
         m->mvx = m->pskip_mv[0]; m->mvy = m->pskip_mv[1]; m->ref = 0;
         break;
+    case S_I_PCM:
+        break;
     default:
+        update_cache_b(S, m, A->B);
         break;
     }
 }
@@ -1172,15 +1230,16 @@ static void transform_rd(ssl *S, smb *m, const panalysis *A, int *i_satd, int *i
         m->t8 = !m->t8;
 }
 
+#include "b_oracle.c"
 static void analyse_mb(ssl *S, smb *m, panalysis *A)
 {
     const slice_params *p = S->p;
     int i_cost = S_COST_MAX;
     m->skip_mc = 0; m->t8 = 0;
     /* x264_mb_analyse_init's fast-intra decision, R/encoder/analyse.c:345-362 */
-    if (S->slice_type == S_SLICE_P && m->mb > 4) {
+    if (S->slice_type != S_SLICE_I && m->mb > 4) {
         int likely = S_IS_INTRA(m->type_left) || S_IS_INTRA(m->type_top) || S_IS_INTRA(m->type_topleft) || S_IS_INTRA(m->type_topright)
-                  || S_IS_INTRA(S->fref[0]->mb_type[m->mb]) || m->mb < 3 * S->intra_count;
+                  || (S->slice_type == S_SLICE_P && S_IS_INTRA(S->fref[0]->mb_type[m->mb])) || m->mb < 3 * S->intra_count;
         m->fast_intra = !likely;
     }
     const int satd_pcm = !S->psy_rd && S->mbrd ? (int)(((uint64_t)(386 * 8) * S->lambda2 + 128) >> 8) : S_COST_MAX;   /* a->i_satd_pcm, :246 */
@@ -1192,6 +1251,8 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
         if (m->satd_i4 < i_cost) { i_cost = m->satd_i4; m->type = S_I_4x4; }
         if (m->satd_i8 < i_cost) { i_cost = m->satd_i8; m->type = S_I_8x8; }
         if (satd_pcm < i_cost) m->type = S_I_PCM;
+    } else if (S->slice_type == S_SLICE_B) {
+        analyse_b(S, m, A, satd_pcm);
     } else {
         int b_skip = 0, try_pskip = 0;
         if (p->fast_pskip && !S->lossless) {
@@ -1476,6 +1537,7 @@ static void update_mb(ssl *S, smb *m)
 }
 
 /* x264_macroblock_encode, R/encoder/macroblock.c:475-790 */
+static void mc_b(const ssl *S, smb *m);
 static void encode_mb(ssl *S, smb *m)
 {
     m->cbp_luma = 0; m->nnz[24] = 0;
@@ -1486,6 +1548,12 @@ static void encode_mb(ssl *S, smb *m)
             mv_clip_frame(S, m, &mvx, &mvy);
             mc_16x16(S, m, 0, mvx, mvy);
         }
+        m->cbp_luma = m->cbp_chroma = 0;
+        memset(m->nnz, 0, sizeof(m->nnz));
+        return;
+    }
+    if (m->type == S_B_SKIP) {                   /* macroblock.c:508-515 */
+        if (!m->skip_mc) mc_b(S, m);
         m->cbp_luma = m->cbp_chroma = 0;
         memset(m->nnz, 0, sizeof(m->nnz));
         return;
@@ -1537,7 +1605,7 @@ static void encode_mb(ssl *S, smb *m)
             enc_i4x4(S, m, 15);
         }
     } else {
-        if (!m->skip_mc) mc_parts(S, m);
+        if (!m->skip_mc) { if (m->type >= S_B_DIRECT) mc_b(S, m); else mc_parts(S, m); }
         enc_inter_luma(S, m);
     }
     if (S_IS_INTRA(m->type)) pred_chroma(S, m, m->chroma_mode);
@@ -1545,6 +1613,7 @@ static void encode_mb(ssl *S, smb *m)
     if (m->type == S_P_L0 && m->partition == S_D_16x16 && !(m->cbp_luma | m->cbp_chroma) && m->mv4[0][0] == m->pskip_mv[0]
         && m->mv4[0][1] == m->pskip_mv[1] && m->ref8[0] == 0)
         m->type = S_P_SKIP;
+    if (m->type == S_B_DIRECT && !(m->cbp_luma | m->cbp_chroma)) m->type = S_B_SKIP;   /* macroblock.c:784-788 */
 }
 
 /* x264_macroblock_cache_save (+ the copy-out the golden harness compares) */
@@ -1563,13 +1632,17 @@ static void save_mb(ssl *S, smb *m)
     }
     S->prev_mb = m->mb;
     if (S->cbp) {
-        S->cbp[m->mb] = (i16)(m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma);
+        S->cbp[m->mb] = (i16)(S_IS_SKIP(m->type) ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma);
         S->chroma_pm[m->mb] = (int8_t)(intra && m->type != S_I_PCM ? s_fix8c[m->chroma_mode] : 0);
         S->qp_mb[m->mb] = (int8_t)m->qp;
         for (int i = 0; i < 16; i++) {
-            const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2), keep = !intra && m->type != S_P_SKIP;
+            const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2), keep = !intra && !S_IS_SKIP(m->type) && !S_IS_DIRECT(m->type);
             S->mvd[(m->mb * 16 + i) * 2] = keep ? m->cmvd[k][0] : 0; S->mvd[(m->mb * 16 + i) * 2 + 1] = keep ? m->cmvd[k][1] : 0;
+            if (S->slice_type == S_SLICE_B) { S->mvd1[(m->mb * 16 + i) * 2] = keep ? m->cmvd1[k][0] : 0; S->mvd1[(m->mb * 16 + i) * 2 + 1] = keep ? m->cmvd1[k][1] : 0; }
         }
+        if (S->slice_type == S_SLICE_B)                  /* macroblock.c:1354-1368 */
+            S->skipbp[m->mb] = m->type == S_B_SKIP || m->type == S_B_DIRECT ? 0xf
+                             : m->type == S_B_8x8 ? (m->sub[0] == S_D_DIRECT_8x8) | (m->sub[1] == S_D_DIRECT_8x8) << 1 | (m->sub[2] == S_D_DIRECT_8x8) << 2 | (m->sub[3] == S_D_DIRECT_8x8) << 3 : 0;
     }
     for (int pl = 0; pl < 3; pl++) {
         int w = pl ? 8 : 16, st = pl ? S->sc : S->sy;
@@ -1588,18 +1661,29 @@ static void save_mb(ssl *S, smb *m)
         S->fdec->mv[(m->mb * 16 + i) * 2 + 1] = intra ? 0 : m->mv4[i][1];
     }
     for (int i = 0; i < 4; i++) S->fdec->ref[m->mb * 4 + i] = intra ? -1 : m->ref8[i];
+    if (S->slice_type == S_SLICE_B) {
+        for (int i = 0; i < 16; i++) {
+            S->fdec->mv1[(m->mb * 16 + i) * 2] = intra ? 0 : m->mv4_1[i][0];
+            S->fdec->mv1[(m->mb * 16 + i) * 2 + 1] = intra ? 0 : m->mv4_1[i][1];
+        }
+        for (int i = 0; i < 4; i++) S->fdec->ref1[m->mb * 4 + i] = intra ? -1 : m->ref8_1[i];
+    }
     if (intra) S->intra_count++;
 
-    o->mb_type[M] = m->type; o->partition[M] = intra || m->type == S_P_SKIP ? S_D_16x16 : m->partition;
-    for (int i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = m->type == S_P_8x8 ? m->sub[i] : 0;
+    o->mb_type[M] = m->type; o->partition[M] = intra || S_IS_SKIP(m->type) || m->type == S_B_DIRECT ? S_D_16x16 : m->partition;
+    for (int i = 0; i < 4; i++) o->sub_partition[M * 4 + i] = m->type == S_P_8x8 || m->type == S_B_8x8 ? m->sub[i] : 0;
     memcpy(o->nnz + M * 27, m->nnz, 27);
     o->qp[M] = m->qp;
-    o->cbp[M] = m->type == S_P_SKIP ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
+    o->cbp[M] = S_IS_SKIP(m->type) ? 0 : (cbp_dc << 8) | (m->cbp_chroma << 4) | m->cbp_luma;
     o->t8[M] = m->t8;
     o->i16mode[M] = m->type == S_I_16x16 ? m->i16mode : 0;
     o->chroma_mode[M] = intra ? m->chroma_mode : 0;
     memcpy(o->i4mode + M * 16, S->i4mode + m->mb * 16, 16);
-    if (S->slice_type == S_SLICE_P) {
+    if (S->o2 && S->o2->mv1) {
+        if (S->slice_type == S_SLICE_B) { memcpy(S->o2->mv1 + M * 32, S->fdec->mv1 + m->mb * 32, 64); memcpy(S->o2->ref1 + M * 4, S->fdec->ref1 + m->mb * 4, 4); }
+        else { memset(S->o2->mv1 + M * 32, 0, 64); memset(S->o2->ref1 + M * 4, -1, 4); }
+    }
+    if (S->slice_type != S_SLICE_I) {
         memcpy(o->mv + M * 32, S->fdec->mv + m->mb * 32, 64);
         memcpy(o->ref + M * 4, S->fdec->ref + m->mb * 4, 4);
         for (int r = 0; r < S->n_ref; r++) {
@@ -1610,7 +1694,7 @@ static void save_mb(ssl *S, smb *m)
         memset(o->ref + M * 4, -1, 4);
     i16 *ly = o->luma + M * 256, *ldc = o->luma_dc + M * 16, *cdc = o->chroma_dc + M * 8, *cac = o->chroma_ac + M * 128;
     memset(ly, 0, 512); memset(ldc, 0, 32); memset(cdc, 0, 16); memset(cac, 0, 256);
-    if (m->type != S_P_SKIP && m->type != S_I_PCM) {
+    if (!S_IS_SKIP(m->type) && m->type != S_I_PCM) {
         if (m->type == S_I_16x16 && m->nnz[24]) memcpy(ldc, m->dc16, 32);
         if (m->t8) {
             for (int i = 0; i < 4; i++) if ((m->cbp_luma >> i & 1) && m->nnz[4 * i]) memcpy(ly + 64 * i, m->luma8[i], 128);
@@ -1678,6 +1762,8 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
     if (p->subme > 5 && (!b_write || !p->cabac || (p->inter & 0x20) || p->qp == 0)) return -3;  /* RD levels: CABAC with the writer in the loop; not yet sub-8x8 / CAVLC / lossless */
     if (b_write && !p->cabac) return -3;
     if (e && e->psy_trellis != 0) return -3;
+    const int nb = e ? clip3i(e->bframes, 0, 16) : 0;
+    if (nb && (!b_write || p->qp == 0 || p->noise_reduction || (e->direct_pred != 1 && e->direct_pred != 2) || p->subme < 1)) return -3;   /* B slices: CABAC with the writer in the loop */
     memset(&S, 0, sizeof(S));
     S.p = p; S.o = o; S.e = e; S.o2 = o2;
     S.chroma_qp_offset = p->chroma_qp_offset;
@@ -1689,7 +1775,6 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
         if (S.psy_rd) S.chroma_qp_offset -= psy < 0.25 ? 1 : 2;
         S.chroma_qp_offset = clip3i(S.chroma_qp_offset, -12, 12);
     }
-    S.mbrd = (p->subme >= 6) + (p->subme >= 8);
     S.lossless = p->qp == 0;                 /* constant QP 0 = lossless (x264_validate_parameters) */
     g_me_lossless = S.lossless;
     S.mb_w = (p->width + 15) / 16; S.mb_h = (p->height + 15) / 16; S.n = S.mb_w * S.mb_h;
@@ -1697,6 +1782,7 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
     S.sy = (S.w16 + 64 + 15) & ~15; S.sc = ((S.sy >> 1) + 15) & ~15;
     S.nnz = calloc(S.n, 27); S.i4mode = calloc(S.n, 16); S.t8 = calloc(S.n, 1);
     S.mvr = calloc((size_t)p->n_refs * S.n * 2, sizeof(i16));
+    S.mvr1 = calloc((size_t)S.n * 2, sizeof(i16)); S.mvd1 = calloc((size_t)S.n * 32, sizeof(i16)); S.skipbp = calloc(S.n, 1);
     S.fenc = sframe_new(&S);
     if (e) {
         S.cbp = calloc(S.n, sizeof(i16)); S.chroma_pm = calloc(S.n, 1); S.mvd = calloc((size_t)S.n * 32, sizeof(i16)); S.qp_mb = calloc(S.n, 1);
@@ -1714,26 +1800,53 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
             for (int i = 0; i < 64; i++) { S.zz8[i] = (u8)l8[i]; S.w8z[i] = w8[k8[((l8[i] >> 1) & 12) | (l8[i] & 3)]]; }
         }
     }
+    /* coding order with a fixed pattern of nb disposable B frames (x264_slicetype_decide without b-adapt, then the reordering of
+     * x264_encoder_encode, R/encoder/encoder.c:1390-1460): an anchor every nb + 1 frames after an IDR, the last frame before the next
+     * IDR / the end of the clip is an anchor too, and every anchor is coded before the B frames it closes */
+    int *order = malloc(sizeof(int) * (p->n_frames + 1)), *ftype = malloc(sizeof(int) * (p->n_frames + 1)), n_order = 0;
+    for (int t = 0; t < p->n_frames;) {
+        if (p->keyint > 0 ? t % p->keyint == 0 : t == 0) { order[n_order] = t; ftype[n_order++] = S_SLICE_I; t++; continue; }
+        int lim = p->keyint > 0 ? (t / p->keyint + 1) * p->keyint : p->n_frames;
+        if (lim > p->n_frames) lim = p->n_frames;
+        const int anchor = t + nb < lim - 1 ? t + nb : lim - 1;
+        order[n_order] = anchor; ftype[n_order++] = S_SLICE_P;
+        for (int b = t; b < anchor; b++) { order[n_order] = b; ftype[n_order++] = S_SLICE_B; }
+        t = anchor + 1;
+    }
+    const int dpb = p->n_refs > (nb ? 2 : 1) ? p->n_refs : (nb ? 2 : 1);   /* sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200 */
     for (int f = 0; f < p->n_frames; f++) {
-        int idr = p->keyint > 0 ? f % p->keyint == 0 : f == 0;
-        size_t F = f;
-        if (idr) { for (int i = 0; i < n_avail; i++) sframe_free(refs[i]); n_avail = 0; last_idr = f; }
-        for (int y = 0; y < p->height; y++) memcpy(S.fenc->plane[0] + y * S.sy, src_y + (F * p->height + y) * p->width, p->width);
+        const int disp = order[f], idr = ftype[f] == S_SLICE_I, is_b = ftype[f] == S_SLICE_B;
+        size_t F = f, D = disp;
+        if (idr) { for (int i = 0; i < n_avail; i++) sframe_free(refs[i]); n_avail = 0; last_idr = disp; }
+        for (int y = 0; y < p->height; y++) memcpy(S.fenc->plane[0] + y * S.sy, src_y + (D * p->height + y) * p->width, p->width);
         for (int y = 0; y < chh; y++) {
-            memcpy(S.fenc->plane[1] + y * S.sc, src_u + (F * chh + y) * cw, cw);
-            memcpy(S.fenc->plane[2] + y * S.sc, src_v + (F * chh + y) * cw, cw);
+            memcpy(S.fenc->plane[1] + y * S.sc, src_u + (D * chh + y) * cw, cw);
+            memcpy(S.fenc->plane[2] + y * S.sc, src_v + (D * chh + y) * cw, cw);
         }
         x264o_plane_pad_mod16(S.fenc->plane[0], S.sy, p->width, p->height, S.w16, S.h16);
         x264o_plane_pad_mod16(S.fenc->plane[1], S.sc, cw, chh, S.w16 / 2, S.h16 / 2);
         x264o_plane_pad_mod16(S.fenc->plane[2], S.sc, cw, chh, S.w16 / 2, S.h16 / 2);
         S.f = f;
         S.fdec = sframe_new(&S);
-        S.fdec->poc = 2 * (f - last_idr);
-        S.n_ref = n_avail < p->n_refs ? n_avail : p->n_refs;
-        for (int i = 0; i < S.n_ref; i++) S.fref[i] = refs[i];
-        S.slice_type = idr ? S_SLICE_I : S_SLICE_P;
-        /* CQP: x264_ratecontrol_new / _start, R/encoder/ratecontrol.c:370-373,845-853 (ip_factor 1.4) */
-        S.frame_qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51) : p->qp;
+        S.fdec->poc = 2 * (disp - last_idr); S.fdec->kept = !is_b;
+        /* x264_reference_build_list, R/encoder/encoder.c:911-981: list 0 = earlier pictures, nearest first; list 1 = later pictures, nearest first */
+        S.n_ref = S.n_ref1 = 0;
+        for (int i = 0; i < n_avail; i++) {
+            if (refs[i]->poc < S.fdec->poc) S.fref[S.n_ref++] = refs[i];
+            else if (refs[i]->poc > S.fdec->poc && S.n_ref1 < 2) S.fref1[S.n_ref1++] = refs[i];
+        }
+        for (int i = 0; i < S.n_ref; i++)
+            for (int k = i + 1; k < S.n_ref; k++)
+                if (S.fref[k]->poc > S.fref[i]->poc) { sframe *t_ = S.fref[i]; S.fref[i] = S.fref[k]; S.fref[k] = t_; }
+        if (S.n_ref1 == 2 && S.fref1[1]->poc < S.fref1[0]->poc) { sframe *t_ = S.fref1[0]; S.fref1[0] = S.fref1[1]; S.fref1[1] = t_; }
+        if (S.n_ref1 > (nb ? 1 : 0)) S.n_ref1 = nb ? 1 : 0;     /* h->frames.i_max_ref1 */
+        if (S.n_ref > p->n_refs) S.n_ref = p->n_refs;
+        S.slice_type = ftype[f];
+        S.direct_spatial = !e || e->direct_pred != 2;
+        /* CQP: x264_ratecontrol_new / _start, R/encoder/ratecontrol.c:370-373,845-853 (ip_factor 1.4, pb_factor 1.3) */
+        S.frame_qp = idr ? clip3i((int)(p->qp - 6.0 * log(1.4f) / log(2.0) + 0.5), 0, 51)
+                   : is_b ? clip3i((int)(p->qp + 6.0 * log(1.3f) / log(2.0) + 0.5), 0, 51) : p->qp;
+        S.mbrd = (p->subme - is_b >= 6) + (p->subme - is_b >= 8);   /* analyse.c:222-225: one level less in B slices */
         S.f_qpm = (float)S.frame_qp;                      /* rc->f_qpm = q, ratecontrol.c:868 (constant QP: an integer) */
         S.cost_mv = 0;
         set_mb_qp(&S, 0, S.frame_qp);
@@ -1746,6 +1859,7 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
             S.fdec->ref_poc[i] = S.fref[i]->poc;
             S.fdec->inv_ref_poc[i] = (256 + delta / 2) / delta;
         }
+        if (is_b) b_slice_init(&S, e);
         S.intra_count = 0; S.stat_intra = S.stat_inter = S.stat_n = 0;
         S.last_qp = S.frame_qp; S.last_dqp = 0; S.i_skip = 0;
         if (b_write) {                                    /* x264_slice_write, R/encoder/encoder.c:1155-1165 */
@@ -1756,6 +1870,7 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
         }
         o->frame_info[4 * F] = S.slice_type; o->frame_info[4 * F + 1] = S.frame_qp; o->frame_info[4 * F + 2] = S.n_ref;
         o->frame_info[4 * F + 3] = S.fdec->poc;
+        if (o2 && o2->frame_info2) { o2->frame_info2[4 * F] = disp; o2->frame_info2[4 * F + 1] = S.n_ref1; o2->frame_info2[4 * F + 2] = !is_b; o2->frame_info2[4 * F + 3] = 0; }
         for (int mb = 0; mb < S.n; mb++) {
             smb m;
             panalysis A;
@@ -1770,19 +1885,22 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
             /* x264_mb_analyse_init, analyse.c:235-252 */
             S.b_trellis = S.trellis > 1 && S.mbrd;
             m.skip_intra = S.lossless ? 0 : S.mbrd ? 2 : !S.trellis && !p->noise_reduction;
-            memset(&A, 0, sizeof(A));
+            struct banalysis BA;
+            memset(&A, 0, sizeof(A)); memset(&BA, 0, sizeof(BA));
+            A.B = &BA;
             analyse_mb(&S, &m, &A);
-            if (S.mbrd) update_cache(&S, &m, &A);          /* :2763 */
+            if (is_b) { update_cache(&S, &m, &A); if (!S.mbrd) analyse_transform_b(&S, &m); b_final_vectors(&m); }   /* :2763-2766 */
+            else if (S.mbrd) update_cache(&S, &m, &A);     /* :2763 */
             else update_mb(&S, &m);
             S.b_trellis = S.trellis;                       /* :2768-2773 */
             if (S.b_trellis == 1 || p->noise_reduction) m.skip_intra = 0;
             encode_mb(&S, &m);
             if (b_write) {                                 /* encoder.c:1192-1205 */
                 if (mb > 0) cb_encode_terminal(&S.cb);
-                if (m.type == S_P_SKIP) cw_mb_skip(&S, &S.cb, &m, 1);
+                if (S_IS_SKIP(m.type)) cw_mb_skip(&S, &S.cb, &m, 1);
                 else {
                     if (S.slice_type != S_SLICE_I) cw_mb_skip(&S, &S.cb, &m, 0);
-                    if (!S_IS_INTRA(m.type)) for (int i = 0; i < 16; i++) {   /* the cache as x264_analyse_update_cache leaves it */
+                    if (!S_IS_INTRA(m.type) && !is_b) for (int i = 0; i < 16; i++) {   /* the cache as x264_analyse_update_cache leaves it */
                         const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2);
                         m.cmv[k][0] = m.mv4[i][0]; m.cmv[k][1] = m.mv4[i][1]; m.cref[k] = m.ref8[(i >> 3) * 2 + ((i & 3) >> 1)];
                     }
@@ -1803,7 +1921,16 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
         }
         if (p->noise_reduction) nr_update(&S);
         o->stat[4 * F] = S.stat_intra; o->stat[4 * F + 1] = S.stat_inter; o->stat[4 * F + 2] = S.stat_n; o->stat[4 * F + 3] = 0;
-        /* x264_fdec_filter_row over the finished frame: loop filter, borders, half-pel planes */
+        /* x264_fdec_filter_row over the finished frame: loop filter, borders, half-pel planes -- nothing of it for a disposable B frame (encoder.c:986-1024) */
+        if (is_b) {
+            for (int y = 0; y < S.h16; y++) memcpy(o->fin_y + (F * S.h16 + y) * S.w16, S.fdec->plane[0] + y * S.sy, S.w16);
+            for (int y = 0; y < S.h16 / 2; y++) {
+                memcpy(o->fin_u + (F * S.h16 / 2 + y) * (S.w16 / 2), S.fdec->plane[1] + y * S.sc, S.w16 / 2);
+                memcpy(o->fin_v + (F * S.h16 / 2 + y) * (S.w16 / 2), S.fdec->plane[2] + y * S.sc, S.w16 / 2);
+            }
+            sframe_free(S.fdec);
+            continue;
+        }
         if (p->deblock) {
             u8 *t = malloc(S.n), *q = malloc(S.n), *t8 = malloc(S.n), *nz = malloc(S.n * 26);
             for (int mb = 0; mb < S.n; mb++) {
@@ -1828,11 +1955,12 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
         }
         for (int i = n_avail; i > 0; i--) refs[i] = refs[i - 1];
         refs[0] = S.fdec; n_avail++;
-        if (n_avail > p->n_refs) sframe_free(refs[--n_avail]);
+        if (n_avail > dpb) sframe_free(refs[--n_avail]);        /* x264_reference_update, encoder.c:1060-1093 */
     }
+    free(order); free(ftype);
     for (int i = 0; i < n_avail; i++) sframe_free(refs[i]);
     sframe_free(S.fenc);
-    free(S.nnz); free(S.i4mode); free(S.t8); free(S.mvr);
+    free(S.nnz); free(S.i4mode); free(S.t8); free(S.mvr); free(S.mvr1); free(S.mvd1); free(S.skipbp);
     free(S.cbp); free(S.chroma_pm); free(S.mvd); free(S.qp_mb); free(S.aq_offset); free(S.bsbuf);
     return 0;
 }

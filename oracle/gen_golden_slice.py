@@ -50,6 +50,7 @@ CASES = [
 # round 2: chains through refslice_encode_chain2 -- the entropy writer in the loop (payload bytes in the fixture), the RD levels
 # (subme 6 / 7), trellis, psy-rd, adaptive quantisation.  (name, size, frames, clip kind, parameters, ext parameters)
 MED = dict(me_method=rs.ME_HEX, n_refs=3, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
+MEDB = dict(MED, inter=0x113, n_refs=2)       # + X264_ANALYSE_BSUB16x16
 CASES2 = [
     ("w_medium_ip", (208, 144), 4, "static", dict(qp=26, subme=5, **MED), dict()),                          # the round-1 medium-like chain, now with its payload
     ("rd6", (208, 144), 4, "moving", dict(qp=28, subme=6, **MED), dict()),
@@ -62,6 +63,11 @@ CASES2 = [
     ("t1_subme4", (200, 120), 4, "moving", dict(qp=30, subme=4, me_method=rs.ME_HEX, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, cabac=1, deblock=1),
      dict(trellis=1)),                                                                                       # trellis without the RD levels: every intra block is coded again
     ("rd7_lowqp", (96, 80), 3, "moving", dict(qp=8, subme=7, **MED), dict(trellis=2, psy_rd=0.0)),            # long levels: the escape codes of the level coding
+    # B slices (coding order in the fixture: I P B B B P B B ...): the medium preset's analysis options with 3 disposable B frames
+    ("b_medium", (208, 144), 8, "moving", dict(qp=26, subme=7, **MEDB), dict(trellis=1, psy_rd=1.0, aq_mode=1, bframes=3, weightb=1, direct_pred=1)),
+    ("b_temporal", (200, 120), 7, "static", dict(qp=28, subme=6, **MEDB), dict(trellis=1, psy_rd=1.0, bframes=2, weightb=0, direct_pred=2)),   # B without the RD levels, P with them
+    ("b_subme5", (208, 144), 6, "moving", dict(qp=30, subme=5, **MEDB), dict(bframes=2, weightb=1, direct_pred=1)),
+    ("b_temporal_rd", (208, 144), 7, "moving", dict(qp=22, subme=7, keyint=6, **MEDB), dict(trellis=2, psy_rd=0.0, bframes=3, weightb=1, direct_pred=2)),   # co-located references outside list 0
 ]
 
 
@@ -85,7 +91,7 @@ def case_inputs(size, frames, kind):
 def masked(a):
     """mvr of skipped macroblocks / unused references is never read by the reference (undefined): zero it."""
     a = dict(a)
-    skip = a["mb_type"] == rs.P_SKIP
+    skip = (a["mb_type"] == rs.P_SKIP) | (a["mb_type"] == rs.B_SKIP)
     m = np.broadcast_to(skip[:, None, :, None], a["mvr"].shape) | \
         (np.arange(a["mvr"].shape[1])[None, :, None, None] >= a["frame_info"][:, 2][:, None, None, None])
     a["mvr"] = np.where(m, 0, a["mvr"]).astype(np.int16)

@@ -8,9 +8,11 @@
  *   x264_macroblock_encode       R/encoder/macroblock.c:475-790
  *   x264_macroblock_cache_save   R/common/macroblock.c:1208-1372
  * followed per frame by the loop filter, border expansion and half-pel planes (the twins above).
- * Supported: I_16x16 / I_4x4 / I_8x8 + chroma, P_SKIP (fast and early), P 16x16 over several
- * references, 8x8 transform choice, CQP, DIA / HEX, subme 0..5.  Not yet: sub-16x16 partitions,
- * B slices, RD, trellis, AQ.  Pinned against the reference's own functions by
+ * Supported: every I, P and B macroblock type x264 core 66 produces (I_16x16 / I_4x4 / I_8x8 / I_PCM, P_SKIP, P 16x16 .. 4x4 over
+ * several references, B_SKIP / B_DIRECT (spatial and temporal) / B 16x16, 16x8, 8x16, 8x8 with list 0, list 1 and bi-prediction,
+ * weighted bi-prediction), the 8x8 transform, DIA / HEX / UMH / ESA, subme 0..7 (mode-decision RD, cabac_oracle.c / rd_oracle.c /
+ * b_oracle.c), trellis 1 and 2, psy-rd, adaptive quantisation, --nr, lossless, the CABAC writer.  Not yet: subme 8-9 (RD refinement),
+ * psy-trellis, CAVLC with the RD levels, B pyramid, adaptive B placement.  Pinned against the reference's own functions by
  * tests/test_oracle_slice.py (oracle/ref_slice.c runs them for the same inputs).               */
 #include <math.h>
 #include <stdio.h>
@@ -192,6 +194,10 @@ typedef struct {
     int bipred_weight[16][2], dist_scale[16][2];   /* h->mb.bipred_weight / dist_scale_factor (x264_macroblock_bipred_init) */
     int8_t map_col_store[18];                /* h->mb.map_col_to_list0 with its -1 / -2 entries */
     int ref_cost1[2];                        /* a->p_cost_ref1 */
+    /* h->mb.cache.ref / mv are never cleared between macroblocks: block 12's entry of either list, as the previous macroblock (of
+     * whatever frame) left it, is what x264_mb_predict_mv_ref16x16 reads as its "direct" candidate when temporal direct prediction
+     * gave up before writing it */
+    int8_t stale_ref[2]; i16 stale_mv[2][2];
 } ssl;
 
 typedef struct {
@@ -898,6 +904,7 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
         if (m->nb & NB_TOPRIGHT) NBSET(8, m->mb - S->mb_w + 1, 12);
         if (m->nb & NB_LEFT) for (int i = 0; i < 4; i++) NBSET(11 + 8 * i, m->mb - 1, 3 + 4 * i);
 #undef NBSET
+        cref[s_scan8(12)] = S->stale_ref[list]; cmv[s_scan8(12)][0] = S->stale_mv[list][0]; cmv[s_scan8(12)][1] = S->stale_mv[list][1];
     }
     m->partition = S_D_16x16;
     /* what the entropy coder reads of the neighbours (R/common/macroblock.c:896-1010,1129-1160) */
@@ -1910,6 +1917,11 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
                 if (o2->mb_bits[F * S.n + mb] / 8 + 2048 > e->payload_cap) return -5;
             }
             save_mb(&S, &m);
+            for (int l = 0; l < (is_b ? 2 : idr ? 0 : 1); l++) {      /* the cache entry the next macroblock inherits (see stale_ref) */
+                const int k = s_scan8(12), inter = !S_IS_INTRA(m.type) && !is_b;
+                S.stale_ref[l] = inter ? m.ref8[3] : CREF(&m, l)[k];
+                S.stale_mv[l][0] = inter ? m.mv4[10][0] : CMV(&m, l)[k][0]; S.stale_mv[l][1] = inter ? m.mv4[10][1] : CMV(&m, l)[k][1];
+            }
             if (o2) o2->qp_offset[F * S.n + mb] = b_aq ? S.aq_offset[mb] : 0;
         }
         if (b_write) {                                     /* encoder.c:1269-1273 */

@@ -31,7 +31,8 @@ if __name__ == "__main__":
         run_case(ora, (160, 128), 5, rs.clip, dict(qp=28, subme=sub, **base), dict(bframes=2, weightb=0, direct_pred=dp))
     else:
         nbad = 0
-        for size in ((208, 144), (200, 120), (96, 80)):
+        sizes = ((208, 144), (200, 120), (96, 80))
+        for size in (sizes if len(sys.argv) < 3 else (sizes[int(sys.argv[2])],)):
             for qp in (12, 22, 30, 40):
                 for subme in (2, 5, 6, 7):
                     for ekw in (dict(bframes=1), dict(bframes=2, weightb=1), dict(bframes=3, weightb=1, direct_pred=2), dict(bframes=2, trellis=1, psy_rd=1.0, aq_mode=1, weightb=1),

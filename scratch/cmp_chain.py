@@ -26,7 +26,7 @@ def static_clip(w, h, n, seed=0):
 
 def compare(a, b, p):
     bad = []
-    skip = a["mb_type"] == rs.P_SKIP
+    skip = (a["mb_type"] == rs.P_SKIP) | (a["mb_type"] == rs.B_SKIP)
     for k in a:
         x, z = a[k], b[k]
         if k == "mvr":

@@ -66,3 +66,10 @@ def test_twin_with_entropy_writer_matches_reference_loop(oracle_lib, name, size,
         assert len(np.unique(want["qp"][1])) > 2 and np.abs(want["qp_offset"]).max() > 0.5
     if kw["subme"] >= 6:
         assert (want["mb_type"][1:] == rs.P_8x8).any() or (want["mb_type"][1:] == rs.P_L0).any()
+    if ekw.get("bframes"):
+        # B slices: the fixture is in coding order (frame_info2 holds the display index); every family of B types occurs, list 1 is used
+        t = want["mb_type"]
+        assert (want["frame_info"][:, 0] == rs.SLICE_B).sum() >= 3 and not np.array_equal(want["frame_info2"][:, 0], np.arange(frames))
+        assert ((t == rs.B_SKIP).any() or kw["qp"] < 24) and (t == rs.B_DIRECT).any() and (t == rs.B_8x8).any() and (t == 16).any() and (t == 12).any()   # B_BI_BI, B_L1_L1
+        assert ((t > rs.B_L0_L0) & (t < 16) & (t != 12)).any()                     # 16x8 / 8x16 with mixed lists
+        assert (want["ref1"] == 0).any() and np.abs(want["mv1"]).max() > 0

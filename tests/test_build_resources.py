@@ -52,12 +52,14 @@ def test_sweep_kernels_use_no_scratch_memory(tmp_path):
 
 
 def test_raster_sweep_resources_are_bounded(tmp_path):
-    """The raster-order variant (RD levels, trellis, the entropy coder in the loop) is new in round 2 and still keeps its trellis
-    survivors and the writer's record in private memory; bound it so that it cannot grow unnoticed (target: 0, like the others)."""
+    """The raster-order variant (RD levels, trellis, the entropy coder in the loop): no private memory either.  (While its encoder
+    had two call sites the compiler kept it as a function and 1.8 KB per lane of shared variables in scratch: rocprofv3 counted 64 KB
+    of HBM writes per macroblock, profiles/r02_raster_traffic.json; one call site -> inlined -> registers.)"""
     md = kernel_metadata(tmp_path)
     rd = [v for k, v in md.items() if "k_slice_sweep" in k and "Lb1EEv" in k]
     assert len(rd) == 1
-    assert rd[0]["private_segment_fixed_size"] <= 2048 and rd[0]["group_segment_fixed_size"] <= 24 * 1024, rd[0]
+    assert rd[0]["private_segment_fixed_size"] == 0 and rd[0]["vgpr_spill_count"] == 0, rd[0]
+    assert rd[0]["group_segment_fixed_size"] <= 24 * 1024, rd[0]
 
 
 def test_no_kernel_spills_registers(tmp_path):

@@ -43,7 +43,10 @@ def run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw, batch=1):
     return out
 
 
-@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", CASES2, ids=[c[0] for c in CASES2])
+IP_CASES2 = [c for c in CASES2 if not c[5].get("bframes")]        # the kernel codes I and P slices; the B chains pin the twin (round 3: the kernel)
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", IP_CASES2, ids=[c[0] for c in IP_CASES2])
 def test_raster_sweep_matches_reference_loop_and_payload(hip_lib, cqm, name, size, frames, kind, kw, ekw):
     with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
         gold = {k: z[k] for k in z.files}

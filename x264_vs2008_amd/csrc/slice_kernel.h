@@ -1796,65 +1796,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             y.lv4 = (i16 (*)[16])s.lv_y; y.lv8 = (i16 (*)[64])s.lv_y8; y.lv_dc = s.lv_dc; y.lv_cdc = (i16 (*)[4])s.lv_cdc; y.lv_cac = (i16 (*)[16])s.lv_cac;
             return y;
         };
-        // x264_rd_cost_mb (R/encoder/rdo.c:139-171): trial encode, distortion, the syntax priced against a copy of the live contexts.
-        // Like the reference it leaves `type` as the encode left it (P_SKIP when nothing was left to code on the skip vector).
-        auto rd_cost_mb = [&]() -> int {
-            const int t8_bak = t8;
-            PROF(6);
-            encode_mb(0);
-            PROF(0);
-            int cost = ssd_mb();
-            if (type == T_P_SKIP) cost += (Q.lambda2 + 128) >> 8;
-            else {
-                syn_prepare();
-                for (int k = lane; k < 460; k += 64) sr.cabac_tmp[k] = sr.cabac[k];
-                const MbSynDev y0 = make_syn();
-                WAVE_SYNC();
-                if (lane == 0) {
-                    DCabac tcb = {0, 0x1FE, -1, 0, nullptr, 0};
-                    MbSynDev y = y0;
-                    cw_macroblock(tcb, sr.cabac_tmp, 1, y, s.fe, 0);
-                    sr.tmp_i[0] = tcb.f8;
-                }
-                WAVE_SYNC();
-                const int f8 = UNI(sr.tmp_i[0]);
-                cost += (int)(((unsigned long long)(u32)f8 * (u32)Q.lambda2 + 32768) >> 16);
-            }
-            t8 = t8_bak;
-            PROF(7);
-            return cost;
-        };
-        (void)cache_fenc_satd; (void)rd_cost_mb;
+        (void)cache_fenc_satd; (void)ssd_mb;
         // a->i_satd_pcm, analyse.c:246
         const int satd_pcm = RD && !rd.psy_rd && mbrd ? (int)(((unsigned long long)(386 * 8) * (u32)Q.lambda2 + 128) >> 8) : MX_COST_MAX;
 
-        if (!is_p) {
-          if constexpr (RD) {
-            // x264_macroblock_analyse, I slice (analyse.c:2169-2186), the RD candidates and the final encode through ONE copy of the encoder
-            if (mbrd) cache_fenc_satd();
-            analyse_intra(MX_COST_MAX);
-#pragma nounroll
-            for (int step = mbrd ? 0 : 3; step < 4; step++) {
-                if (step == 0) { if (!(satd_i16 <= MX_COST_MAX)) continue; type = T_I_16x16; }                                  // x264_intra_rd, :845-874
-                else if (step == 1) { if (!(satd_i4 < MX_COST_MAX)) { satd_i4 = MX_COST_MAX; continue; } type = T_I_4x4; }
-                else if (step == 2) { if (!(satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; } type = T_I_8x8; }
-                else {
-                    type = T_I_16x16;
-                    int i_cost = satd_i16;
-                    if (satd_i4 < i_cost) { i_cost = satd_i4; type = T_I_4x4; }
-                    if (satd_i8 < i_cost) { i_cost = satd_i8; type = T_I_8x8; }
-                    if (satd_pcm < i_cost) type = T_I_PCM;
-                    tq.on = rd.trellis != 0;                                      // analyse.c:2768-2773
-                    if (rd.trellis == 1 || a.nr) skip_intra = 0;
-                    PROF(6);
-                    if (type != T_I_PCM) encode_mb(1);
-                    encoded = true;
-                    break;
-                }
-                const int c = rd_cost_mb();
-                if (step == 0) satd_i16 = c; else if (step == 1) satd_i4 = c; else satd_i8 = c;
-            }
-          } else {
+        if (!RD && !is_p) {
+          {
             analyse_intra(MX_COST_MAX);
             type = T_I_16x16;
             int i_cost = satd_i16;
@@ -1862,18 +1809,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (satd_i8 < i_cost) { i_cost = satd_i8; type = T_I_8x8; }
           }
         } else {
+            // (The raster variant sends an I slice's macroblocks down this path too, its motion parts skipped: the candidate loop at the
+            // end -- and with it the encoder, the distortion and the bit counter -- then exists ONCE in the kernel.  Two call sites of
+            // the encoder made the compiler keep it as a function, and every variable it shares with the rest in scratch memory.)
             // ---- motion neighbours: what cache_load puts around the block (R/common/macroblock.c:1040-1128) ----
             int ra = left_ref, ax = left_mvx, ay = left_mvy;                 // A
             int rb = -2, bx = 0, byv = 0, rc = -2, cx = 0, cy = 0;            // B, C (or D)
-            if (nb & NB_TOP) { const int o = mb - a.mb_w; rb = UNI(a.ref[o * 4 + 2]); bx = UNI(a.mv[(o * 16 + 12) * 2]); byv = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
-            if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = UNI(a.ref[o * 4 + 2]); cx = UNI(a.mv[(o * 16 + 12) * 2]); cy = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
+            if (is_p && (nb & NB_TOP)) { const int o = mb - a.mb_w; rb = UNI(a.ref[o * 4 + 2]); bx = UNI(a.mv[(o * 16 + 12) * 2]); byv = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
+            if (!is_p) {}
+            else if (nb & NB_TOPRIGHT) { const int o = mb - a.mb_w + 1; rc = UNI(a.ref[o * 4 + 2]); cx = UNI(a.mv[(o * 16 + 12) * 2]); cy = UNI(a.mv[(o * 16 + 12) * 2 + 1]); }
             else if (nb & NB_TOPLEFT) { const int o = mb - a.mb_w - 1; rc = UNI(a.ref[o * 4 + 3]); cx = UNI(a.mv[(o * 16 + 15) * 2]); cy = UNI(a.mv[(o * 16 + 15) * 2 + 1]); }
             // The motion cache (h->mb.cache.ref[0] / mv[0], x264_scan8 layout) and the partition analysis' candidate records live in
             // the register file as lane-indexed arrays: entry k = lane k of a VGPR, read with v_readlane (uniform index), written
             // by the lane itself or with v_writelane -- no LDS round trip, no barrier.
             int cref_v = -2, cmvx_v = 0, cmvy_v = 0, pme_v = 0;
             int sub_mx = 0, sub_my = 0, sub_cost = 0, sub_px = 0, sub_py = 0, sub_t = 3;      // sub-8x8 records (lanes 0..31) and chosen type (lanes 0..3)
-            if (RD || (a.flags_inter & 0x10)) {
+            if (is_p && (RD || (a.flags_inter & 0x10))) {
                 // the full motion cache for x264_mb_predict_mv on partitions: -2 = not available, neighbours as cache_load leaves them
                 if ((nb & NB_TOP) && lane >= 4 && lane < 8) {
                     const int o = mb - a.mb_w, k = lane - 4;
@@ -1893,8 +1844,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 }
             }
             if constexpr (RD) {     // the neighbours' part of the motion cache, for the entropy coder's x264_mb_predict_mv / ref contexts
-                if (lane < 48) { sr.cref[lane] = (signed char)cref_v; sr.cmv[lane][0] = (i16)cmvx_v; sr.cmv[lane][1] = (i16)cmvy_v; }
-                WAVE_SYNC();
+                if (is_p) {
+                    if (lane < 48) { sr.cref[lane] = (signed char)cref_v; sr.cmv[lane][0] = (i16)cmvx_v; sr.cmv[lane][1] = (i16)cmvy_v; }
+                    WAVE_SYNC();
+                }
             }
             // x264_mb_predict_mv_16x16, :90-128
             auto predict16 = [&](int i_ref, int &px, int &py) {
@@ -1909,7 +1862,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             else predict16(0, pskx, psky);
 
             int b_skip = 0, try_pskip = 0;
-            if (a.fast_pskip) {
+            if (is_p && a.fast_pskip) {
                 if (a.subme >= 3) try_pskip = 1;
                 else if (left_type == T_P_SKIP || type_top == T_P_SKIP || type_topleft == T_P_SKIP || type_topright == T_P_SKIP) {
                     b_skip = sw_probe_pskip(s, refs, a, Q, pskx, psky, mbx, mby, oy, oc, by_, bc_, lane);
@@ -1925,7 +1878,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 c.cost_g = (MX_GLB(i16))(a.cost_mv + a.cost_center); c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true; c.patch = (MX_LDS(u8))s.patch; c.has_patch = true; c.patch_on = false;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
-                for (int r = 0; r < a.n_refs; r++) {
+                for (int r = 0; r < (is_p ? a.n_refs : 0); r++) {
                     int mvpx, mvpy;
                     predict16(r, mvpx, mvpy);
                     // x264_mb_predict_mv_ref16x16, R/common/macroblock.c:376-437
@@ -2254,31 +2207,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         };
 #pragma nounroll
                         for (int step = 0; step < 11; step++) {
+                            bool fin = false;
                             if (step == 0) {
                                 if (!mbrd) continue;
                                 cache_fenc_satd();
-                                if (!(me16r == 0 && me16x == pskx && me16y == psky)) continue;
+                                if (!is_p || !(me16r == 0 && me16x == pskx && me16y == psky)) continue;
                                 type = T_P_L0; part = 16;
                             } else if (step == 1) {
                                 if (rd_skip) { step = 9; continue; }
-                                type = T_P_L0;
-                                search_partitions();
-                                if (!mbrd) refine_winner();
-                                WAVE_SYNC();
-                                if (part == 13) sub_t_mb = sub_t;
-                                PROF(2);
-                                LAUNDER();
-                                final_type = type; final_part = part;
-                                if (a.chroma_me) {
-                                    analyse_chroma();
-                                    analyse_intra(i_cost - satd_chroma);
-                                    satd_i16 += satd_chroma; satd_i8 += satd_chroma; satd_i4 += satd_chroma;
-                                } else
-                                    analyse_intra(i_cost);
+                                int intra_thresh = MX_COST_MAX;              // an I slice: x264_mb_analyse_intra(h, &analysis, COST_MAX), analyse.c:2175
+                                if (is_p) {
+                                    type = T_P_L0;
+                                    search_partitions();
+                                    if (!mbrd) refine_winner();
+                                    WAVE_SYNC();
+                                    if (part == 13) sub_t_mb = sub_t;
+                                    PROF(2);
+                                    LAUNDER();
+                                    final_type = type; final_part = part;
+                                    intra_thresh = i_cost;
+                                    if (a.chroma_me) { analyse_chroma(); intra_thresh = i_cost - satd_chroma; }
+                                }
+                                analyse_intra(intra_thresh);
+                                if (is_p && a.chroma_me) { satd_i16 += satd_chroma; satd_i8 += satd_chroma; satd_i4 += satd_chroma; }
                                 satd_inter = i_cost; satd_intra = min(min(satd_i16, satd_i8), satd_i4);
                                 if (!mbrd) { step = 9; continue; }
                                 rd_isat = min(satd_inter, satd_intra); rd_thresh = rd_isat * 5 / 4;
                                 type = T_P_L0;
+                                if (!is_p) step = 6;                         // an I slice: straight to x264_intra_rd (:2177)
                                 continue;
                             } else if (step == 2) {
                                 if (!(rd16 == MX_COST_MAX && best <= rd_isat * 3 / 2)) continue;
@@ -2300,17 +2256,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 type = final_type; part = final_part;
                                 if (!(i_cost < MX_COST_MAX) || !a.transform8x8) continue;        // x264_mb_analyse_transform_rd, :2127-2150
                                 t8 = !t8;
-                            } else if (step == 7) {                                                // x264_intra_rd, :845-874
-                                if (!(satd_i16 <= satd_inter * 5 / 4)) { satd_i16 = MX_COST_MAX; continue; }
+                            } else if (step == 7) {                                                // x264_intra_rd, :845-874 (threshold COST_MAX in an I slice)
+                                if (!(satd_i16 <= (is_p ? satd_inter * 5 / 4 : MX_COST_MAX))) { satd_i16 = MX_COST_MAX; continue; }
                                 type = T_I_16x16;
                             } else if (step == 8) {
-                                if (!(satd_i4 <= satd_inter * 5 / 4 && satd_i4 < MX_COST_MAX)) { satd_i4 = MX_COST_MAX; continue; }
+                                if (!(satd_i4 <= (is_p ? satd_inter * 5 / 4 : MX_COST_MAX) && satd_i4 < MX_COST_MAX)) { satd_i4 = MX_COST_MAX; continue; }
                                 type = T_I_4x4;
                             } else if (step == 9) {
-                                if (!(satd_i8 <= satd_inter * 5 / 4 && satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; }
+                                if (!(satd_i8 <= (is_p ? satd_inter * 5 / 4 : MX_COST_MAX) && satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; }
                                 type = T_I_8x8;
                             } else {
-                                if (rd_skip) type = T_P_SKIP;
+                                fin = true;
+                                if (!is_p) {                                 // analyse.c:2179-2184: 16x16, then 4x4, then 8x8, then PCM on strict improvement
+                                    type = T_I_16x16;
+                                    int ic = satd_i16;
+                                    if (satd_i4 < ic) { ic = satd_i4; type = T_I_4x4; }
+                                    if (satd_i8 < ic) { ic = satd_i8; type = T_I_8x8; }
+                                    if (satd_pcm < ic) type = T_I_PCM;
+                                } else if (rd_skip) type = T_P_SKIP;
                                 else {
                                     // analyse.c:2391-2404: best intra type (16x16, then 8x8, then 4x4, then PCM on strict improvement) against inter
                                     int itype = T_I_16x16, icost = satd_i16;
@@ -2322,17 +2285,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     if (icost == MX_COST_MAX) icost = i_cost * satd_intra / satd_inter + 1;
                                     stat_intra = icost; analysed = 1;
                                     stat_inter = i_cost;
-                                    if (mbrd && !IS_INTRA_T(type)) update_cache_p();              // x264_analyse_update_cache, :2763
                                 }
                                 tq.on = rd.trellis != 0;                                          // :2768-2773
                                 if (rd.trellis == 1 || a.nr) skip_intra = 0;
-                                PROF(6);
-                                if (type != T_I_PCM) encode_mb(1);
-                                encoded = true;
-                                break;
                             }
-                            if (!IS_INTRA_T(type)) update_cache_p();
-                            const int c = rd_cost_mb();
+                            // x264_analyse_update_cache (:2763 for the final type), then the encoder: the trial of x264_rd_cost_mb
+                            // (R/encoder/rdo.c:139-171) or the real thing
+                            if ((!fin || mbrd) && !IS_INTRA_T(type)) update_cache_p();
+                            const int t8_bak = t8;
+                            PROF(6);
+                            if (!(fin && type == T_I_PCM)) encode_mb(fin ? 1 : 0);
+                            if (fin) { encoded = true; break; }
+                            PROF(0);
+                            // distortion, and the syntax priced against a copy of the live contexts.  Like the reference this leaves `type`
+                            // as the encode left it (P_SKIP when nothing was left to code on the skip vector).
+                            int c = ssd_mb();
+                            if (type == T_P_SKIP) c += (Q.lambda2 + 128) >> 8;
+                            else {
+                                syn_prepare();
+                                for (int k = lane; k < 460; k += 64) sr.cabac_tmp[k] = sr.cabac[k];
+                                const MbSynDev y0 = make_syn();
+                                WAVE_SYNC();
+                                if (lane == 0) {
+                                    DCabac tcb = {0, 0x1FE, -1, 0, nullptr, 0};
+                                    MbSynDev y = y0;
+                                    cw_macroblock(tcb, sr.cabac_tmp, 1, y, s.fe, 0);
+                                    sr.tmp_i[0] = tcb.f8;
+                                }
+                                WAVE_SYNC();
+                                const int f8 = UNI(sr.tmp_i[0]);
+                                c += (int)(((unsigned long long)(u32)f8 * (u32)Q.lambda2 + 32768) >> 16);
+                            }
+                            t8 = t8_bak;
+                            PROF(7);
                             if (step == 0) { rd16 = c; if (type == T_P_SKIP) rd_skip = true; }
                             else if (step == 2) rd16 = c;
                             else if (step == 3) c16x8 = c;

@@ -35,7 +35,7 @@
 #include "me_exact.h"
 #include "intra_pred.h"
 #include "frame_internal.h"
-#include "trellis_dev.h"
+#include "trellis_wave.h"
 
 using namespace x264hip;
 
@@ -161,7 +161,7 @@ struct SwLdsRd {
     int w4z[16], w8z[64];
     u8 zero16[16];                  // sixteen zeros (SATD / SA8D of the source against nothing)
     int tmp_i[4];                   // lane 0 -> wave: bit count / QP after the writer
-    TrellisScratch ts;
+    TdWave tw;
 };
 struct SwLdsNone { int unused; };
 // the record cabac_dev.h's writer walks (same member names as MbSyn): scalars in registers, arrays where the kernel keeps them in LDS
@@ -424,12 +424,12 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const 
         }
     }
     if (tq.on) {
-        // x264_quant_4x4_trellis (R/encoder/rdo.c:641-650): a serial dynamic programme per block, walked by one lane
+        // x264_quant_4x4_trellis (R/encoder/rdo.c:641-650): four blocks at a time, sixteen lanes each (trellis_wave.h)
         WAVE_SYNC();
-        if (lane == 0)
-            for (int b = 0; b < 16; b++)
-                td_trellis_quant(tq.r->ts, &s.coef[b][0], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
-                                 d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16);
+#pragma nounroll
+        for (int it = 0; it < 4; it++)
+            td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.coef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
+                            d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16, lane);
         WAVE_SYNC();
     }
     if (lane < 16) {
@@ -505,9 +505,11 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const
 {
     if (a.lossless) return sw_ll_luma16(s, true, lane);
     sw_luma4x4_fwd(s, a, Q, tq, 0, true, lane);
+    i16 d[16], t[16];
+    int nz = 0, cbp = 0;
     if (lane == 0) {
         const int b_decimate = a.dct_decimate && a.slice_type == 0;
-        int score = b_decimate ? 0 : 9, cbp = 0;
+        int score = b_decimate ? 0 : 9;
         for (int i = 0; i < 16; i++) {
             int v = s.score[i];
             s.nnz[i] = (u8)(v >> 8);
@@ -515,7 +517,6 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const
         }
         if (score < 6) { cbp = 0; for (int i = 0; i < 16; i++) s.nnz[i] = 0; }
         // dct4x4dc (R/common/dct.c:39-71), quant_4x4_dc, scan, idct4x4dc, dequant_4x4_dc (quant.c:151-178)
-        i16 d[16], t[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
 #pragma unroll
@@ -529,15 +530,22 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const
             d[4 * r + 2] = (i16)((q - w + 1) >> 1); d[4 * r + 3] = (i16)((q + w + 1) >> 1);
         }
         const int mf = (int)s.qmf[0][0] >> 1, bias = (int)s.qbias[0][0] << 1;
-        int nz = 0;
-        if (tq.on) {                                   // x264_quant_dc_trellis( .., DCT_LUMA_DC, 1 ), macroblock.c:247-248
+        if (tq.on) {
 #pragma unroll
             for (int i = 0; i < 16; i++) s.dc16[i] = d[i];
-            nz = td_trellis_quant(tq.r->ts, &s.dc16[0], s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16);
-#pragma unroll
-            for (int i = 0; i < 16; i++) d[i] = s.dc16[i];
         } else
             for (int i = 0; i < 16; i++) { int q = quant_one(d[i], mf, bias); d[i] = (i16)q; nz |= q; }
+    }
+    if (tq.on) {                                       // x264_quant_dc_trellis( .., DCT_LUMA_DC, 1 ), macroblock.c:247-248
+        WAVE_SYNC();
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.dc16[0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16, lane);
+        WAVE_SYNC();
+    }
+    if (lane == 0) {
+        if (tq.on) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) { d[i] = s.dc16[i]; nz |= d[i]; }
+        }
         s.nnz[24] = (u8)(nz != 0);
         if (nz) {
             { i16 lvd[16]; SCAN4_FRAME(lvd, d);
@@ -601,9 +609,9 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
     }
     if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_CHROMA_AC, !b_inter, 0 ), macroblock.c:310-311
         WAVE_SYNC();
-        if (lane == 0)
-            for (int b = 0; b < 8; b++)
-                td_trellis_quant(tq.r->ts, &s.ccoef[b][0], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16);
+#pragma nounroll
+        for (int it = 0; it < 2; it++)
+            td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.ccoef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16, lane);
         WAVE_SYNC();
     }
     if (lane < 8) {
@@ -634,9 +642,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
     }
     if (tq.on) {                                      // x264_quant_dc_trellis( .., DCT_CHROMA_DC, !b_inter ), macroblock.c:325-326
         WAVE_SYNC();
-        if (lane == 0)
-            for (int ch = 0; ch < 2; ch++)
-                td_trellis_quant(tq.r->ts, &s.cdcout[4 * ch], s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4);
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.cdcout[4 * ((lane >> 4) & 1)], lane < 32, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4, lane);
         WAVE_SYNC();
     }
     if (lane < 2) {
@@ -789,11 +795,11 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, const SwQp &Q, SwTq tq,
             }
         }
     WAVE_SYNC();
-    if (tq.on) {                                      // x264_quant_8x8_trellis (R/encoder/rdo.c:652-660), one lane
-        if (lane == 0)
-            for (int j = 0; j < 4; j++)
-                if ((mask >> j) & 1)
-                    td_trellis_quant(tq.r->ts, coef + 64 * j, s.q8mf[cat], tq.r->unq8[cat], tq.r->w8z, tq.r->zz8, tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64);
+    if (tq.on) {                                      // x264_quant_8x8_trellis (R/encoder/rdo.c:652-660): one block at a time (its level lists fill the scratch area), sixteen lanes
+#pragma nounroll
+        for (int j = 0; j < 4; j++)
+            if ((mask >> j) & 1)
+                td_trellis_wave(tq.r->tw, (u32 *)s.patch, coef + 64 * j, lane < 16, s.q8mf[cat], tq.r->unq8[cat], tq.r->w8z, tq.r->zz8, tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64, lane);
         WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -927,7 +933,7 @@ __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, const 
     if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_LUMA_4x4, 1, idx ), macroblock.c:134
         if (lane < 16) s.coef[idx][l16] = (i16)v;
         WAVE_SYNC();
-        if (lane == 0) td_trellis_quant(tq.r->ts, &s.coef[idx][0], s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16);
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.coef[idx][0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16, lane);
         WAVE_SYNC();
         q = s.coef[idx][l16];
     } else

@@ -107,8 +107,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="0: 12 (raster variant) / 24 (--wavefront 1)")
     ap.add_argument("--warmup", type=int, default=-1, help="-1: 2 (raster variant) / 3 (--wavefront 1)")
-    ap.add_argument("--batch", type=int, default=0, help="independent GOP chains advanced per step on each GPU; 0: 1792 for the raster "
-                    "variant (one wavefront per chain: 7 per CU, what its LDS footprint allows), 240 with --wavefront 1")
+    ap.add_argument("--batch", type=int, default=0, help="independent GOP chains advanced per step on each GPU; 0: 2048 (8 wavefronts on each of the 256 CUs) for the raster "
+                    "variant (one wavefront per chain, all resident: what its 20 KB of LDS and 234 VGPRs allow), 240 with --wavefront 1")
     ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
     ap.add_argument("--trellis", type=int, default=1)
     ap.add_argument("--psy-rd", type=float, default=1.0)
@@ -132,7 +132,7 @@ def main():
     wf = bool(args.wavefront)
     args.steps = args.steps or (24 if wf else 12)
     args.warmup = args.warmup if args.warmup >= 0 else (3 if wf else 2)
-    args.batch = args.batch or (240 if wf else 1792)
+    args.batch = args.batch or (240 if wf else 2048)
     args.subme = args.subme or (5 if wf else 7)
     args.keyint = args.keyint or (24 if wf else 12)
     args.cpu_frames = args.cpu_frames or (40 if wf else 12)

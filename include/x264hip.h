@@ -263,6 +263,9 @@ typedef struct x264hip_slice_rd {
     int payload_cap;
     int32_t *payload_len;          /* device [batch] */
     int32_t *mb_bits;              /* optional device [batch][n_mb]: x264_cabac_pos after every macroblock */
+    int i_frame_stride;            /* chain b of the batch has coded i_frame + b * i_frame_stride frames before this one: the chains of a
+                                      launch may be the closed GOPs of ONE stream (GOP g starts keyint frames after GOP g - 1), see
+                                      x264_vs2008_amd/shard.py.  0: every chain counts alike */
 } x264hip_slice_rd;
 #define X264HIP_PAYLOAD_LEAD 64
 

@@ -203,7 +203,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     memset(&r, 0, sizeof(r));
     if (prd) {
         r.on = 1; r.mbrd = mbrd; r.trellis = p->cabac ? prd->trellis : 0; r.psy_rd = mbrd ? prd->psy_rd : 0;
-        r.write = prd->write; r.cabac_init_idc = prd->cabac_init_idc; r.i_frame = prd->i_frame;
+        r.write = prd->write; r.cabac_init_idc = prd->cabac_init_idc; r.i_frame = prd->i_frame; r.i_frame_stride = prd->i_frame_stride;
         r.aq = prd->aq_offset != nullptr; r.qp_min = prd->qp_min; r.qp_max = prd->qp_max; r.chroma_qp_offset = p->chroma_qp_offset;
         r.f_qpm = prd->f_qpm; r.aq_offset = prd->aq_offset; r.cost_mv_all = prd->cost_mv_all;
         r.unq4 = prd->unquant4_mf; r.unq8 = prd->unquant8_mf;

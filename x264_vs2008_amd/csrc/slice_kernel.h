@@ -137,7 +137,7 @@ struct SwLds {
 struct SwRd {                       // kernel argument
     int on;                         // this launch is the raster variant
     int mbrd, trellis, psy_rd;      // a->i_mbrd, param.analyse.i_trellis, h->mb.i_psy_rd
-    int write, cabac_init_idc, i_frame;
+    int write, cabac_init_idc, i_frame, i_frame_stride;
     int aq, qp_min, qp_max, chroma_qp_offset;
     float f_qpm;
     const float *aq_offset;         // [batch][n_mb]
@@ -2371,7 +2371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     else {
                         if (is_p) cw_mb_skip(cab, sr.cabac, left_type, type_top, 0);
                         MbSynDev y = y0;
-                        cw_macroblock(cab, sr.cabac, 0, y, s.fe, rd.i_frame);
+                        cw_macroblock(cab, sr.cabac, 0, y, s.fe, rd.i_frame + bz * rd.i_frame_stride);
                         sr.tmp_i[1] = y.qp;
                     }
                     if (rd.mb_bits) rd.mb_bits[cb + mb] = cd_pos(cab, payload0);
@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
   }   // rows
     if constexpr (RD) {     // x264_slice_write's end (R/encoder/encoder.c:1269-1273)
-        if (rd.write && lane == 0) { cd_encode_flush(cab, rd.i_frame); rd.payload_len[bz] = (int)(cab.p - payload0); }
+        if (rd.write && lane == 0) { cd_encode_flush(cab, rd.i_frame + bz * rd.i_frame_stride); rd.payload_len[bz] = (int)(cab.p - payload0); }
     }
     if (a.nr) {
         if (lane >= 1 && lane < 16 && nr_acc4) atomicAdd(a.nr_sum + (size_t)bz * 128 + lane, (u32)nr_acc4);

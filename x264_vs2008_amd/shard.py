@@ -2,8 +2,9 @@
 
 Frames between two IDR frames reference nothing outside their GOP, so GOPs go
 to ranks round-robin with no pixel exchange; the only cross-GOP state in the
-reference is scalar rate-control history, which stays on the host.  This
-module is pure bookkeeping (no GPU, no collective on the data path)."""
+reference is scalar rate-control history, which stays on the host.  The first
+half of this module is the bookkeeping; encode_clip below is the data path built on it (one rank's GOPs = the batch of the
+raster sweep), gather_digests the only exchange between ranks (results, after coding)."""
 
 
 def gop_bounds(n_frames, keyint):
@@ -30,3 +31,72 @@ def frame_num_and_poc(frame, keyint):
     talking to the others."""
     local = frame % keyint
     return local, 2 * local
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The data path: ONE clip, split into its closed GOPs, the GOPs spread over the ranks (one process per GPU).  A rank advances all
+# of its GOPs together -- they are the chains of the raster sweep's batch, one wavefront each -- so that frame t of every GOP it
+# owns is coded by the same kernel launch.  Nothing is exchanged while coding (a closed GOP references nothing outside itself);
+# what the ranks exchange afterwards is the result: the slice payloads or, as here, their digests.
+
+def encode_clip(hip, cqm, frames, keyint, rank=0, world=1, **options):
+    """Code `frames` (a list of (y, u, v) numpy planes, display order, I/P only) as ONE stream with an IDR every `keyint`
+    frames; this rank codes the GOPs shard.gops_for_rank gives it.  Returns {gop_index: [payload bytes of its frames]}.
+    The payloads are those of a single-process run of the whole clip, bit for bit: frame_num / POC restart at every IDR and the
+    only stream-global quantity in a slice's data, the padding bit x264_cabac_encode_flush derives from the number of frames
+    coded so far (R/common/cabac.c:918), is given to the kernel per chain (x264hip_slice_rd.i_frame_stride)."""
+    from . import slice as sl
+    n = len(frames)
+    gops = gop_bounds(n, keyint)
+    mine = [i for i in range(len(gops)) if i % world == rank]
+    out = {g: [] for g in mine}
+    if not mine:
+        return out
+    h, w = frames[0][0].shape
+    enc = sl.ChainEncoder(hip, w, h, cqm, batch=len(mine), write=1, keyint=keyint, **options)
+    try:
+        # chain b is GOP mine[b] = rank + b * world: frame t of it is frame (rank + b * world) * keyint + t of the stream
+        enc.i_frame, enc.i_frame_stride = rank * keyint, world * keyint
+        for t in range(keyint):
+            live = [b for b, g in enumerate(mine) if gops[g][0] + t < gops[g][1]]
+            if not live:
+                break
+            for b, g in enumerate(mine):            # a GOP cut short by the end of the clip repeats its last frame; the result is dropped
+                y, u, v = frames[min(gops[g][0] + t, gops[g][1] - 1)]
+                enc.upload(y, u, v, b=b)
+            enc.encode_frame()
+            enc.status()
+            pay = enc.payloads()
+            enc.finish_frame()
+            for b in live:
+                out[mine[b]].append(pay[b])
+        enc.ctx.sync()
+    finally:
+        enc.close()
+    return out
+
+
+def payload_digests(per_gop):
+    """{gop_index: sha256 over the GOP's slice payloads (each preceded by its length)} -- what the ranks gather."""
+    import hashlib
+    d = {}
+    for g, pays in per_gop.items():
+        hsh = hashlib.sha256()
+        for p in pays:
+            hsh.update(len(p).to_bytes(4, "little"))
+            hsh.update(p)
+        d[g] = hsh.hexdigest()
+    return d
+
+
+def gather_digests(local, dist=None):
+    """All ranks' {gop: digest} merged on every rank (torch.distributed all_gather_object over gloo -- the payload bytes stay
+    where they are; a muxer would fetch them by GOP index).  Without a process group: the local dictionary."""
+    if dist is None:
+        return dict(local)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return merged

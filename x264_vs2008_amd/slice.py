@@ -35,7 +35,7 @@ class SliceRd(C.Structure):
     _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_int), ("write", C.c_int), ("cabac_init_idc", C.c_int), ("i_frame", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("f_qpm", C.c_float), ("aq_offset", C.c_void_p), ("cost_mv_all", C.c_void_p),
                 ("unquant4_mf", C.c_void_p), ("unquant8_mf", C.c_void_p), ("payload", C.c_void_p), ("payload_cap", C.c_int),
-                ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p)]
+                ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p), ("i_frame_stride", C.c_int)]
 
 
 PAYLOAD_LEAD = 64
@@ -141,7 +141,7 @@ class ChainEncoder:
                 rb["aq_offset"] = DeviceArray(lib, (B, n), np.float32)
             self.rd_bufs = rb
             self.payload_cap = cap
-        self.i_frame = 0
+        self.i_frame, self.i_frame_stride = 0, 0      # shard.py sets both when the chains are the GOPs of one stream
         self.fenc = self.ctx.new_picture()
         self.pool = [self.ctx.new_picture() for _ in range(n_refs + 1)]
         self.states = [DeviceState(self.ctx) for _ in range(n_refs + 1)]
@@ -198,7 +198,8 @@ class ChainEncoder:
             self.rd = SliceRd(trellis=ro["trellis"], psy_rd=self.psy_rd_fix, write=ro["write"], cabac_init_idc=ro["cabac_init_idc"], i_frame=self.i_frame,
                               qp_min=ro["qp_min"], qp_max=ro["qp_max"], f_qpm=float(qp), aq_offset=rb["aq_offset"].ptr if ro["aq_mode"] else None,
                               cost_mv_all=rb["cost_mv_all"].ptr, unquant4_mf=rb["unquant4_mf"].ptr, unquant8_mf=rb["unquant8_mf"].ptr,
-                              payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr)
+                              payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
+                              i_frame_stride=self.i_frame_stride)
             p.rd = C.addressof(self.rd)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]

@@ -1,4 +1,8 @@
-"""The per-frame hot-path pass on the GPU, in the order the reference's frame
+"""NOT THE HOT PATH: the frame-level entry points of round 1 (exhaustive ME surfaces, residual for given vectors, filters) strung
+together for tests/test_gpu_pipeline.py and as a usage example of INTEGRATION.md section 3.  The macroblock loop itself -- analysis,
+mode decision, encode, entropy coding -- is slice.py (ChainEncoder) over x264hip_slice_sweep_frame; bench.py times that.
+
+The per-frame pass on the GPU, in the order the reference's frame
 loop reaches these operations (R/encoder/encoder.c:1406-1421 lowres + AQ,
 R/encoder/analyse.c:2228 motion search per reference, R/encoder/macroblock.c:
 596-768 residual, R/encoder/encoder.c:983-1057 deblock + border + half-pel

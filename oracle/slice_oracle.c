@@ -1023,13 +1023,14 @@ static void mbsyn_fill(const ssl *S, const smb *m, MbSyn *y)
     memset(y, 0, sizeof(*y));
     y->slice_type = S->slice_type; y->type = m->type; y->partition = m->partition;
     y->i16mode = m->i16mode; y->chroma_mode = m->chroma_mode; y->cbp_luma = m->cbp_luma; y->cbp_chroma = m->cbp_chroma; y->t8 = m->t8; y->qp = m->qp;
-    y->n_ref = S->n_ref; y->pps_t8 = S->p->transform8x8; y->t8_allowed = s_t8_allowed(S, m);
+    y->n_ref = S->n_ref; y->n_ref1 = S->n_ref1; y->pps_t8 = S->p->transform8x8; y->t8_allowed = s_t8_allowed(S, m);
     y->type_left = m->type_left; y->type_top = m->type_top; y->cbp_left = m->cbp_left; y->cbp_top = m->cbp_top;
     y->cpm_left = m->cpm_left; y->cpm_top = m->cpm_top; y->nb_t8 = m->nb_t8;
     y->last_qp = S->last_qp; y->last_dqp = S->last_dqp;
     y->prev_coded = m->mb > 0 && (S->fdec->mb_type[S->prev_mb] == S_I_16x16 || (S->cbp[S->prev_mb] & 0x3f));
     memcpy(y->sub, m->sub, 4); memcpy(y->i4c, m->i4c, 48); memcpy(y->cref, m->cref, 48);
     memcpy(y->cmv, m->cmv, sizeof(y->cmv)); memcpy(y->cmvd, m->cmvd, sizeof(y->cmvd));
+    memcpy(y->cref1, m->cref1, 48); memcpy(y->cmv1, m->cmv1, sizeof(y->cmv1)); memcpy(y->cmvd1, m->cmvd1, sizeof(y->cmvd1)); memcpy(y->cskip, m->cskip, 48);
     memcpy(y->nnz, m->nnz, 27);
     memcpy(y->nz_l, m->nz_l, 4); memcpy(y->nz_t, m->nz_t, 4); memcpy(y->nz_lc, m->nz_lc, 4); memcpy(y->nz_tc, m->nz_tc, 4);
     memcpy(y->lv4, m->luma4, sizeof(y->lv4)); memcpy(y->lv8, m->luma8, sizeof(y->lv8)); memcpy(y->lv_dc, m->dc16, sizeof(y->lv_dc));
@@ -1038,7 +1039,6 @@ static void mbsyn_fill(const ssl *S, const smb *m, MbSyn *y)
 static void cw_macroblock_chk(ssl *S, o_cabac *cb, int rd, smb *m)
 {
     MbSyn y;
-    if (S->slice_type == S_SLICE_B) { cw_macroblock(S, cb, rd, m); return; }   /* the device code has no B syntax yet */
     DCabac d = {cb->low, cb->range, cb->queue, cb->outstanding, 0, cb->f8};
     u8 st[460], out[64 + 1024], fe[384];
     memcpy(st, cb->state, 460);
@@ -1051,7 +1051,8 @@ static void cw_macroblock_chk(ssl *S, o_cabac *cb, int rd, smb *m)
     cw_macroblock(S, cb, rd, m);
     devhost_cw_macroblock(&d, st, rd, &y, fe, cb->i_frame);
     g_devcheck_calls++;
-    int bad = memcmp(st, cb->state, 460) != 0 || y.qp != m->qp || memcmp(y.cmvd, m->cmvd, sizeof(y.cmvd)) != 0;
+    int bad = memcmp(st, cb->state, 460) != 0 || y.qp != m->qp || memcmp(y.cmvd, m->cmvd, sizeof(y.cmvd)) != 0
+           || (S->slice_type == S_SLICE_B && memcmp(y.cmvd1, m->cmvd1, sizeof(y.cmvd1)) != 0);
     if (rd) bad |= d.f8 != cb->f8;
     else {
         const int n = (int)(cb->p - p0);

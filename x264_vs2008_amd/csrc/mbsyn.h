@@ -10,10 +10,10 @@ typedef struct DCabac {         // x264_cabac_t's coder registers (R/common/caba
 
 // everything x264_macroblock_write_cabac reads of the macroblock and its neighbours (h->mb, h->mb.cache, h->dct)
 typedef struct MbSyn {
-    int slice_type;             // 0 P, 2 I
+    int slice_type;             // 0 P, 1 B, 2 I
     int type, partition;        // T_* / D_* with the reference's numbering
     int i16mode, chroma_mode, cbp_luma, cbp_chroma, t8, qp;
-    int n_ref;                  // h->mb.pic.i_fref[0]
+    int n_ref, n_ref1;          // h->mb.pic.i_fref[0] / [1]
     int pps_t8, t8_allowed;     // pps->b_transform_8x8_mode, x264_mb_transform_8x8_allowed
     int type_left, type_top;    // -1: not available
     int cbp_left, cbp_top;      // h->mb.cache.i_cbp_left / top, -1: not available
@@ -24,6 +24,9 @@ typedef struct MbSyn {
     signed char i4c[48];        // intra4x4_pred_mode cache, x264_scan8 layout
     signed char cref[48];       // h->mb.cache.ref[0]
     int16_t cmv[48][2], cmvd[48][2];   // h->mb.cache.mv[0] / mvd[0]
+    signed char cref1[48];      // list 1 of the same (B slices)
+    int16_t cmv1[48][2], cmvd1[48][2];
+    signed char cskip[48];      // h->mb.cache.skip: direct blocks, whose references do not count in a reference index's context
     uint8_t nnz[28];            // this macroblock's non_zero_count: 0..15 luma, 16..23 chroma AC, 24 luma DC, 25 / 26 chroma DC
     uint8_t nz_l[4], nz_t[4], nz_lc[2][2], nz_tc[2][2];   // the neighbours' counts next to it, 0x80: none
     int16_t lv4[16][16], lv8[4][64], lv_dc[16], lv_cdc[2][4], lv_cac[8][16];   // h->dct

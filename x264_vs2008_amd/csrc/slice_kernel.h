@@ -170,6 +170,9 @@ struct MbSynDev {
     int type_left, type_top, cbp_left, cbp_top, cpm_left, cpm_top, nb_t8, last_qp, last_dqp, prev_coded;
     signed char *sub, *i4c, *cref;
     i16 (*cmv)[2], (*cmvd)[2];
+    int n_ref1;                          // B slices: list 1 of the caches, the skip flags of direct blocks
+    signed char *cref1, *cskip;
+    i16 (*cmv1)[2], (*cmvd1)[2];
     u8 *nnz, *nz_l, *nz_t;
     u8 (*nz_lc)[2], (*nz_tc)[2];
     i16 (*lv4)[16], (*lv8)[64], *lv_dc, (*lv_cdc)[4], (*lv_cac)[16];

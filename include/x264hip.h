@@ -236,6 +236,12 @@ typedef struct {
     int32_t *progress;     /* [batch][mb_h] + abort flag: the sweep's row counters */
     int poc, n_ref0, inv_ref_poc[8];                   /* x264_frame_t.i_poc / i_ref[0] / inv_ref_poc, filled by the sweep */
     int16_t *mvd;          /* [n][16][2] h->mb.mvd[0] (CABAC contexts of the row below; raster variant only) */
+    /* B slices: list 1 of the same (h->mb.mv[1] / ref[1] / mvr[1][0] / mvd[1]) and h->mb.skipbp */
+    int16_t *mv1;          /* [n][16][2] */
+    int8_t  *ref1;         /* [n][4] */
+    int16_t *mvr1;         /* [n][2] */
+    int16_t *mvd1;         /* [n][16][2] */
+    uint8_t *skipbp;       /* [n] */
 } x264hip_mb_state;
 
 /* ---- round 2: the raster-order variant of the sweep ------------------------------------------------
@@ -270,6 +276,7 @@ typedef struct x264hip_slice_rd {
 #define X264HIP_PAYLOAD_LEAD 64
 
 struct x264hip_slice_rd;
+struct x264hip_slice_b;
 typedef struct {
     int slice_type;                    /* 0 = SLICE_TYPE_P, 2 = SLICE_TYPE_I (R/common/common.h:128-134) */
     int qp, chroma_qp_offset;
@@ -293,7 +300,19 @@ typedef struct {
      * x264_validate_parameters: qp 0 for every slice, chroma_qp_offset 0, fast_pskip 0, noise_reduction 0, 8x8dct only with CABAC */
     int lossless;
     const struct x264hip_slice_rd *rd;   /* NULL: the wavefront schedule of round 1; set: the raster-order variant (below) */
+    const struct x264hip_slice_b *b;     /* slice_type 1 (B): list 1 and what direct prediction reads (below); needs rd */
 } x264hip_slice_params;
+
+/* A B slice (slice_type = 1; the raster variant with the entropy coder: rd set, write = 1, subme 7).  x264 core 66 without
+ * b-pyramid has one list-1 picture and its B frames are disposable (never references).  refs / n_refs of the call are list 0
+ * (x264_reference_build_list, R/encoder/encoder.c:911-981: earlier pictures, nearest first); l0 = refs[0]'s state as always. */
+typedef struct x264hip_slice_b {
+    const x264hip_picture *fref1;        /* h->fref1[0]: the next anchor, reconstructed, borders expanded, half-pel planes built */
+    const x264hip_mb_state *l1_state;    /* the state it was coded with: mb_type / ref / mv of the co-located macroblocks (x264_mb_predict_mv_direct16x16) */
+    int ref1_poc;                        /* h->fref1[0]->i_poc (x264_macroblock_bipred_init, R/common/macroblock.c:1374-1408) */
+    int weightb;                         /* param.analyse.b_weighted_bipred */
+    int direct_spatial;                  /* sh.b_direct_spatial_mv_pred; 0 (temporal) is refused for now */
+} x264hip_slice_b;
 
 /* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:
  * sum [batch][2][64] uint32 (cat 0: 4x4, first 16 used; cat 1: 8x8), count [batch][2] uint32, offset [batch][2][64] uint16 */

@@ -67,6 +67,8 @@ CASES2 = [
     ("b_medium", (208, 144), 8, "moving", dict(qp=26, subme=7, **MEDB), dict(trellis=1, psy_rd=1.0, aq_mode=1, bframes=3, weightb=1, direct_pred=1)),
     ("b_temporal", (200, 120), 7, "static", dict(qp=28, subme=6, **MEDB), dict(trellis=1, psy_rd=1.0, bframes=2, weightb=0, direct_pred=2)),   # B without the RD levels, P with them
     ("b_subme5", (208, 144), 6, "moving", dict(qp=30, subme=5, **MEDB), dict(bframes=2, weightb=1, direct_pred=1)),
+    ("b_rd_2b", (200, 120), 7, "static", dict(qp=31, subme=7, me_method=rs.ME_HEX, n_refs=1, inter=0x113, intra=0x3, transform8x8=1, cabac=1, deblock=1),
+     dict(trellis=2, psy_rd=0.0, bframes=2, weightb=0, direct_pred=1)),                                            # one reference, psy off: I_PCM live in B slices
     ("b_temporal_rd", (208, 144), 7, "moving", dict(qp=22, subme=7, keyint=6, **MEDB), dict(trellis=2, psy_rd=0.0, bframes=3, weightb=1, direct_pred=2)),   # co-located references outside list 0
 ]
 

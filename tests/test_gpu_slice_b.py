@@ -1,0 +1,63 @@
+"""B slices on the GPU (round 2): the raster sweep's B instantiation against the reference's own loop -- coding order, list 0 /
+list 1, spatial direct prediction, bi-prediction with and without weights, b8x8 / 16x8 / 8x16, the B RD decision, bidirectional
+refinement, the CABAC B syntax -- frame after frame, decisions, pixels and payload bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle.gen_golden_slice import CASES2, case_inputs
+from x264_vs2008_amd import slice as sl
+
+pytestmark = pytest.mark.gpu
+B_CASES = [c for c in CASES2 if c[5].get("bframes") and c[5].get("direct_pred", 1) == 1 and c[4]["subme"] == 7]
+STATE = ["mb_type", "partition", "sub_partition", "ref", "mv", "i4mode", "i16mode", "chroma_mode", "qp", "cbp", "t8", "nnz", "luma", "luma_dc", "chroma_dc", "chroma_ac"]
+
+
+def get1(enc, state, name, shape, dt):
+    out = np.zeros(shape, dt)
+    import ctypes as C
+    assert enc.ctx.lib.x264hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(getattr(state.st, name)), C.c_size_t(out.nbytes)) == 0
+    return out
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", B_CASES, ids=[c[0] for c in B_CASES])
+def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, frames, kind, kw, ekw):
+    with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
+        gold = {k: z[k] for k in z.files}
+    y, u, v = case_inputs(size, frames, kind)
+    kw = dict(kw)
+    kw.pop("cqm_preset", 0)
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, **kw, **{k: v_ for k, v_ in ekw.items() if k != "write"})
+    order = sl.coding_order(frames, kw.get("keyint", 0), ekw["bframes"])
+    assert [d for d, _ in order] == gold["frame_info2"][:, 0].tolist() and [t for _, t in order] == gold["frame_info"][:, 0].tolist()
+    n = gold["mb_type"].shape[1]
+    try:
+        for f, (disp, stype) in enumerate(order):
+            enc.upload(y[disp], u[disp], v[disp])
+            st, qp, state = enc.encode_frame(stype=stype, disp=disp)
+            enc.status()
+            assert (st, qp) == (int(gold["frame_info"][f, 0]), int(gold["frame_info"][f, 1])), "frame %d" % f
+            got = {k: state.get(k)[0] for k in STATE}
+            if stype == sl.SLICE_B:
+                got["mv1"] = get1(enc, state, "mv1", (n, 16, 2), np.int16)
+                got["ref1"] = get1(enc, state, "ref1", (n, 4), np.int8)
+            for k in STATE + (["mv1", "ref1"] if stype == sl.SLICE_B else []):
+                if stype == sl.SLICE_I and k in ("mv", "ref"):
+                    continue
+                want = gold[k][f]
+                assert np.array_equal(got[k], want), "frame %d (%s, display %d): %s differs first at %s" % (
+                    f, "IPB"[[2, 0, 1].index(stype)], disp, k, np.argwhere(got[k] != want)[:4].tolist())
+            pay = enc.payloads()[0]
+            want = bytes(gold["payload"][f, :gold["payload_len"][f]])
+            assert pay == want, "frame %d: payload differs (%d vs %d bytes)" % (f, len(pay), len(want))
+            recon = enc.last[0]
+            for nm in ("y", "u", "v"):
+                assert np.array_equal(enc.ctx.download(recon, nm, padded=False, b=0), gold["rec_" + nm][f]), "frame %d rec_%s" % (f, nm)
+            enc.finish_frame()
+            enc.ctx.sync()
+    finally:
+        enc.close()
+    t = gold["mb_type"]
+    assert (t == 18).any() and (t == 16).any() and (t == 17).any()

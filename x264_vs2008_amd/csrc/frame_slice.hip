@@ -4,6 +4,7 @@
 #include "slice_kernel.h"
 
 void x264hip_launch_slice_rd(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
+void x264hip_launch_slice_b(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 
 // b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
 // knowing it (it could not change their type) recorded the statistics term for the other answer in cost_alt.
@@ -50,7 +51,8 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
         {(void **)&st->mv, 64 * n}, {(void **)&st->mvr, 4 * SW_MAX_REFS * n}, {(void **)&st->cbp, 2 * n}, {(void **)&st->nnz, 27 * n},
         {(void **)&st->luma, 512 * n}, {(void **)&st->luma_dc, 32 * n}, {(void **)&st->chroma_dc, 16 * n}, {(void **)&st->chroma_ac, 256 * n},
         {(void **)&st->cost_intra, 4 * n}, {(void **)&st->cost_inter, 4 * n}, {(void **)&st->cost_intra_alt, 4 * n},
-        {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}, {(void **)&st->mvd, 64 * n}};
+        {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}, {(void **)&st->mvd, 64 * n},
+        {(void **)&st->mv1, 64 * n}, {(void **)&st->ref1, 4 * n}, {(void **)&st->mvr1, 4 * n}, {(void **)&st->mvd1, 64 * n}, {(void **)&st->skipbp, n}};
     for (auto &it : items) {
         if (hipMalloc(it.p, it.bytes) != hipSuccess || hipMemsetAsync(*it.p, 0, it.bytes, c->stream) != hipSuccess) {
             set_error("mb_state_alloc: %zu bytes", it.bytes);
@@ -64,7 +66,8 @@ extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st
 {
     (void)c;
     void *ps[] = {st->mb_type, st->partition, st->sub_partition, st->ref, st->i4mode, st->i16mode, st->chroma_mode, st->qp, st->t8, st->mv, st->mvr, st->cbp,
-                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress, st->mvd};
+                  st->nnz, st->luma, st->luma_dc, st->chroma_dc, st->chroma_ac, st->cost_intra, st->cost_inter, st->cost_intra_alt, st->progress, st->mvd,
+                  st->mv1, st->ref1, st->mvr1, st->mvd1, st->skipbp};
     for (void *p : ps) if (p) (void)hipFree(p);
     memset(st, 0, sizeof(*st));
 }
@@ -115,12 +118,20 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
                                          x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
                                          x264hip_mb_state *out)
 {
-    const bool is_p = p->slice_type == 0;
-    if (p->slice_type != 0 && p->slice_type != 2) { set_error("slice_sweep: slice type %d not built (0 P, 2 I)", p->slice_type); return -1; }
+    const bool is_b = p->slice_type == 1, is_p = p->slice_type == 0 || is_b;     // is_p: "has list 0" in what follows
+    if (p->slice_type != 0 && p->slice_type != 1 && p->slice_type != 2) { set_error("slice_sweep: slice type %d (0 P, 1 B, 2 I)", p->slice_type); return -1; }
     if (is_p && (n_refs < 1 || n_refs > SW_MAX_REFS)) { set_error("slice_sweep: %d references (1..%d)", n_refs, SW_MAX_REFS); return -1; }
+    const x264hip_slice_b *pb = is_b ? p->b : nullptr;
+    if (is_b) {
+        if (!pb || !pb->fref1 || !pb->l1_state || !p->rd) { set_error("slice_sweep: a B slice needs x264hip_slice_params.b (list 1) and .rd (the raster variant)"); return -1; }
+        if (!pb->direct_spatial) { set_error("slice_sweep: temporal direct prediction is not built in the kernel yet (spatial is)"); return -1; }
+        if (p->subme != 7 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 7 (mode-decision RD) with the CABAC writer in the loop"); return -1; }
+        if (p->noise_reduction || p->lossless) { set_error("slice_sweep: B slices with --nr / lossless are not built"); return -1; }
+        if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
+    }
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
     const x264hip_slice_rd *prd = p->rd;
-    const int mbrd = (p->subme >= 6) + (p->subme >= 8);
+    const int mbrd = (p->subme - is_b >= 6) + (p->subme - is_b >= 8);       /* one level less in a B slice, R/encoder/analyse.c:222-225 */
     if (p->subme < 0 || p->subme > 7) { set_error("slice_sweep: subme %d (RD refinement of vectors and intra modes) not built", p->subme); return -1; }
     if (mbrd && (!prd || !prd->write || !p->cabac)) { set_error("slice_sweep: subme %d prices its trial encodes against the live CABAC contexts: it needs x264hip_slice_params.rd with write = 1 and cabac = 1", p->subme); return -1; }
     if (prd) {
@@ -159,12 +170,13 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     }
     a.l0_n_ref0 = l0 ? l0->n_ref0 : 0;
     a.me_method = p->me_method; a.me_range = p->me_range; a.subme = p->subme;
-    a.chroma_me = p->chroma_me && is_p && p->subme >= 5;            // h->mb.b_chroma_me, analyse.c:234-235
-    a.fast_pskip = p->fast_pskip; a.dct_decimate = p->dct_decimate; a.cabac = p->cabac; a.mv_range = p->mv_range > 0 ? p->mv_range : 512;
+    a.chroma_me = p->chroma_me && is_p && !is_b && p->subme >= 5;   // h->mb.b_chroma_me, analyse.c:234-235
+    a.fast_pskip = p->fast_pskip; a.cabac = p->cabac; a.mv_range = p->mv_range > 0 ? p->mv_range : 512;
+    a.dct_decimate = p->dct_decimate || is_b;     // B slices always decimate (R/encoder/macroblock.c:193,275,479)
     a.q4mf = p->quant4_mf; a.q4bias = p->quant4_bias; a.dq4 = p->dequant4_mf;
     a.q8mf = p->quant8_mf; a.q8bias = p->quant8_bias; a.dq8 = p->dequant8_mf;
     a.transform8x8 = p->transform8x8 != 0;
-    a.flags_inter = is_p ? (p->analyse_inter & 0x30) : 0; a.mixed_refs = p->mixed_refs != 0;
+    a.flags_inter = is_p ? (p->analyse_inter & (is_b ? 0x100 : 0x30)) : 0; a.mixed_refs = p->mixed_refs != 0;     // B: X264_ANALYSE_BSUB16x16
     // x264_mb_analyse_intra takes its flags from param.analyse.intra in I slices and from .inter in P slices (analyse.c:614);
     // i8x8 needs the 8x8 transform (x264_validate_parameters, R/encoder/encoder.c:487-491)
     a.flags_intra = (is_p ? p->analyse_inter : p->analyse_intra) & (a.transform8x8 ? 3 : 1);
@@ -192,6 +204,26 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         for (int k = 0; k < 4; k++) t.y[i][k] = r->filtered[k];
         t.u[i] = r->plane[1]; t.v[i] = r->plane[2];
     }
+    if (is_b) {                                                      // x264_macroblock_bipred_init, R/common/macroblock.c:1374-1408
+        for (int k = 0; k < 4; k++) t.y1[k] = pb->fref1->filtered[k];
+        t.u1 = pb->fref1->plane[1]; t.v1 = pb->fref1->plane[2];
+        for (int i = 0; i < SW_MAX_REFS; i++) {
+            const int poc0 = p->ref_poc[i < n_refs ? i : 0];
+            int td = pb->ref1_poc - poc0; td = td < -128 ? -128 : td > 127 ? 127 : td;
+            int dsf = 256;
+            if (td) {
+                int tb = p->poc - poc0; tb = tb < -128 ? -128 : tb > 127 ? 127 : tb;
+                const int tx = (16384 + (abs(td) >> 1)) / td;
+                dsf = (tb * tx + 32) >> 6; dsf = dsf < -1024 ? -1024 : dsf > 1023 ? 1023 : dsf;
+            }
+            dsf >>= 2;
+            t.biw[i] = pb->weightb && dsf >= -64 && dsf <= 128 ? 64 - dsf : 32;
+        }
+    } else {
+        for (int k = 0; k < 4; k++) t.y1[k] = t.y[0][k];
+        t.u1 = t.u[0]; t.v1 = t.v[0];
+        for (int i = 0; i < SW_MAX_REFS; i++) t.biw[i] = 32;
+    }
     HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
     static int wpe = 0;
     if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..3
@@ -209,6 +241,11 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         r.unq4 = prd->unquant4_mf; r.unq8 = prd->unquant8_mf;
         r.payload = prd->payload; r.payload_cap = prd->payload_cap; r.payload_len = prd->payload_len; r.mb_bits = prd->mb_bits;
         r.mvd = out->mvd;
+        if (is_b) {
+            r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
+            r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
+            x264hip_launch_slice_b(a, t, r, c->stream);
+        } else
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
@@ -224,7 +261,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
                            (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
     HIPCHK(hipGetLastError());
     // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
-    out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;
+    out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;     /* (a B frame's state is never read by later frames) */
     for (int i = 0; i < SW_MAX_REFS; i++) {
         int delta = i < n_refs && is_p ? p->poc - p->ref_poc[i] : 0;
         out->inv_ref_poc[i] = delta ? (256 + delta / 2) / delta : 0;

@@ -46,7 +46,9 @@ using namespace x264hip;
 #define FDU (19 * FD)
 #define FDV (19 * FD + 16)
 
-enum { T_I_4x4 = 0, T_I_8x8 = 1, T_I_16x16 = 2, T_I_PCM = 3, T_P_L0 = 4, T_P_8x8 = 5, T_P_SKIP = 6 };
+enum { T_I_4x4 = 0, T_I_8x8 = 1, T_I_16x16 = 2, T_I_PCM = 3, T_P_L0 = 4, T_P_8x8 = 5, T_P_SKIP = 6,
+       T_B_DIRECT = 7, T_B_L0_L0 = 8, T_B_L1_L1 = 12, T_B_BI_BI = 16, T_B_8x8 = 17, T_B_SKIP = 18 };
+#define IS_SKIP_T(t) ((t) == T_P_SKIP || (t) == T_B_SKIP)
 enum { NB_LEFT = 1, NB_TOP = 2, NB_TOPRIGHT = 4, NB_TOPLEFT = 8 };
 #define IS_INTRA_T(t) ((t) >= 0 && (t) <= T_I_PCM)
 
@@ -56,6 +58,9 @@ struct SwRefs {
     // everything indexed by a run-time reference number lives here, in the argument the kernel never writes: SwArgs is adjusted per
     // chain at the top of the kernel, and a modified argument struct with a dynamically indexed member is kept in scratch memory whole
     int ref_bits[SW_MAX_REFS], poc_delta[SW_MAX_REFS], l0_inv_ref_poc[SW_MAX_REFS];   // REF_COST = lambda * ref_bits (bs_size_te, R/encoder/analyse.c:195-197)
+    // B slices: the list-1 picture (x264 core 66 without b-pyramid has one) and h->mb.bipred_weight[list-0 reference][0]
+    const u8 *y1[4], *u1, *v1;
+    int biw[SW_MAX_REFS];
 };
 struct SwArgs {
     int mb_w, mb_h, sy, sc, batch, batch_pad;
@@ -145,7 +150,32 @@ struct SwRd {                       // kernel argument
     const int *unq4, *unq8;         // h->unquant4_mf [4][52][16], h->unquant8_mf [2][52][64]
     u8 *payload; int payload_cap; int *payload_len, *mb_bits;
     i16 *mvd;                       // h->mb.mvd[0]: [batch][n_mb][16][2]
+    // B slices: list 1 of the per-macroblock state, h->mb.skipbp, and the co-located picture's arrays (direct prediction)
+    i16 *mv1, *mvr1, *mvd1;
+    signed char *ref1;
+    u8 *skipbp;
+    const signed char *col_type, *col_ref;
+    const i16 *col_mv;
 };
+// what a B slice adds to the wavefront's LDS: list 1 of the motion caches, the direct prediction, the analysis records
+struct SwLdsB {
+    signed char cref1[48], cskip[48];
+    i16 cmv1[48][2], cmvd1[48][2];
+    signed char dref[2][4], sub[4];     // h->mb.cache.direct_ref; h->mb.i_sub_partition
+    i16 dmv[2][16][2];                  // h->mb.cache.direct_mv (the 16 blocks in raster order)
+    i16 mv4_1[16][2];
+    signed char ref8_1[4];
+    i16 left_mv4_1[4][2], left_mvd1[4][2], left_mvr1[2];
+    signed char left_r8_1[2];
+    u8 left_skipbp;
+    int me[2][9][6];                    // x264_me_t records of a->l0 / a->l1: [list][me16x16, me8x8 x 4, me16x8 x 2, me8x16 x 2][mv x, y, cost, cost_mv, mvp x, y]
+    int cost8direct[4];
+    u8 visited[512];                    // x264_me_refine_bidir's visited[8][8][8]
+};
+struct SwLdsRdB;
+// x264_me_refine_bidir's 32 candidate offsets per pass in evaluation order (CHECK_BIDIR8 / CHECK_BIDIR2, R/encoder/me.c:893-909):
+// (m0x, m0y, m1x, m1y) offsets + 1 in four 2-bit fields
+static __device__ const u8 c_bidir_dirs[32] = {149, 21, 101, 69, 89, 81, 86, 84, 165, 5, 105, 65, 90, 80, 150, 20, 153, 17, 102, 68, 133, 37, 97, 73, 88, 82, 22, 148, 145, 25, 100, 70};
 struct SwLdsRd {
     u8 cabac[460], cabac_tmp[460];  // h->cabac.state and the RD trial's copy (COPY_CABAC, R/encoder/rdo.c:62)
     // what the entropy coder reads beyond SwLds (MbSynDev below points into both)
@@ -164,6 +194,7 @@ struct SwLdsRd {
     TdWave tw;
 };
 struct SwLdsNone { int unused; };
+struct SwLdsRdB { SwLdsRd r; SwLdsB b; };
 // the record cabac_dev.h's writer walks (same member names as MbSyn): scalars in registers, arrays where the kernel keeps them in LDS
 struct MbSynDev {
     int slice_type, type, partition, i16mode, chroma_mode, cbp_luma, cbp_chroma, t8, qp, n_ref, pps_t8, t8_allowed;
@@ -504,14 +535,14 @@ __device__ __forceinline__ int sw_encode_inter_luma(SwLds &s, const SwArgs &a, c
     return keep;
 }
 // x264_mb_encode_i16x16 (prediction already in s.fd); returns cbp_luma, fills s.nnz[0..15], s.nnz[24]
-__device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int lane)
+__device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int lane, bool b_slice = false)
 {
     if (a.lossless) return sw_ll_luma16(s, true, lane);
     sw_luma4x4_fwd(s, a, Q, tq, 0, true, lane);
     i16 d[16], t[16];
     int nz = 0, cbp = 0;
     if (lane == 0) {
-        const int b_decimate = a.dct_decimate && a.slice_type == 0;
+        const int b_decimate = b_slice || (a.dct_decimate && a.slice_type == 0);     // macroblock.c:193: B always, P with dct_decimate
         int score = b_decimate ? 0 : 9;
         for (int i = 0; i < 16; i++) {
             int v = s.score[i];
@@ -1235,14 +1266,18 @@ static __device__ const int d_lambda2_tab[52] = {14, 18, 22, 28, 36, 45, 57, 72,
 static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
                                               29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
-template <int WPE, bool LL = false, bool RD = false>
+template <int WPE, bool LL = false, bool RD = false, bool BS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
 {
+    static_assert(!BS || RD, "B slices run in the raster variant");
+#undef IS_SKIP_T
+#define IS_SKIP_T(t) (BS ? ((t) == T_P_SKIP || (t) == T_B_SKIP) : (t) == T_P_SKIP)      /* BS is a template constant: the other kernels keep their single compare */
     __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
                                                         // kernel argument is copied to scratch memory whole)
     __shared__ SwLds s;
-    __shared__ typename std::conditional<RD, SwLdsRd, SwLdsNone>::type sr_;
+    __shared__ typename std::conditional<BS, SwLdsRdB, typename std::conditional<RD, SwLdsRd, SwLdsNone>::type>::type sr_;
     SwLdsRd &sr = *(SwLdsRd *)&sr_;                     // only touched when RD
+    SwLdsB &sb = *(SwLdsB *)((char *)&sr_ + sizeof(SwLdsRd));    // only touched when BS (then sr_ is an SwLdsRdB)
     const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = RD ? (int)blockIdx.x : (int)(blockIdx.x % a.batch_pad), mby0 = RD ? 0 : (int)(blockIdx.x / a.batch_pad);
     if (bz >= a.batch) return;
@@ -1264,7 +1299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         const int cat = lane >> 4, i = lane & 15, q = cat < 2 ? Q.qp : Q.qpc;
         s.qmf[cat][i] = a.q4mf[(cat * 52 + q) * 16 + i]; s.qbias[cat][i] = a.q4bias[(cat * 52 + q) * 16 + i];
         s.qdq[cat][i] = a.dq4[cat * 96 + (q % 6) * 16 + i];
-        if (is_p)
+        if (is_p || BS)
             for (int k = lane; k < 2 * MX_COST_LDS + 1; k += 64) s.costl[k] = cost_g[k - MX_COST_LDS];
         if (a.transform8x8)
             for (int c8 = 0; c8 < 2; c8++) {
@@ -1464,9 +1499,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // bounds leave the answer open (the rows above never wait for this one, so this terminates).
         // wait = 0: answer 0 / 1, or 2 when the bounds do not decide it yet; wait = 1: poll until they do
         auto fast_intra_now = [&](int wait) -> int {
-            if (!is_p || mb <= 4) return 0;
+            if ((!is_p && !BS) || mb <= 4) return 0;
             if (IS_INTRA_T(left_type) || IS_INTRA_T(type_top) || IS_INTRA_T(type_topleft) || IS_INTRA_T(type_topright)) return 0;
-            if (a.l0_type && IS_INTRA_T(UNI(a.l0_type[mb]))) return 0;
+            if ((!BS || is_p) && a.l0_type && IS_INTRA_T(UNI(a.l0_type[mb]))) return 0;      // only in a P slice (analyse.c:357)
             if constexpr (RD) return mb < 3 * intra_before ? 0 : 1;        // raster order: every earlier macroblock is done
             for (int spins = 0;; spins++) {
                 int known = row_intra, pending = 0;
@@ -1496,6 +1531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (c < satd_i16) { satd_i16 = c; pred16 = m; }
                 }
             }
+            if constexpr (BS) satd_i16 += Q.lambda * 9;                  // i_mb_b_cost_table[I_16x16], analyse.c:659-661
             if (!(a.flags_intra & 3)) return;
             if (satd_i16 > 2 * satd_inter) {
                 // b_fast_intra would end the analysis here.  If the raster-order count behind it is not decidable yet, go on
@@ -1507,7 +1543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             }
             if (a.flags_intra & 2) {                                   // X264_ANALYSE_I8x8
                 const int thresh = mbrd ? MX_COST_MAX : min(satd_inter, satd_i16);
-                int cost = 0, idx, acbp = 0;
+                int cost = BS ? Q.lambda * 9 : 0, idx, acbp = 0;            // i_mb_b_cost_table[I_8x8], :676-677
                 for (idx = 0;; idx++) {
                     const int bx = 8 * (idx & 1), by = 8 * (idx >> 1), pm = sw_pred_i4mode(s, 4 * idx), nb8 = sw_nb8(idx, nb);
                     int n;
@@ -1578,7 +1614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             if (a.flags_intra & 1) {                                   // X264_ANALYSE_I4x4
                 int thresh = min(min(satd_inter, satd_i16), satd_i8);
                 if (mbrd) thresh = thresh * (10 - fast_intra_now(0)) / 8;
-                int cost = Q.lambda * 24, idx, acbp = 0;
+                int cost = Q.lambda * (BS ? 24 + 9 : 24), idx, acbp = 0;    // + i_mb_b_cost_table[I_4x4] in a B slice, :770-771
                 for (idx = 0;; idx++) {
                     int bx, by, n;
                     sw_blk_xy(idx, bx, by);
@@ -1652,11 +1688,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             cbp_luma = 0; cbp_chroma = 0;
             if (lane < 32) s.nnz[lane] = 0;
             WAVE_SYNC();
+            if (BS && type == T_B_SKIP) return;              // x264_macroblock_encode_skip: the prediction (made by the caller) is the reconstruction
             if (type == T_I_16x16) {
                 t8 = 0;
                 analyse_chroma();
                 sw_pred16(s, pred16, lane, a.lossless);
-                cbp_luma = sw_encode_i16x16(s, a, Q, tq, lane);
+                cbp_luma = sw_encode_i16x16(s, a, Q, tq, lane, BS);
                 sw_pred8c(s, predc, lane, a.lossless);
                 cbp_chroma = sw_encode_chroma(s, a, Q, tq, 0, lane);
             } else if (type == T_I_8x8 || type == T_I_4x4) {
@@ -1711,7 +1748,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 sw_pred8c(s, predc, lane, a.lossless);
                 cbp_chroma = sw_encode_chroma(s, a, Q, tq, 0, lane);
             } else {
-                sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);
+                if constexpr (!BS) sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);    // (B slice: the caller has run the bi-predictive motion compensation)
                 WAVE_SYNC();
                 // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
                 if (!mbrd && a.transform8x8 && !a.lossless && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
@@ -1731,6 +1768,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 cbp_luma = t8 ? sw_encode_inter_luma8(s, a, Q, tq, lane, &nr_acc8, nr_on) : sw_encode_inter_luma(s, a, Q, tq, lane, &nr_acc4, nr_on);   // never a conditional pointer: that pins the counter in scratch memory
                 cbp_chroma = sw_encode_chroma(s, a, Q, tq, 1, lane);
                 if (type == T_P_L0 && part == 16 && !(cbp_luma | cbp_chroma) && mvx == pskx && mvy == psky && ref == 0) type = T_P_SKIP;
+                if (BS && type == T_B_DIRECT && !(cbp_luma | cbp_chroma)) type = T_B_SKIP;       // macroblock.c:784-788
             }
         };
 
@@ -1796,11 +1834,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             y.slice_type = a.slice_type; y.type = type; y.partition = part; y.i16mode = pred16; y.chroma_mode = predc;
             y.cbp_luma = cbp_luma; y.cbp_chroma = cbp_chroma; y.t8 = t8; y.qp = Q.qp; y.n_ref = a.n_refs; y.pps_t8 = a.transform8x8;
             y.t8_allowed = a.transform8x8 && (type == T_P_L0 || (type == T_P_8x8 && __ballot(lane < 4 && sub_t_mb != 3) == 0));
+            if constexpr (BS) y.t8_allowed = a.transform8x8 && type >= T_B_DIRECT && type <= T_B_8x8;
             // h->mb.type[] holds x264_mb_type_fix'ed types (I_8x8 is stored as I_4x4, R/common/macroblock.c:1209,1226)
             y.type_left = left_type == T_I_8x8 ? T_I_4x4 : left_type; y.type_top = type_top == T_I_8x8 ? T_I_4x4 : type_top; y.cbp_left = left_cbp; y.cbp_top = cbp_top; y.cpm_left = left_cpm; y.cpm_top = cpm_top;
             y.nb_t8 = (left_type >= 0 && left_t8) + (type_top >= 0 && t8_top);
             y.last_qp = last_qp; y.last_dqp = last_dqp; y.prev_coded = prev_coded;
             y.sub = sr.sub; y.i4c = s.i4c; y.cref = sr.cref; y.cmv = sr.cmv; y.cmvd = sr.cmvd;
+            y.n_ref1 = 0; y.cref1 = nullptr; y.cskip = nullptr; y.cmv1 = nullptr; y.cmvd1 = nullptr;
+            if constexpr (BS) { y.n_ref1 = 1; y.sub = sb.sub; y.cref1 = sb.cref1; y.cskip = sb.cskip; y.cmv1 = sb.cmv1; y.cmvd1 = sb.cmvd1; }
             y.nnz = s.nnz; y.nz_l = sr.nz_l; y.nz_t = sr.nz_t; y.nz_lc = sr.nz_lc; y.nz_tc = sr.nz_tc;
             y.lv4 = (i16 (*)[16])s.lv_y; y.lv8 = (i16 (*)[64])s.lv_y8; y.lv_dc = s.lv_dc; y.lv_cdc = (i16 (*)[4])s.lv_cdc; y.lv_cac = (i16 (*)[16])s.lv_cac;
             return y;
@@ -1809,6 +1850,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         // a->i_satd_pcm, analyse.c:246
         const int satd_pcm = RD && !rd.psy_rd && mbrd ? (int)(((unsigned long long)(386 * 8) * (u32)Q.lambda2 + 128) >> 8) : MX_COST_MAX;
 
+        if constexpr (BS) {
+#include "slice_b_flow.h"
+        } else
         if (!RD && !is_p) {
           {
             analyse_intra(MX_COST_MAX);
@@ -2370,9 +2414,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 const MbSynDev y0 = make_syn();
                 if (lane == 0) {
                     if (mb > 0) cd_encode_terminal(cab);
-                    if (type == T_P_SKIP) cw_mb_skip(cab, sr.cabac, left_type, type_top, 1);
+                    if (IS_SKIP_T(type)) cw_mb_skip(cab, sr.cabac, left_type, type_top, 1, a.slice_type);
                     else {
-                        if (is_p) cw_mb_skip(cab, sr.cabac, left_type, type_top, 0);
+                        if (is_p || BS) cw_mb_skip(cab, sr.cabac, left_type, type_top, 0, a.slice_type);
                         MbSynDev y = y0;
                         cw_macroblock(cab, sr.cabac, 0, y, s.fe, rd.i_frame + bz * rd.i_frame_stride);
                         sr.tmp_i[1] = y.qp;
@@ -2380,7 +2424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (rd.mb_bits) rd.mb_bits[cb + mb] = cd_pos(cab, payload0);
                 }
                 WAVE_SYNC();
-                if (type != T_P_SKIP) mb_qp = UNI(sr.tmp_i[1]);
+                if (!IS_SKIP_T(type)) mb_qp = UNI(sr.tmp_i[1]);
             }
             // x264_macroblock_cache_save's QP rules (R/common/macroblock.c:1244-1272): a macroblock without coefficients has no QP of its own
             if (type == T_I_PCM) { mb_qp = 0; last_dqp = 0; if (lane < 27) s.nnz[lane] = 16; WAVE_SYNC(); }
@@ -2412,25 +2456,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 s.left_i4[lane == 5 ? 0 : lane == 7 ? 1 : lane == 13 ? 2 : 3] = i48 ? s.i4c[sw_scan8(lane)] : (signed char)2;
         }
         if (lane < 4) {
-            const signed char rv = (signed char)(is_p ? (intra ? -1 : s.ref8[lane]) : -1);
+            const signed char rv = (signed char)(is_p || BS ? (intra ? -1 : s.ref8[lane]) : -1);
             a.ref[(size_t)mb * 4 + lane] = rv;
             if (lane & 1) s.left_r8[lane >> 1] = rv;
         }
-        if (lane < 27) (a.nnz + 27 * cb)[(size_t)mb * 27 + lane] = type == T_P_SKIP ? (u8)0 : s.nnz[lane];
-        if (lane < 4) (a.sub_partition + 4 * cb)[(size_t)mb * 4 + lane] = (signed char)(type == T_P_8x8 ? sub_t_mb : 0);
+        if (lane < 27) (a.nnz + 27 * cb)[(size_t)mb * 27 + lane] = IS_SKIP_T(type) ? (u8)0 : s.nnz[lane];
+        if (lane < 4) (a.sub_partition + 4 * cb)[(size_t)mb * 4 + lane] = (signed char)(type == T_P_8x8 ? sub_t_mb : BS && type == T_B_8x8 ? (int)sb.sub[lane] : 0);
+        if constexpr (BS) {     // list 1 of x264_macroblock_cache_save, h->mb.skipbp, and what the next macroblock sees to its left
+            if (lane < 16) {
+                const i16 vx = (i16)(intra ? 0 : sb.mv4_1[lane][0]), vy = (i16)(intra ? 0 : sb.mv4_1[lane][1]);
+                (rd.mv1 + 32 * cb)[((size_t)mb * 16 + lane) * 2] = vx; (rd.mv1 + 32 * cb)[((size_t)mb * 16 + lane) * 2 + 1] = vy;
+                if ((lane & 3) == 3) { sb.left_mv4_1[lane >> 2][0] = vx; sb.left_mv4_1[lane >> 2][1] = vy; }
+            }
+            if (lane < 4) {
+                const signed char rv1 = (signed char)(intra ? -1 : sb.ref8_1[lane]);
+                (rd.ref1 + 4 * cb)[(size_t)mb * 4 + lane] = rv1;
+                if (lane & 1) sb.left_r8_1[lane >> 1] = rv1;
+            }
+            if (lane == 0) {
+                const int sbp = type == T_B_SKIP || type == T_B_DIRECT ? 0xf
+                              : type == T_B_8x8 ? (sb.sub[0] == 12) | (sb.sub[1] == 12) << 1 | (sb.sub[2] == 12) << 2 | (sb.sub[3] == 12) << 3 : 0;
+                (rd.skipbp + cb)[mb] = (u8)sbp; sb.left_skipbp = (u8)sbp;
+            }
+        }
         if (lane == 0) {
             const int cbp_dc = a.cabac ? (s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2) : 0;
             a.mb_type[mb] = (signed char)type;
-            (a.partition + cb)[mb] = (signed char)(intra || type == T_P_SKIP ? 16 : part);
+            (a.partition + cb)[mb] = (signed char)(intra || IS_SKIP_T(type) || (BS && type == T_B_DIRECT) ? 16 : part);
             (a.i16mode + cb)[mb] = (signed char)(type == T_I_16x16 ? pred16 : 0);
             (a.chroma_mode + cb)[mb] = (signed char)(intra ? predc : 0);
             (a.qp_out + cb)[mb] = (signed char)mb_qp;
             (a.t8 + cb)[mb] = (signed char)t8;
-            (a.cbp + cb)[mb] = (i16)(type == T_P_SKIP ? 0 : type == T_I_PCM ? 0x72f : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
+            (a.cbp + cb)[mb] = (i16)(IS_SKIP_T(type) ? 0 : type == T_I_PCM ? 0x72f : (cbp_dc << 8) | (cbp_chroma << 4) | cbp_luma);
             (a.cost_intra + cb)[mb] = stat_intra; (a.cost_inter + cb)[mb] = stat_inter; (a.cost_alt + cb)[mb] = stat_alt;
         }
         {   // coefficient levels, masked by what the entropy coder reads (cbp, then nnz)
-            const bool coded = type != T_P_SKIP && type != T_I_PCM;
+            const bool coded = !IS_SKIP_T(type) && type != T_I_PCM;
             i16 *ly = (a.luma + 256 * cb) + (size_t)mb * 256, *cac = (a.chroma_ac + 128 * cb) + (size_t)mb * 128;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -2447,17 +2508,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         }
         if constexpr (RD) {     // what the next macroblock's entropy coding reads of this one (kept in LDS / registers), and mvd for the row below
             const int cbp_dc = s.nnz[24] | s.nnz[25] << 1 | s.nnz[26] << 2;
-            cbp_store = type == T_P_SKIP ? 0 : type == T_I_PCM ? 0x72f : (UNI(cbp_dc) << 8) | (cbp_chroma << 4) | cbp_luma;
-            const bool keep = !intra && type != T_P_SKIP;
+            cbp_store = IS_SKIP_T(type) ? 0 : type == T_I_PCM ? 0x72f : (UNI(cbp_dc) << 8) | (cbp_chroma << 4) | cbp_luma;
+            const bool keep = !intra && !IS_SKIP_T(type) && !(BS && type == T_B_DIRECT);
             if (lane < 16) {
                 const int k = 12 + (lane & 3) + 8 * (lane >> 2);
                 i16 *mvd = rd.mvd + ((cb + mb) * 16 + lane) * 2;
                 mvd[0] = keep ? sr.cmvd[k][0] : (i16)0; mvd[1] = keep ? sr.cmvd[k][1] : (i16)0;
                 if ((lane & 3) == 3) { sr.left_mvd[lane >> 2][0] = mvd[0]; sr.left_mvd[lane >> 2][1] = mvd[1]; }
+                if constexpr (BS) {
+                    i16 *mvd1 = rd.mvd1 + ((cb + mb) * 16 + lane) * 2;
+                    mvd1[0] = keep ? sb.cmvd1[k][0] : (i16)0; mvd1[1] = keep ? sb.cmvd1[k][1] : (i16)0;
+                    if ((lane & 3) == 3) { sb.left_mvd1[lane >> 2][0] = mvd1[0]; sb.left_mvd1[lane >> 2][1] = mvd1[1]; }
+                }
             } else if (lane < 24) {
                 const int j = lane - 16;
                 const int idx = j < 4 ? (j == 0 ? 5 : j == 1 ? 7 : j == 2 ? 13 : 15) : 16 + 4 * ((j - 4) >> 1) + 1 + 2 * (j & 1);
-                sr.left_nz[j] = type == T_P_SKIP ? (u8)0 : s.nnz[idx];
+                sr.left_nz[j] = IS_SKIP_T(type) ? (u8)0 : s.nnz[idx];
             }
             left_cbp = cbp_store; left_cpm = intra && type != T_I_PCM ? sw_fix8c(predc) : 0; left_t8 = t8;
             prev_coded = type == T_I_16x16 || (cbp_store & 0x3f);
@@ -2465,7 +2531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             WAVE_SYNC();
         }
         left_type = type;
-        left_ref = is_p ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);
+        left_ref = is_p || BS ? (intra ? -1 : UNI(s.ref8[1])) : -1; left_mvx = intra ? 0 : UNI(s.mv4[3][0]); left_mvy = intra ? 0 : UNI(s.mv4[3][1]);
         PROF(4);
         LAUNDER();
         if constexpr (!RD) {

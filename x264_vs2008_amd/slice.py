@@ -12,7 +12,7 @@ import numpy as np
 
 from .frame import CqmDevice, DeblockParams, DeviceArray, FrameCtx, cost_mv_table
 
-SLICE_P, SLICE_I = 0, 2
+SLICE_P, SLICE_B, SLICE_I = 0, 1, 2
 I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = range(7)
 LAMBDA_TAB = (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
               6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91)   # R/encoder/analyse.c:140-149
@@ -27,7 +27,13 @@ STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("sub_part
 
 class MbState(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in STATE_FIELDS] + \
-               [("progress", C.c_void_p), ("poc", C.c_int), ("n_ref0", C.c_int), ("inv_ref_poc", C.c_int * 8), ("mvd", C.c_void_p)]
+               [("progress", C.c_void_p), ("poc", C.c_int), ("n_ref0", C.c_int), ("inv_ref_poc", C.c_int * 8), ("mvd", C.c_void_p),
+                ("mv1", C.c_void_p), ("ref1", C.c_void_p), ("mvr1", C.c_void_p), ("mvd1", C.c_void_p), ("skipbp", C.c_void_p)]
+
+
+class SliceB(C.Structure):
+    """x264hip_slice_b: list 1 of a B slice and what direct prediction reads."""
+    _fields_ = [("fref1", C.c_void_p), ("l1_state", C.c_void_p), ("ref1_poc", C.c_int), ("weightb", C.c_int), ("direct_spatial", C.c_int)]
 
 
 class SliceRd(C.Structure):
@@ -50,12 +56,35 @@ class SliceParams(C.Structure):
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
                 ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
                 ("mixed_refs", C.c_int), ("profile", C.c_void_p), ("noise_reduction", C.c_int), ("nr", C.c_void_p), ("lossless", C.c_int),
-                ("rd", C.c_void_p)]
+                ("rd", C.c_void_p), ("b", C.c_void_p)]
 
 
 class NrState(C.Structure):
     """x264hip_nr_state: h->nr_residual_sum / nr_count / nr_offset of every chain (device)."""
     _fields_ = [("sum", C.c_void_p), ("count", C.c_void_p), ("offset", C.c_void_p)]
+
+
+def bframe_qp(qp, pb_factor=1.3):
+    """rc->qp_constant[SLICE_TYPE_B] (R/encoder/ratecontrol.c:369-372)."""
+    return min(max(int(qp + 6.0 * math.log(float(np.float32(pb_factor))) / math.log(2.0) + 0.5), 0), 51)
+
+
+def coding_order(n_frames, keyint, bframes):
+    """[(display index, slice type)] in coding order for a fixed pattern of `bframes` disposable B frames (x264_slicetype_decide
+    without b-adapt, then x264_encoder_encode's reordering): an anchor every bframes + 1 frames after an IDR, the last frame before
+    the next IDR / the end of the clip is an anchor too, every anchor is coded before the B frames it closes."""
+    out, t = [], 0
+    while t < n_frames:
+        if (t % keyint == 0) if keyint > 0 else t == 0:
+            out.append((t, SLICE_I))
+            t += 1
+            continue
+        lim = min((t // keyint + 1) * keyint if keyint > 0 else n_frames, n_frames)
+        anchor = min(t + bframes, lim - 1)
+        out.append((anchor, SLICE_P))
+        out += [(b, SLICE_B) for b in range(t, anchor)]
+        t = anchor + 1
+    return out
 
 
 def iframe_qp(qp, ip_factor=1.4):
@@ -90,7 +119,8 @@ class ChainEncoder:
     def __init__(self, lib, width, height, cqm, batch=1, qp=26, me_method=0, me_range=16, subme=0, n_refs=1, inter=0, intra=0,
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
                  chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0, mv_range=0,
-                 trellis=0, psy_rd=0.0, aq_mode=0, aq_strength=1.0, write=0, cabac_init_idc=0, qp_min=0, qp_max=51, payload_cap=0, raster=None):
+                 trellis=0, psy_rd=0.0, aq_mode=0, aq_strength=1.0, write=0, cabac_init_idc=0, qp_min=0, qp_max=51, payload_cap=0, raster=None,
+                 bframes=0, weightb=0, direct_pred=1):
         self.lib = lib
         # x264_validate_parameters (R/encoder/encoder.c:493-522): what the RD-side options do to each other
         trellis = min(max(trellis, 0), 2) if cabac else 0
@@ -143,8 +173,12 @@ class ChainEncoder:
             self.payload_cap = cap
         self.i_frame, self.i_frame_stride = 0, 0      # shard.py sets both when the chains are the GOPs of one stream
         self.fenc = self.ctx.new_picture()
-        self.pool = [self.ctx.new_picture() for _ in range(n_refs + 1)]
-        self.states = [DeviceState(self.ctx) for _ in range(n_refs + 1)]
+        # B frames (disposable, one list-1 picture): encode_frame(src, stype, disp) in coding_order(); the DPB then holds
+        # max(n_refs, 2) pictures (sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200)
+        self.bopt = dict(bframes=bframes, weightb=int(bool(weightb)), direct_spatial=int(direct_pred != 2))
+        self.dpb = max(n_refs, 2 if bframes else 1)
+        self.pool = [self.ctx.new_picture() for _ in range(self.dpb + 1)]
+        self.states = [DeviceState(self.ctx) for _ in range(self.dpb + 1)]
         self.refs = []                 # [(picture, state, poc)], newest first
         self.t = 0
         self.last_idr = 0
@@ -166,21 +200,28 @@ class ChainEncoder:
     def upload(self, y, u, v, b=0):
         self.ctx.upload(self.fenc, y, u, v, b=b)
 
-    def encode_frame(self, src=None):
+    def encode_frame(self, src=None, stype=None, disp=None):
         """The macroblock sweep for the frame held by `src` (default: the picture upload() fills) in every
-        batch element.  Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync()."""
+        batch element.  Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync().
+        Without stype: I / P chains in display order (an IDR every keyint frames).  With stype / disp (see coding_order): the
+        frame's slice type and display index, frames arriving in coding order -- the way B frames are coded."""
         L, c, o = self.lib, self.ctx, self.opt
         fenc = self.fenc if src is None else src
-        idr = (self.t % o["keyint"] == 0) if o["keyint"] > 0 else self.t == 0
+        if stype is None:
+            idr = (self.t % o["keyint"] == 0) if o["keyint"] > 0 else self.t == 0
+            stype, disp = (SLICE_I if idr else SLICE_P), self.t
+        idr, is_b = stype == SLICE_I, stype == SLICE_B
         if idr:
-            self.refs, self.last_idr = [], self.t
+            self.refs, self.last_idr = [], disp
+        poc = 2 * (disp - self.last_idr)
         used = [r[0] for r in self.refs]
         pic_i = next(i for i, p in enumerate(self.pool) if not any(p is q for q in used))
         recon, state = self.pool[pic_i], self.states[pic_i]
-        refs = self.refs[:o["n_refs"]]
-        stype = SLICE_I if idr else SLICE_P
-        qp = iframe_qp(o["qp"]) if idr else o["qp"]
-        poc = 2 * (self.t - self.last_idr)
+        # x264_reference_build_list (R/encoder/encoder.c:911-981): list 0 = earlier pictures, nearest first; list 1 = later ones
+        refs = sorted([r for r in self.refs if r[2] < poc], key=lambda r: -r[2])[:o["n_refs"]]
+        refs1 = sorted([r for r in self.refs if r[2] > poc], key=lambda r: r[2])[:1] if is_b else []
+        qp = iframe_qp(o["qp"]) if idr else bframe_qp(o["qp"]) if is_b else o["qp"]
+        self.last_is_b, self.last_poc = is_b, poc
         b = self.cqm.bufs
         p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
                         subme=o["subme"], chroma_me=o["chroma_me"], mv_range=o["mv_range"] or 512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
@@ -201,6 +242,10 @@ class ChainEncoder:
                               payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
                               i_frame_stride=self.i_frame_stride)
             p.rd = C.addressof(self.rd)
+        if is_b:
+            self.sb = SliceB(fref1=C.addressof(refs1[0][0]), l1_state=C.addressof(refs1[0][1].st), ref1_poc=refs1[0][2],
+                             weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"])
+            p.b = C.addressof(self.sb)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]
         arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(r[0]) for r in refs]) if refs else None
@@ -223,6 +268,10 @@ class ChainEncoder:
         """x264_fdec_filter_row for the whole frame: loop filter, borders, half-pel planes; then the frame joins the reference list."""
         L, c, o = self.lib, self.ctx, self.opt
         recon, state = self.last
+        if getattr(self, "last_is_b", False):          # a disposable B frame: neither filtered nor kept (R/encoder/encoder.c:986-1024,1060-1068)
+            self.t += 1
+            self.i_frame += 1
+            return
         if o["deblock"]:
             s = state.st
             dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
@@ -231,8 +280,8 @@ class ChainEncoder:
             c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
         c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
         c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
-        self.refs.insert(0, (recon, state, 2 * (self.t - self.last_idr)))
-        del self.refs[o["n_refs"]:]
+        self.refs.insert(0, (recon, state, getattr(self, "last_poc", 2 * (self.t - self.last_idr))))
+        del self.refs[self.dpb:]
         self.t += 1
         self.i_frame += 1
 

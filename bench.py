@@ -53,7 +53,10 @@ def analysis_options(args):
 
 def rd_options(args):
     """What the raster-order variant adds (x264hip_slice_rd)."""
-    return dict(trellis=args.trellis, psy_rd=args.psy_rd, aq_mode=args.aq_mode, aq_strength=1.0)
+    o = dict(trellis=args.trellis, psy_rd=args.psy_rd, aq_mode=args.aq_mode, aq_strength=1.0)
+    if args.bframes:
+        o.update(bframes=args.bframes, weightb=args.weightb, direct_pred=1)
+    return o
 
 
 def _cpu_chain(job):
@@ -111,6 +114,9 @@ def main():
                     "variant (one wavefront per chain, all resident: what its 20 KB of LDS and 234 VGPRs allow), 240 with --wavefront 1")
     ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
     ap.add_argument("--trellis", type=int, default=1)
+    ap.add_argument("--bframes", type=int, default=-1, help="disposable B frames between anchors, fixed pattern (-1: 3 for the raster variant = the medium "
+                    "preset's --bframes 3 without b-adapt; 0 with --wavefront 1)")
+    ap.add_argument("--weightb", type=int, default=1)
     ap.add_argument("--psy-rd", type=float, default=1.0)
     ap.add_argument("--aq-mode", type=int, default=1)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0: one per host core)")
@@ -138,6 +144,9 @@ def main():
     args.cpu_frames = args.cpu_frames or (40 if wf else 12)
     if wf:
         args.trellis, args.psy_rd, args.aq_mode = 0, 0.0, 0
+    args.bframes = (0 if wf else 3) if args.bframes < 0 else args.bframes
+    if args.bframes:
+        args.inter |= 0x100                          # X264_ANALYSE_BSUB16x16: the medium preset's b8x8
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,8 +183,15 @@ def main():
             ctx.upload(pic, *pool[(i + 3 * b) % pool_n], b=b)
         srcs.append(pic)
 
+    # with B frames the chains are coded in coding order: I P B B B P B B B ... (x264_vs2008_amd/slice.py: coding_order)
+    order = sl.coding_order(args.warmup + args.steps + args.keyint, args.keyint, args.bframes) if args.bframes else None
+
     def one_step(k):
-        enc.encode_frame(srcs[k % n_src])
+        if order:
+            disp, stype = order[k]
+            enc.encode_frame(srcs[disp % n_src], stype=stype, disp=disp)
+        else:
+            enc.encode_frame(srcs[k % n_src])
         enc.finish_frame()
 
     def sync_all():
@@ -208,7 +224,7 @@ def main():
     ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, st, nr in enc.events]
     # algorithmic bytes of each launch (SURVEY 8(d) terms that belong to this kernel): per frame the source (1.5 B/px), each
     # reference's four luma planes + chroma (4.5 B/px) and the reconstruction (1.5 B/px)
-    by_all = [B * px * (1.5 + 4.5 * (nr if st == sl.SLICE_P else 0) + 1.5) for a, b, st, nr in enc.events]
+    by_all = [B * px * (1.5 + 4.5 * (nr if st != sl.SLICE_I else 0) + 1.5) for a, b, st, nr in enc.events]      # nr: list 0 + list 1
     for a, b, _, _ in enc.events:
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
     sweep_ms = float(np.mean(ms_all))
@@ -245,15 +261,17 @@ def main():
                        "CRF rate control", "lookahead / scenecut", "entropy coding"]
             par = "B closed-GOP chains per GPU in every launch (one wavefront per macroblock row per chain); chains shard across GPUs with no data-path collective"
         else:
-            metric = ("encoded frames/sec, 1080p, I/P slices with preset=medium's analysis (subme 7 RD, trellis 1, psy-rd, aq-mode 1, CABAC payload on the GPU) "
-                      "at constant QP; B slices, CRF and lookahead not built yet; 1/2/4/8 MI355X (bit-exact)")
+            metric = ("encoded frames/sec, 1080p, %s slices with preset=medium's analysis (subme 7 RD, trellis 1, psy-rd, aq-mode 1, CABAC payload on the GPU) "
+                      "at constant QP%s; CRF and lookahead not built yet; 1/2/4/8 MI355X (bit-exact)"
+                      % ("I/P/B" if args.bframes else "I/P", ", %d B frames in a fixed pattern, weightb, spatial direct" % args.bframes if args.bframes else "; no B slices"))
             what = ("%dx%d I/P chains through the reference's per-macroblock loop on the GPU, raster order (one wavefront per chain): cache_load, "
                     "x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, x264_macroblock_write_cabac (the slice payload is produced "
                     "by the same launch), cache_save, then deblock, borders, half-pel planes; --ref %d --me %s --subme %d --trellis %d --psy-rd %.1f "
                     "--aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x, chroma ME, fast P-skip, dct-decimate, CABAC, CQP %d, keyint %d"
                     % (args.width, args.height, args.refs, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs,
                        args.inter, args.intra, args.qp, args.keyint))
-            missing = ["B slices (--bframes 3 --b-adapt 1 --weightb --direct spatial): about 3/4 of a medium encode's frames",
+            missing = (["B slices (--bframes 3 --b-adapt 1 --weightb --direct spatial): about 3/4 of a medium encode's frames"] if not args.bframes else
+                       ["adaptive B placement (--b-adapt 1): the B frames are placed in a fixed pattern of %d" % args.bframes]) + [
                        "CRF rate control (--crf 23): constant QP %d + adaptive quantisation here" % args.qp, "lookahead (b-adapt, scenecut, lowres motion candidates)",
                        "slice / NAL headers around the payload"]
             par = ("B closed-GOP chains per GPU in every launch, one wavefront per chain walking its frame in raster order (the RD levels, trellis and AQ "

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 from oracle import refslice as rs
-from oracle.gen_golden_slice import MED, masked2
+from oracle.gen_golden_slice import MED, MEDB, masked2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -27,16 +27,22 @@ HASH_CASES = [
     ("hd_medium_rd", (1920, 1080), 3, dict(qp=26, subme=7, **MED), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0)),
     ("uhd_umh_subme5", (3840, 2160), 2, dict(qp=28, subme=5, me_method=rs.ME_UMH, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1), None),
     ("uhd_umh_medium_rd", (3840, 2160), 2, dict(qp=26, subme=7, **dict(MED, me_method=rs.ME_UMH, n_refs=2)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0)),
+    # the medium preset's analysis options with its GOP shape: I P B B B P in coding order (3 disposable B frames, weightb, spatial direct)
+    ("hd_medium_b", (1920, 1080), 6, dict(qp=26, subme=7, **dict(MEDB, n_refs=3)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0, bframes=3, weightb=1, direct_pred=1)),
 ]
+
+
+def arrays_for(ekw):
+    return ARRAYS + (["mv1", "ref1"] if ekw and ekw.get("bframes") else [])
 
 
 def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def hashes(arrs, frames):
+def hashes(arrs, frames, names=ARRAYS):
     """{array: [sha256 per frame]} (+ the payload bytes and the frame info when the writer ran)."""
-    out = {k: [digest(arrs[k][f]) for f in range(frames)] for k in ARRAYS}
+    out = {k: [digest(arrs[k][f]) for f in range(frames)] for k in names}
     out["frame_info"] = arrs["frame_info"].tolist()
     out["stat"] = arrs["stat"].tolist()
     if "payload_len" in arrs:
@@ -61,7 +67,9 @@ def main():
         if only and name not in only:
             continue
         a = run_case(rs.run_reference, rs.run_reference2, size, frames, kw, ekw)
-        h = hashes(a, frames)
+        h = hashes(a, frames, arrays_for(ekw))
+        if ekw and ekw.get("bframes"):
+            h["frame_info2"] = a["frame_info2"].tolist()
         h["mb_type_counts"] = [np.bincount(a["mb_type"][f], minlength=7).tolist() for f in range(frames)]
         path = os.path.join(GOLDEN, "hash_%s.json" % name)
         with open(path, "w") as f:

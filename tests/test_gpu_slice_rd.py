@@ -2,6 +2,7 @@
 psy-rd, adaptive quantisation and the CABAC entropy coder inside the macroblock loop -- against chains the REFERENCE's own loop
 produced with x264_macroblock_write_cabac in it (oracle/ref_slice.c refslice_encode_chain2, fixtures tests/golden/slice2_*.npz):
 every decision, level and pixel as in test_gpu_slice.py, the per-macroblock QP, AND the slice payload bytes."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -20,14 +21,25 @@ def run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw, batch=1):
     kw.pop("cqm_preset", 0)
     enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=batch, write=1, **kw, **{k: v_ for k, v_ in ekw.items() if k != "write"})
     out = []
+    # B frames: the chain in coding order (the golden fixtures of such chains are in coding order too)
+    order = sl.coding_order(frames, kw.get("keyint", 0), ekw["bframes"]) if ekw.get("bframes") else None
     try:
         for f in range(frames):
+            disp = order[f][0] if order else f
             for b in range(batch):
-                enc.upload(y[f], u[f], v[f], b=b)
-            stype, qp, state = enc.encode_frame()
+                enc.upload(y[disp], u[disp], v[disp], b=b)
+            stype, qp, state = enc.encode_frame(stype=order[f][1], disp=disp) if order else enc.encode_frame()
             enc.status()
             recon = enc.last[0]
             d = {k: state.get(k) for k in STATE + ["mvr", "cost_intra", "cost_inter"]}
+            if order:
+                n_mb = state.get("mb_type").shape[1]
+                for nm, tail, dt in (("mv1", (16, 2), np.int16), ("ref1", (4,), np.int8)):
+                    a = np.zeros((batch, n_mb) + tail, dt)
+                    assert enc.ctx.lib.x264hip_memcpy_d2h(a.ctypes.data_as(C.c_void_p), C.c_void_p(getattr(state.st, nm)), C.c_size_t(a.nbytes)) == 0
+                    if stype != sl.SLICE_B:               # the reference reports zeros / -1 outside B slices
+                        a[...] = 0 if nm == "mv1" else -1
+                    d[nm] = a
             d["info"] = (stype, qp)
             d["payload"] = enc.payloads()
             d["mb_bits"] = enc.rd_bufs["mb_bits"].get()

@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import refslice as rs
-from oracle.gen_golden_hash import ARRAYS, HASH_CASES, digest, hashes, run_case
+from oracle.gen_golden_hash import ARRAYS, HASH_CASES, arrays_for, digest, hashes, run_case
 from x264_vs2008_amd import slice as sl
 
 
@@ -29,8 +29,8 @@ def test_twin_matches_reference_hashes(oracle_lib, name, size, frames, kw, ekw):
     want = load(name)
     got = run_case(lambda p, y, u, v: rs.run(oracle_lib, "x264o_encode_chain", p, y, u, v),
                    lambda p, e, y, u, v: rs.run2(oracle_lib, "x264o_encode_chain2", p, e, y, u, v), size, frames, kw, ekw)
-    h = hashes(got, frames)
-    for k in ARRAYS + (["payload", "payload_len"] if ekw is not None else []):
+    h = hashes(got, frames, arrays_for(ekw))
+    for k in arrays_for(ekw) + (["payload", "payload_len"] if ekw is not None else []):
         assert h[k] == want[k], "%s: frames %s differ" % (k, [f for f in range(frames) if h[k][f] != want[k][f]])
     assert h["stat"] == want["stat"] and h["frame_info"] == want["frame_info"]
 
@@ -45,11 +45,11 @@ def test_gpu_matches_reference_hashes(hip_lib, cqm, name, size, frames, kw, ekw)
     out = run_chain(hip_lib, cqm, size, frames, y, u, v, kw) if ekw is None else run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw)
     n_mb = ((size[0] + 15) // 16) * ((size[1] + 15) // 16)
     shapes = {"sub_partition": (n_mb, 4), "mv": (n_mb, 16, 2), "ref": (n_mb, 4), "nnz": (n_mb, 27), "i4mode": (n_mb, 16), "luma": (n_mb, 256),
-              "luma_dc": (n_mb, 16), "chroma_dc": (n_mb, 8), "chroma_ac": (n_mb, 128)}
+              "luma_dc": (n_mb, 16), "chroma_dc": (n_mb, 8), "chroma_ac": (n_mb, 128), "mv1": (n_mb, 16, 2), "ref1": (n_mb, 4)}
     for f in range(frames):
-        for k in ARRAYS:
+        for k in arrays_for(ekw):
             a = out[f][k][0]
-            if k in STATE:
+            if k in STATE or k in ("mv1", "ref1"):
                 a = a.reshape(shapes.get(k, (n_mb,)))
             assert digest(a) == want[k][f], "frame %d: %s" % (f, k)
         assert list(out[f]["info"]) == want["frame_info"][f][:2]

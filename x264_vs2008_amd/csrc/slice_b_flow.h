@@ -235,6 +235,7 @@
     };
 
     // ---- x264_me_refine_bidir_satd (R/encoder/me.c:790-928) on one bi-predicted block ----
+    u8 *visited = (u8 *)s.t8;                             // x264_me_refine_bidir's visited[8][8][8]: the 8x8 transform's scratch is idle while analysing
     auto refine_bidir_satd = [&](int slot, int bx, int by, int w, int h) {
         const int r0 = l_ref0;
         int bm0x = ME(0, slot, 0), bm0y = ME(0, slot, 1), bm1x = ME(1, slot, 0), bm1y = ME(1, slot, 1);
@@ -242,7 +243,7 @@
         // all four cost tables are centred on predictors clipped to the HORIZONTAL range, as the reference has it
         const int c0x = clip3(ME(0, slot, 4), L.smin0, L.smax0), c0y = clip3(ME(0, slot, 5), L.smin0, L.smax0);
         const int c1x = clip3(ME(1, slot, 4), L.smin0, L.smax0), c1y = clip3(ME(1, slot, 5), L.smin0, L.smax0);
-        for (int k = lane; k < 512; k += 64) sb.visited[k] = 0;
+        for (int k = lane; k < 512; k += 64) visited[k] = 0;
         WAVE_SYNC();
         int om0x = bm0x, om0y = bm0y, om1x = bm1x, om1y = bm1y, bcost = MX_COST_MAX;
 #pragma nounroll
@@ -253,9 +254,9 @@
                 const u32 d = pass < 0 ? 0x5555u : c_bidir_dirs[k];        // four 2-bit fields, value - 1 = the offset
                 const int x0 = om0x + (int)(d & 3) - 1, y0 = om0y + (int)((d >> 2) & 3) - 1, x1 = om1x + (int)((d >> 4) & 3) - 1, y1 = om1y + (int)((d >> 6) & 3) - 1;
                 const int vi = ((x0 & 7) * 8 + (y0 & 7)) * 8 + (x1 & 7), vb = 1 << (y1 & 7);
-                const int seen = UNI(sb.visited[vi]);
+                const int seen = UNI(visited[vi]);
                 if (pass > 0 && (seen & vb)) continue;
-                if (lane == 0) sb.visited[vi] = (u8)(seen | vb);
+                if (lane == 0) visited[vi] = (u8)(seen | vb);
                 bi_to_tmp(bx, by, w, h, r0, x0, y0, x1, y1);
                 const int cost = satd_region(tmp, 16, bx, by, w, h) + UNI(cost_g[x0 - c0x]) + UNI(cost_g[y0 - c0y]) + UNI(cost_g[x1 - c1x]) + UNI(cost_g[y1 - c1y]);
                 if (cost < bcost) { bcost = cost; bm0x = x0; bm0y = y0; bm1x = x1; bm1y = y1; }

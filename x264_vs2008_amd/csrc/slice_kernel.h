@@ -170,7 +170,6 @@ struct SwLdsB {
     u8 left_skipbp;
     int me[2][9][6];                    // x264_me_t records of a->l0 / a->l1: [list][me16x16, me8x8 x 4, me16x8 x 2, me8x16 x 2][mv x, y, cost, cost_mv, mvp x, y]
     int cost8direct[4];
-    u8 visited[512];                    // x264_me_refine_bidir's visited[8][8][8]
 };
 struct SwLdsRdB;
 // x264_me_refine_bidir's 32 candidate offsets per pass in evaluation order (CHECK_BIDIR8 / CHECK_BIDIR2, R/encoder/me.c:893-909):

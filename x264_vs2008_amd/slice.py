@@ -258,7 +258,7 @@ class ChainEncoder:
                 "slice_sweep_frame")
         if ev:
             L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
-            self.events.append((ev[0], ev[1], stype, len(refs)))
+            self.events.append((ev[0], ev[1], stype, len(refs) + len(refs1)))
         if self.nr:                            # x264_noise_reduction_update at the end of every frame (R/encoder/encoder.c:1755)
             c.check(L.x264hip_noise_reduction_update(c.h, C.byref(self.nr), o["noise_reduction"]), "noise_reduction_update")
         self.last = (recon, state)

@@ -174,14 +174,28 @@ def main():
 
     # resident working set: a ring of source pictures, each holding one frame of every chain.  Chains and
     # steps see different frames of the synthetic clip (rank-dependent offset).
-    n_src, pool_n = (8, 16) if wf else (3, 8)
+    # The raster variant: eight sources in rotation, so that no frame meets its own picture among its references
+    # (with fewer sources than the DPB reaches back, a frame's reference holds the identical content and the search is trivial).
+    n_src, pool_n = (8, 16) if wf else (min(max(args.keyint, 4), 8), 16)     # (8 x 7 GB of sources at 2048 chains: what fits beside the DPBs and states)
+    pool_n = max(pool_n, n_src + 1)
     pool = [synth.frame(args.width, args.height, rank * 97 + i) for i in range(pool_n)]
     srcs = []
-    for i in range(n_src):
-        pic = ctx.new_picture()
-        for b in range(B):
-            ctx.upload(pic, *pool[(i + 3 * b) % pool_n], b=b)
-        srcs.append(pic)
+    if wf or B < pool_n:
+        for i in range(n_src):
+            pic = ctx.new_picture()
+            for b in range(B):
+                ctx.upload(pic, *pool[(i + 3 * b) % pool_n], b=b)
+            srcs.append(pic)
+    else:       # the pool goes up once (into the first elements of a staging picture); the sources are filled on the device
+        stage = ctx.new_picture(source_only=True)
+        for k in range(pool_n):
+            ctx.upload(stage, *pool[k], b=k)
+        for i in range(n_src):
+            pic = ctx.new_picture(source_only=True)
+            for b in range(B):
+                ctx.copy_element(pic, b, stage, (i + 3 * b) % pool_n)
+            srcs.append(pic)
+        ctx.sync()
 
     # with B frames the chains are coded in coding order: I P B B B P B B B ... (x264_vs2008_amd/slice.py: coding_order)
     order = sl.coding_order(args.warmup + args.steps + args.keyint, args.keyint, args.bframes) if args.bframes else None

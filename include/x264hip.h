@@ -107,6 +107,9 @@ x264hip_frame_ctx *x264hip_frame_ctx_new(x264hip_frame_dims *dims, void *hip_str
 void  x264hip_frame_ctx_delete(x264hip_frame_ctx *c);
 void *x264hip_frame_ctx_stream(x264hip_frame_ctx *c);
 int   x264hip_picture_alloc(x264hip_frame_ctx *c, x264hip_picture *pic);
+/* a source frame: Y, U, V only (no half-pel / lowres planes); copy_element: one batch element's planes from picture to picture */
+int   x264hip_picture_alloc_source(x264hip_frame_ctx *c, x264hip_picture *pic);
+int   x264hip_picture_copy_element(x264hip_frame_ctx *c, x264hip_picture *dst, int dst_b, const x264hip_picture *src, int src_b);
 void  x264hip_picture_free(x264hip_frame_ctx *c, x264hip_picture *pic);
 int   x264hip_sync(x264hip_frame_ctx *c);
 /* Batching: a context created with dims.batch = B holds B independent frames per picture (one per

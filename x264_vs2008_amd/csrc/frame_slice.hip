@@ -125,7 +125,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (is_b) {
         if (!pb || !pb->fref1 || !pb->l1_state || !p->rd) { set_error("slice_sweep: a B slice needs x264hip_slice_params.b (list 1) and .rd (the raster variant)"); return -1; }
         if (!pb->direct_spatial) { set_error("slice_sweep: temporal direct prediction is not built in the kernel yet (spatial is)"); return -1; }
-        if (p->subme != 7 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 7 (mode-decision RD) with the CABAC writer in the loop"); return -1; }
+        if (p->subme < 2 || p->subme > 7 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 2..7 with the CABAC writer in the loop"); return -1; }
         if (p->noise_reduction || p->lossless) { set_error("slice_sweep: B slices with --nr / lossless are not built"); return -1; }
         if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
     }

@@ -320,8 +320,10 @@
             if (lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); sb.dref[0][lane] = sr.cref[k]; sb.dref[1][lane] = sb.cref1[k]; }
             finals_from_cache();
             mc_b();
-            bskip_cost = ssd_mb();
-            if (bskip_cost <= ((6 * Q.lambda2 + 128) >> 8)) { skip_mc = 1; fin = true; }      // "6 = minimum cavlc cost of a non-skipped MB"
+            bool b_skip;
+            if (mbrd) { bskip_cost = ssd_mb(); b_skip = bskip_cost <= ((6 * Q.lambda2 + 128) >> 8); }      // "6 = minimum cavlc cost of a non-skipped MB"
+            else b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;   // x264_macroblock_probe_bskip
+            if (b_skip) { skip_mc = 1; fin = true; }
             else {
                 skip_mc = 0;
                 // ---- x264_mb_analyse_inter_direct: the direct prediction is in fdec ----
@@ -387,7 +389,7 @@
                 if (ME(1, 0, 2) < i_cost_b) { i_cost_b = ME(1, 0, 2); i_type_b = T_B_L1_L1; }
                 if (cost16bi < i_cost_b) { i_cost_b = cost16bi; i_type_b = T_B_BI_BI; }
                 if (cost16direct < i_cost_b) { i_cost_b = cost16direct; i_type_b = T_B_DIRECT; }
-                if (cost16direct <= i_cost_b * 33 / 32) { pass = 0; bthresh = i_cost_b * (17 + (rd.psy_rd != 0)) / 16; kcand = 0; bstep = BS_CAND; }
+                if (mbrd && cost16direct <= i_cost_b * 33 / 32) { pass = 0; bthresh = i_cost_b * (17 + (rd.psy_rd != 0)) / 16; kcand = 0; bstep = BS_CAND; }
                 else bstep = BS_AN2;
                 continue;
             }
@@ -489,21 +491,54 @@
             }
             PROF(2);
             LAUNDER();
+            if (!mbrd) {
+                // ---- x264_me_refine_qpel on the winning partition (analyse.c:2586-2655): one loop over (block, list) so that the refinement
+                // exists once; a block's sub-partition type cost leaves its cost while it is refined ----
+#pragma nounroll
+                for (int j = 0; j < 8; j++) {
+                    const int l = j & 1, i = j >> 1;
+                    int slot, w, h, bx, by, ptype, tc = 0;
+                    if (i_part_b == 16) {
+                        if (i) continue;
+                        slot = 0; w = 16; h = 16; bx = 0; by = 0; tc = Q.lambda * 3;
+                        ptype = i_type_b == T_B_L0_L0 ? 3 : i_type_b == T_B_L1_L1 ? 7 : i_type_b == T_B_BI_BI ? 11 : 12;
+                    } else if (i_part_b == 14) { if (i > 1) continue; slot = 5 + i; w = 16; h = 8; bx = 0; by = 8 * i; ptype = i ? part16x8_1 : part16x8_0; }
+                    else if (i_part_b == 15) { if (i > 1) continue; slot = 7 + i; w = 8; h = 16; bx = 8 * i; by = 0; ptype = i ? part8x16_1 : part8x16_0; }
+                    else { slot = 1 + i; w = 8; h = 8; bx = 8 * (i & 1); by = 8 * (i >> 1); ptype = SUB(i); tc = Q.lambda * 3; }
+                    if (!sub_uses(ptype, l)) continue;
+                    int vx = ME(l, slot, 0), vy = ME(l, slot, 1);
+                    const int old = ME(l, slot, 2);
+                    aim_b(l, LREF(l), w, h, bx, by);
+                    c.mvpx = ME(l, slot, 4); c.mvpy = ME(l, slot, 5);
+                    LAUNDER(); c.lane = lane;
+                    const int nc = me_refine_qpel16(c, L, mo_b, old - tc, vx, vy);
+                    WAVE_SYNC();
+                    if (lane < 3) sb.me[l][slot][lane] = lane == 0 ? vx : lane == 1 ? vy : nc;
+                    WAVE_SYNC();
+                    if (i_part_b == 16 && ptype != 11) i_cost_b = nc + tc;
+                    if (i_part_b == 13 && ptype != 11) cost8bi += nc + tc - old;
+                }
+                bstep = BS_SELECT;
+                continue;
+            }
             i_satd_inter_b = i_cost_b;
             pass = 1; bthresh = i_satd_inter_b * (17 + (rd.psy_rd != 0)) / 16; kcand = 0; bstep = BS_CAND;
             continue;
         } else if (bstep == BS_SELECT) {
-            i_type_b = T_B_SKIP; i_cost_b = bskip_cost; i_part_b = 16;
-            if (rd_l0 < i_cost_b) { i_cost_b = rd_l0; i_type_b = T_B_L0_L0; }
-            if (rd_l1 < i_cost_b) { i_cost_b = rd_l1; i_type_b = T_B_L1_L1; }
-            if (rd_bi < i_cost_b) { i_cost_b = rd_bi; i_type_b = T_B_BI_BI; }
-            if (rd_direct < i_cost_b) { i_cost_b = rd_direct; i_type_b = T_B_DIRECT; }
-            if (rd_168 < i_cost_b) { i_cost_b = rd_168; i_type_b = type16x8; i_part_b = 14; }
-            if (rd_816 < i_cost_b) { i_cost_b = rd_816; i_type_b = type8x16; i_part_b = 15; }
-            if (rd_8 < i_cost_b) { i_cost_b = rd_8; i_type_b = T_B_8x8; i_part_b = 13; }
-            type = i_type_b; part = i_part_b;
-            analyse_intra(i_satd_inter_b);
+            if (mbrd) {
+                i_type_b = T_B_SKIP; i_cost_b = bskip_cost; i_part_b = 16;
+                if (rd_l0 < i_cost_b) { i_cost_b = rd_l0; i_type_b = T_B_L0_L0; }
+                if (rd_l1 < i_cost_b) { i_cost_b = rd_l1; i_type_b = T_B_L1_L1; }
+                if (rd_bi < i_cost_b) { i_cost_b = rd_bi; i_type_b = T_B_BI_BI; }
+                if (rd_direct < i_cost_b) { i_cost_b = rd_direct; i_type_b = T_B_DIRECT; }
+                if (rd_168 < i_cost_b) { i_cost_b = rd_168; i_type_b = type16x8; i_part_b = 14; }
+                if (rd_816 < i_cost_b) { i_cost_b = rd_816; i_type_b = type8x16; i_part_b = 15; }
+                if (rd_8 < i_cost_b) { i_cost_b = rd_8; i_type_b = T_B_8x8; i_part_b = 13; }
+                type = i_type_b; part = i_part_b;
+            }
+            analyse_intra(i_satd_inter_b);                      // without the RD levels the reference passes 0 here (its i_satd_inter is only set for them): only I_16x16 gets a cost
             PROF(6);
+            if (!mbrd) { bstep = BS_FINAL; continue; }
             // x264_mb_analyse_transform_rd: every B type but B_SKIP may use the 8x8 transform (direct_8x8_inference is on)
             if (a.transform8x8 && type != T_B_SKIP) { t8 = !t8; skip_mc = 0; bstep = BS_T8; }
             else { bstep = BS_I16; continue; }
@@ -525,7 +560,7 @@
             type = i_type_b; part = i_part_b;
             skip_mc = 0;
             // x264_refine_bidir (subme >= 5): the bi-predicted blocks of the chosen partition
-            if (!IS_INTRA_T(type)) {
+            if (!IS_INTRA_T(type) && a.subme >= 5) {
                 if (part == 16) { if (type == T_B_BI_BI) refine_bidir_satd(0, 0, 0, 16, 16); }
                 else if (part == 14) { if (part16x8_0 == 11) refine_bidir_satd(5, 0, 0, 16, 8); if (part16x8_1 == 11) refine_bidir_satd(6, 0, 8, 16, 8); }
                 else if (part == 15) { if (part8x16_0 == 11) refine_bidir_satd(7, 0, 0, 8, 16); if (part8x16_1 == 11) refine_bidir_satd(8, 8, 0, 8, 16); }

@@ -726,12 +726,14 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
 }
 // x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883); leaves the P-skip prediction in s.fd
 __device__ __forceinline__ int sw_probe_pskip(SwLds &s, const SwRefs &refs, const SwArgs &a, const SwQp &Q, int pmx, int pmy, int mbx, int mby,
-                                              ptrdiff_t oy, ptrdiff_t oc, size_t by_, size_t bc_, int lane)
+                                              ptrdiff_t oy, ptrdiff_t oc, size_t by_, size_t bc_, int lane, bool b_bidir = false)
 {
-    const int vx = clip3(pmx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
-    const int vy = clip3(pmy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
-    sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
-    WAVE_SYNC();
+    if (!b_bidir) {                 // x264_macroblock_probe_bskip: the (direct) prediction is in fdec already
+        const int vx = clip3(pmx, 4 * (-16 * mbx - 24), 4 * (16 * (a.mb_w - mbx - 1) + 24));
+        const int vy = clip3(pmy, 4 * (-16 * mby - 24), 4 * (16 * (a.mb_h - mby - 1) + 24));
+        sw_mc16(s, refs, a, 0, vx, vy, oy, oc, by_, bc_, lane, true);
+        WAVE_SYNC();
+    }
     int score = 0, dc = 0, ssd = 0;
     if (lane < 24) {
         const bool luma = lane < 16;

@@ -110,11 +110,17 @@ class FrameCtx:
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (what, self.lib.x264hip_last_error().decode()))
 
-    def new_picture(self):
+    def new_picture(self, source_only=False):
         pic = Picture()
-        self.check(self.lib.x264hip_picture_alloc(self.h, C.byref(pic)), "picture_alloc")
+        if source_only:                 # Y, U, V only: an input frame
+            self.check(self.lib.x264hip_picture_alloc_source(self.h, C.byref(pic)), "picture_alloc_source")
+        else:
+            self.check(self.lib.x264hip_picture_alloc(self.h, C.byref(pic)), "picture_alloc")
         self.pictures.append(pic)
         return pic
+
+    def copy_element(self, dst, dst_b, src, src_b):
+        self.check(self.lib.x264hip_picture_copy_element(self.h, C.byref(dst), C.c_int(dst_b), C.byref(src), C.c_int(src_b)), "picture_copy_element")
 
     def select(self, b):
         """Choose the batch element that upload / download / x264hip_ssd_frame address."""

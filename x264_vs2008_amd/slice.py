@@ -172,7 +172,7 @@ class ChainEncoder:
             self.rd_bufs = rb
             self.payload_cap = cap
         self.i_frame, self.i_frame_stride = 0, 0      # shard.py sets both when the chains are the GOPs of one stream
-        self.fenc = self.ctx.new_picture()
+        self._fenc = None              # the picture upload() fills: allocated on first use (a caller with its own source pictures never needs it)
         # B frames (disposable, one list-1 picture): encode_frame(src, stype, disp) in coding_order(); the DPB then holds
         # max(n_refs, 2) pictures (sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200)
         self.bopt = dict(bframes=bframes, weightb=int(bool(weightb)), direct_spatial=int(direct_pred != 2))
@@ -196,6 +196,12 @@ class ChainEncoder:
             tab = cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)
             self.cost[qp] = DeviceArray(self.lib, tab.shape, np.uint16, tab)
         return self.cost[qp]
+
+    @property
+    def fenc(self):
+        if self._fenc is None:
+            self._fenc = self.ctx.new_picture(source_only=True)
+        return self._fenc
 
     def upload(self, y, u, v, b=0):
         self.ctx.upload(self.fenc, y, u, v, b=b)

@@ -250,16 +250,19 @@ def main():
     traffic, traffic_note = None, "no rocprofv3 PMC measurement committed for this configuration"
     tname = "r01_sweep_traffic.json" if wf else "r02_raster_traffic.json"
     tpath = os.path.join(ROOT, "profiles", tname)
-    defaults = (args.width, args.height, args.qp, args.me, args.inter, args.intra, args.dct8, args.mixed_refs) == (1920, 1080, 26, 1, 0x13, 0x3, 1, 1) and \
+    defaults = (args.width, args.height, args.qp, args.me, args.inter & 0x33, args.intra, args.dct8, args.mixed_refs) == (1920, 1080, 26, 1, 0x13, 0x3, 1, 1) and \
                (args.subme, args.keyint) == ((5, 24) if wf else (7, 12)) and (wf or (args.trellis, args.psy_rd, args.aq_mode) == (1, 1.0, 1))
     if defaults and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        hit = [l for l in tj["launches"] if l["slice"] == "P" and l["refs"] == args.refs]
-        if hit and tj["batch"] == B:
+        import collections
+        kinds = collections.Counter(("I" if st == sl.SLICE_I else "B" if st == sl.SLICE_B else "P", nr) for _, _, st, nr in enc.events)
+        (kname, knr), _ = kinds.most_common(1)[0]
+        hit = [l for l in tj["launches"] if l["slice"] == kname and l["refs"] == knr]
+        if hit and tj["batch"] == B and tj.get("bframes", 0) == args.bframes:
             traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
-            traffic_note = ("FETCH_SIZE + WRITE_SIZE of one P launch with %d references (the most frequent launch of the timed region), rocprofv3 --pmc, "
-                            "separate passes, raw request-granular counters (profiles/%s)" % (args.refs, tname))
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE of one %s launch with %d reference pictures (the most frequent launch of the timed region), rocprofv3 --pmc, "
+                            "separate passes, raw request-granular counters (profiles/%s)" % (kname, knr, tname))
 
     if rank == 0:
         fps = world * B * args.steps / dt

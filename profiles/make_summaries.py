@@ -35,7 +35,8 @@ if sys.argv[1] == "trace":
     print("launches", len(ms), "mean timed", sum(timed) / len(timed), "bench", b["roofline"]["avg_launch_ms"], b["value"])
 else:
     fdb, wdb, batch, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
-    names = [a.split(":") for a in sys.argv[6:]]
+    names = [a.split(":") for a in sys.argv[6:] if ":" in a]
+    bframes = next((int(a[8:]) for a in sys.argv[6:] if a.startswith("bframes=")), 0)
 
     def per_dispatch(db, counter):
         c = sqlite3.connect(db)
@@ -55,8 +56,8 @@ else:
         launches.append({"slice": st, "refs": int(nr), "fetch_bytes": fb, "write_bytes": wb,
                          "fetch_bytes_per_macroblock": fb // mbs, "write_bytes_per_macroblock": wb // mbs})
     json.dump({"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (counters only, no trace domains), over "
-               "`python3 bench.py --steps 4 --warmup 0 --no-cpu` (default options: raster variant, subme 7, trellis 1, psy-rd 1.0, AQ, CABAC) on "
-               "MI355X, round 2.  One k_slice_sweep<raster> launch per frame: one I frame, then P frames with 1, 2 and 3 references.  Values are "
+               "`python3 bench.py --steps N --warmup 0 --no-cpu` (default options: raster variant, subme 7, trellis 1, psy-rd 1.0, AQ, CABAC, 3 B frames) on "
+               "MI355X, round 2.  One k_slice_sweep<raster> launch per frame in coding order; refs = list 0 + list 1 pictures of the launch.  Values are "
                "the counters as reported (KB) converted to bytes: they tally the L2's memory-side requests at request granularity; raw values.",
-               "batch": batch, "macroblocks_per_launch": mbs, "launches": launches}, open(out, "w"), indent=1)
+               "batch": batch, "bframes": bframes, "macroblocks_per_launch": mbs, "launches": launches}, open(out, "w"), indent=1)
     print(json.dumps(launches, indent=1))

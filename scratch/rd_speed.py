@@ -37,6 +37,8 @@ for B in [int(x) for x in os.environ.get("BATCHES", "64,256").split(",")]:
         n = enc.rd_bufs["payload_len"].get()
         if enc.profile:
             pr = enc.profile.get()[:, -1, :].astype(np.float64).mean(axis=0) / 100e6 / (ctx.dims.mb_w * ctx.dims.mb_h) * 1e6
+            tot = enc.profile.get()[:, -1, :].astype(np.float64).sum(axis=1) / 100e6      # seconds per chain (accumulated over the rows)
+            print('   chain seconds: min %.3f mean %.3f p90 %.3f max %.3f' % (tot.min(), tot.mean(), np.percentile(tot, 90), tot.max()))
             print('   us/MB: trial-encode %.1f load %.1f inter-ME %.1f final-encode %.1f stores %.1f entropy-write %.1f analysis(rest) %.1f trial-ssd+bits %.1f | total %.1f' % (pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr.sum()))
             enc.profile.set(np.zeros((B, ctx.dims.mb_h, 8), np.int64))
         print("B %d frame %d (%s): sweep %.3f s, filters %.3f s -> %.1f frames/s; payload bytes mean %.0f" % (B, k, "I" if k == 0 else "P", t1 - t0, t2 - t1, B / (t2 - t0), n.mean()), flush=True)

@@ -59,6 +59,14 @@ def rd_options(args):
     return o
 
 
+def gpu_options(args):
+    """How the GPU side schedules the same work (not an encoder option: the CPU leg does not see it)."""
+    o = rd_options(args)
+    if args.bframes and args.lanes:
+        o.update(lanes=args.lanes)
+    return o
+
+
 def _cpu_chain(job):
     """One chain through the reference's loop on one core (own process: the reference keeps process-global tables)."""
     import time as _t
@@ -117,6 +125,8 @@ def main():
     ap.add_argument("--bframes", type=int, default=-1, help="disposable B frames between anchors, fixed pattern (-1: 3 for the raster variant = the medium "
                     "preset's --bframes 3 without b-adapt; 0 with --wavefront 1)")
     ap.add_argument("--weightb", type=int, default=1)
+    ap.add_argument("--payload-cap", type=int, default=1 << 20, help="bytes of payload buffer per chain and frame in flight (the library's default, 800 B per macroblock, is x264's worst case)")
+    ap.add_argument("--lanes", type=int, default=-1, help="streams for the B frames of a mini-GOP, which run beside the next anchor (-1: one per B frame of the pattern; 0: one stream)")
     ap.add_argument("--psy-rd", type=float, default=1.0)
     ap.add_argument("--aq-mode", type=int, default=1)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0: one per host core)")
@@ -145,6 +155,7 @@ def main():
     if wf:
         args.trellis, args.psy_rd, args.aq_mode = 0, 0.0, 0
     args.bframes = (0 if wf else 3) if args.bframes < 0 else args.bframes
+    args.lanes = args.bframes if args.lanes < 0 else args.lanes
     if args.bframes:
         args.inter |= 0x100                          # X264_ANALYSE_BSUB16x16: the medium preset's b8x8
 
@@ -166,7 +177,9 @@ def main():
         raise SystemExit("bench.py: no MI355X visible to libx264hip.so (there is no CPU fallback)")
     hip = L.load(local % ndev)                       # one rank per GPU; wraps only when rehearsing on fewer GPUs
     B = args.batch
-    ropt = {} if wf else dict(write=1, **rd_options(args))
+    # the raster variant's product is the payload: no coefficient-level arrays in the states, and a payload buffer sized for the
+    # content (the sweep stops with an error, never writes past it, if a chain's slice does not fit)
+    ropt = {} if wf else dict(write=1, levels=False, payload_cap=args.payload_cap, **gpu_options(args))
     enc = sl.ChainEncoder(hip, args.width, args.height, load_cqm(), batch=B, **analysis_options(args), **ropt)
     ctx = enc.ctx
     d = ctx.dims
@@ -241,6 +254,8 @@ def main():
     by_all = [B * px * (1.5 + 4.5 * (nr if st != sl.SLICE_I else 0) + 1.5) for a, b, st, nr in enc.events]      # nr: list 0 + list 1
     for a, b, _, _ in enc.events:
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
+    if os.environ.get("BENCH_LAUNCHES"):             # developer aid: every timed sweep launch, "slice type:references:ms"
+        print(" ".join("%s:%d:%.0f" % ("PBI"[st], nr, ms) for ms, (_, _, st, nr) in zip(ms_all, enc.events)), file=sys.stderr)
     sweep_ms = float(np.mean(ms_all))
     sweep_bytes = int(np.mean(by_all))
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9

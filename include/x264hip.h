@@ -64,6 +64,7 @@ void *x264hip_event_create(void);
 void  x264hip_event_destroy(void *ev);
 int   x264hip_event_record(void *ev, void *hip_stream);
 float x264hip_event_elapsed_ms(void *start, void *stop);   /* waits for stop; <0 on error */
+int   x264hip_stream_wait_event(void *hip_stream, void *ev);   /* work enqueued on hip_stream from now on runs after what ev recorded */
 
 /* ---- table level: replaces x264_*_init(cpu, ...) of R/encoder/encoder.c:730-745 */
 int x264_pixel_init_hip(x264hip_pixel_function_t *pixf);            /* R/common/pixel.c:565 */
@@ -329,6 +330,8 @@ void x264hip_nr_state_free(x264hip_frame_ctx *c, x264hip_nr_state *nr);
 int  x264hip_noise_reduction_update(x264hip_frame_ctx *c, const x264hip_nr_state *nr, int noise_reduction);
 
 int  x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st);
+#define X264HIP_STATE_NO_LEVELS 1   /* luma / luma_dc / chroma_dc / chroma_ac stay NULL: for sweeps that write the payload themselves (rd.write) */
+int  x264hip_mb_state_alloc_ex(x264hip_frame_ctx *c, x264hip_mb_state *st, int flags);
 void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st);
 /* refs: list0, most recent first (reconstructed, borders expanded, half-pel planes built);
  * l0 = the state refs[0] was coded with (temporal predictors, fast-intra test) or NULL;
@@ -338,6 +341,8 @@ int  x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc
                                const x264hip_mb_state *l0, x264hip_mb_state *out);
 /* synchronises; -1 if a wavefront gave up waiting for its neighbours (the frame is then invalid) */
 int  x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st);
+int  x264hip_slice_sweep_occupancy(int b_slice);   /* raster variant: chains the runtime keeps resident per CU (I / P kernel, or the B one); <0 on error */
+int  x264hip_slice_sweep_lds_bytes(int raster, int b_slice);   /* dynamic LDS per wavefront of the sweep variant (occupancy planning; host only) */
 
 /* Inter residual pipeline for every macroblock (x264_macroblock_encode's
  * inter branch, R/encoder/macroblock.c:596-768, without trellis/denoise):

@@ -264,7 +264,7 @@ def test_abort_path_is_sticky(hip_lib, cqm, monkeypatch):
         enc.encode_frame()
         with pytest.raises(RuntimeError) as e:
             enc.status()
-        assert "gave up waiting" in str(e.value)
+        assert "gave up" in str(e.value)
         monkeypatch.delenv("X264HIP_SPIN_LIMIT")
         for f in (1, 2):                     # the ring of states wraps: the aborted frame's own flag is cleared
             enc.finish_frame()

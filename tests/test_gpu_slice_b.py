@@ -61,3 +61,49 @@ def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, fra
         enc.close()
     t = gold["mb_type"]
     assert (t == 18).any() and (t == 16).any() and (t == 17).any()
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", B_CASES[:2], ids=[c[0] for c in B_CASES[:2]])
+def test_b_frames_on_lanes_run_beside_the_next_anchor(hip_lib, cqm, name, size, frames, kind, kw, ekw):
+    """lanes = 3: every B frame on a stream of its own, ordered by events only (no host synchronisation until the clip is
+    enqueued).  The frames still resident at the end -- the last anchor and the B frames after it -- match the reference."""
+    with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
+        gold = {k: z[k] for k in z.files}
+    y, u, v = case_inputs(size, frames, kind)
+    kw = dict(kw)
+    kw.pop("cqm_preset", 0)
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, lanes=3, **kw, **{k: v_ for k, v_ in ekw.items() if k != "write"})
+    order = sl.coding_order(frames, kw.get("keyint", 0), ekw["bframes"])
+    srcs = []
+    for d in range(frames):
+        pic = enc.ctx.new_picture(source_only=True)
+        enc.ctx.upload(pic, y[d], u[d], v[d], b=0)
+        srcs.append(pic)
+    held = {}                                  # frame index in coding order -> (recon, state, bufs) of what is still resident at the end
+    try:
+        for f, (disp, stype) in enumerate(order):
+            enc.encode_frame(srcs[disp], stype=stype, disp=disp)
+            held[id(enc.last[1])] = (f, stype, enc.last[0], enc.last[1], enc.last_bufs)
+            enc.finish_frame()
+        enc.sync()
+        enc.status()
+        n = gold["mb_type"].shape[1]
+        checked_b = 0
+        for f, stype, recon, state, bufs in held.values():
+            if stype != sl.SLICE_B and f != max(g for g, t, *_ in held.values() if t != sl.SLICE_B):
+                continue                       # an older anchor's payload buffer has been reused since
+            for k in STATE:
+                if stype == sl.SLICE_I and k in ("mv", "ref"):
+                    continue
+                assert np.array_equal(state.get(k)[0], gold[k][f]), "frame %d: %s" % (f, k)
+            if stype == sl.SLICE_B:
+                assert np.array_equal(get1(enc, state, "mv1", (n, 16, 2), np.int16), gold["mv1"][f])
+                checked_b += 1
+            ln = int(bufs["payload_len"].get()[0])
+            pay = bytes(bufs["payload"].get()[0, sl.PAYLOAD_LEAD:sl.PAYLOAD_LEAD + ln])
+            assert pay == bytes(gold["payload"][f, :gold["payload_len"][f]]), "frame %d: payload" % f
+            for nm in ("y", "u", "v") if stype == sl.SLICE_B else ():       # (the anchor has been through the loop filter since)
+                assert np.array_equal(enc.ctx.download(recon, nm, padded=False, b=0), gold["rec_" + nm][f]), "frame %d rec_%s" % (f, nm)
+        assert checked_b >= 2
+    finally:
+        enc.close()

@@ -84,3 +84,35 @@ def test_raster_sweep_batched_chains(hip_lib, cqm):
         for b in range(3):
             check_frame(out[f], gold, f, kw.get("n_refs", 1), b=b)
             assert out[f]["payload"][b] == bytes(gold["payload"][f, :n])
+
+
+def test_payload_only_states_and_a_full_payload_buffer(hip_lib, cqm):
+    """levels=False (X264HIP_STATE_NO_LEVELS: the states carry no coefficient-level arrays, the payload is the product) gives the
+    same bytes; and a payload buffer the slice does not fit stops the sweep with an error instead of writing past it."""
+    name, size, frames, kind, kw, ekw = next(c for c in CASES2 if c[0] == "rd7_aq")
+    with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
+        gold = {k: z[k] for k in z.files}
+    y, u, v = case_inputs(size, frames, kind)
+    kw = dict(kw)
+    kw.pop("cqm_preset", 0)
+    ekw = {k: v_ for k, v_ in ekw.items() if k != "write"}
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, levels=False, **kw, **ekw)
+    try:
+        assert not enc.states[0].st.luma and not enc.states[0].st.chroma_ac and enc.states[0].st.mv
+        for f in range(frames):
+            enc.upload(y[f], u[f], v[f])
+            enc.encode_frame()
+            enc.status()
+            assert enc.payloads()[0] == bytes(gold["payload"][f, :int(gold["payload_len"][f])]), "frame %d" % f
+            enc.finish_frame()
+    finally:
+        enc.close()
+    # (at QP 6 the first slice of this clip is far beyond the 2 KB such a buffer leaves before the guard's margin)
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, payload_cap=4096 + sl.PAYLOAD_LEAD, **dict(kw, qp=6), **ekw)
+    try:
+        enc.upload(y[0], u[0], v[0])
+        enc.encode_frame()
+        with pytest.raises(RuntimeError, match="aborted"):
+            enc.status()
+    finally:
+        enc.close()

@@ -41,9 +41,12 @@ static const uint8_t k_chroma_qp[52] = {  // i_chroma_qp_table, R/common/macrobl
     29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
 extern "C" void x264hip_mb_state_free(x264hip_frame_ctx *c, x264hip_mb_state *st);
-extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st)
+extern "C" int x264hip_mb_state_alloc_ex(x264hip_frame_ctx *c, x264hip_mb_state *st, int flags);
+extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st) { return x264hip_mb_state_alloc_ex(c, st, 0); }
+extern "C" int x264hip_mb_state_alloc_ex(x264hip_frame_ctx *c, x264hip_mb_state *st, int flags)
 {
     const size_t n = (size_t)c->d.mb_w * c->d.mb_h * c->batch;
+    const bool no_levels = flags & X264HIP_STATE_NO_LEVELS;     // 816 of a macroblock's 1184 bytes: nobody reads them when the sweep writes the payload itself
     memset(st, 0, sizeof(*st));
     struct { void **p; size_t bytes; } items[] = {
         {(void **)&st->mb_type, n}, {(void **)&st->partition, n}, {(void **)&st->sub_partition, 4 * n}, {(void **)&st->ref, 4 * n}, {(void **)&st->i4mode, 16 * n},
@@ -54,6 +57,7 @@ extern "C" int x264hip_mb_state_alloc(x264hip_frame_ctx *c, x264hip_mb_state *st
         {(void **)&st->progress, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1)}, {(void **)&st->mvd, 64 * n},
         {(void **)&st->mv1, 64 * n}, {(void **)&st->ref1, 4 * n}, {(void **)&st->mvr1, 4 * n}, {(void **)&st->mvd1, 64 * n}, {(void **)&st->skipbp, n}};
     for (auto &it : items) {
+        if (no_levels && (it.p == (void **)&st->luma || it.p == (void **)&st->luma_dc || it.p == (void **)&st->chroma_dc || it.p == (void **)&st->chroma_ac)) continue;
         if (hipMalloc(it.p, it.bytes) != hipSuccess || hipMemsetAsync(*it.p, 0, it.bytes, c->stream) != hipSuccess) {
             set_error("mb_state_alloc: %zu bytes", it.bytes);
             x264hip_mb_state_free(c, st);              // what was allocated so far
@@ -144,6 +148,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         if (mbrd && (p->analyse_inter & 0x20)) { set_error("slice_sweep: sub-8x8 partitions with the RD levels (x264_rd_cost_part) not built"); return -1; }
         if (!out->mvd) { set_error("slice_sweep: mb_state without mvd"); return -1; }
     }
+    if (!out->luma && !(prd && prd->write)) { set_error("slice_sweep: an mb_state without level arrays (X264HIP_STATE_NO_LEVELS) needs the entropy coder in the loop (rd.write)"); return -1; }
     if (p->me_method < 0 || p->me_method > 3) { set_error("slice_sweep: me method %d not built (0 DIA, 1 HEX, 2 UMH, 3 ESA)", p->me_method); return -1; }
     if (p->me_method == 3 && p->subme < 1) { set_error("slice_sweep: ESA at subme 0 is undefined in the reference (it never fills the integral plane there, encoder.c:1009 / mc.c:431)"); return -1; }
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
@@ -249,11 +254,12 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
+    const size_t lds_bytes = sw_lds_bytes<false, false>();
     switch (a.lossless ? 0 : wpe) {
-    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t, r); break;
-    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t, r); break;
-    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t, r); break;
-    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t, r); break;
+    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, lds_bytes, c->stream, a, t, r); break;
+    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, lds_bytes, c->stream, a, t, r); break;
+    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, lds_bytes, c->stream, a, t, r); break;
+    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, lds_bytes, c->stream, a, t, r); break;
     }
     }
     if (!prd && is_p && a.flags_intra)
@@ -269,14 +275,31 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     return 0;
 }
 
+// dynamic LDS one wavefront of the sweep is launched with (the kernels' static LDS -- the CABAC tables of the raster variants -- comes
+// on top): what bounds the chains resident per CU (tests/test_build_resources.py)
+extern "C" int x264hip_slice_sweep_lds_bytes(int raster, int b_slice)
+{
+    return (int)(!raster ? sw_lds_bytes<false, false>() : b_slice ? sw_lds_bytes<true, true>() : sw_lds_bytes<true, false>());
+}
+
+// chains (one-wavefront workgroups) of the raster variant the runtime will keep resident per CU -- what a caller sizes its batch by
+int x264hip_occupancy_slice_rd(void);
+int x264hip_occupancy_slice_b(void);
+extern "C" int x264hip_slice_sweep_occupancy(int b_slice)
+{
+    const int n = b_slice ? x264hip_occupancy_slice_b() : x264hip_occupancy_slice_rd();
+    if (n < 0) set_error("slice_sweep_occupancy: no device");
+    return n;
+}
+
 extern "C" int x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st)
 {
     int flag = 0, total = 0;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(&flag, st->progress + (size_t)c->d.mb_h * c->batch, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&total, (char *)c->ssd_dev + 24 * (size_t)c->batch + 32, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag) { set_error("slice_sweep: a wavefront gave up waiting for its neighbours (aborted frame)"); return -1; }
+    if (flag) { set_error("slice_sweep: a wavefront gave up -- waiting for its neighbours, or out of payload space (aborted frame)"); return -1; }
     // sticky: an aborted frame may have been used as a reference since, and its own flag is cleared when its state is reused
-    if (total) { set_error("slice_sweep: %d wavefront(s) of an EARLIER frame of this context gave up waiting (aborted frame): everything coded since is invalid", total); return -1; }
+    if (total) { set_error("slice_sweep: %d wavefront(s) of an EARLIER frame of this context gave up -- waiting, or out of payload space (aborted frame): everything coded since is invalid", total); return -1; }
     return 0;
 }

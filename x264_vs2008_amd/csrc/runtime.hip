@@ -167,6 +167,13 @@ extern "C" int x264hip_event_record(void *e, void *stream)
     HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)stream));
     return 0;
 }
+// everything enqueued on `stream` after this call runs after the work the event recorded (another stream's): how the B frames of a
+// mini-GOP, each on a stream of its own, are ordered behind the anchor they predict from (x264_vs2008_amd/slice.py: lanes)
+extern "C" int x264hip_stream_wait_event(void *stream, void *e)
+{
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e, 0));
+    return 0;
+}
 extern "C" float x264hip_event_elapsed_ms(void *start, void *stop)
 {
     float ms = -1.0f;

@@ -95,9 +95,10 @@ def iframe_qp(qp, ip_factor=1.4):
 class DeviceState:
     """One x264hip_mb_state: allocated by the library, read back as numpy arrays [batch][n][...]."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, levels=True):
         self.ctx, self.st = ctx, MbState()
-        ctx.check(ctx.lib.x264hip_mb_state_alloc(ctx.h, C.byref(self.st)), "mb_state_alloc")
+        # levels=False: X264HIP_STATE_NO_LEVELS -- no coefficient-level arrays (2/3 of a state's bytes), for sweeps that write the payload themselves
+        ctx.check(ctx.lib.x264hip_mb_state_alloc_ex(ctx.h, C.byref(self.st), C.c_int(0 if levels else 1)), "mb_state_alloc")
 
     def get(self, name):
         d, B = self.ctx.dims, self.ctx.batch
@@ -120,7 +121,7 @@ class ChainEncoder:
                  transform8x8=0, fast_pskip=1, dct_decimate=1, chroma_me=1, cabac=0, deblock=0, alpha_c0=0, beta=0,
                  chroma_qp_offset=0, keyint=0, mixed_refs=0, noise_reduction=0, mv_range=0,
                  trellis=0, psy_rd=0.0, aq_mode=0, aq_strength=1.0, write=0, cabac_init_idc=0, qp_min=0, qp_max=51, payload_cap=0, raster=None,
-                 bframes=0, weightb=0, direct_pred=1):
+                 bframes=0, weightb=0, direct_pred=1, lanes=0, levels=True):
         self.lib = lib
         # x264_validate_parameters (R/encoder/encoder.c:493-522): what the RD-side options do to each other
         trellis = min(max(trellis, 0), 2) if cabac else 0
@@ -152,8 +153,7 @@ class ChainEncoder:
             d, B = self.ctx.dims, batch
             n = d.mb_w * d.mb_h
             cap = payload_cap or (n * 800 + 4096 + PAYLOAD_LEAD)
-            rb = dict(payload=DeviceArray(lib, (B, cap), np.uint8), payload_len=DeviceArray(lib, (B,), np.int32),
-                      mb_bits=DeviceArray(lib, (B, n), np.int32))
+            rb = self._frame_bufs(B, n, cap, aq_mode)
             # p_cost_mv of every QP and the unquant tables, built by the library's host C (x264hip_cost_mv_table / _unquant_table)
             tabs = np.zeros((52, 2 * COST_SPAN + 1), np.int16)
             for q in range(52):
@@ -166,9 +166,6 @@ class ChainEncoder:
             lib.x264hip_unquant_table(q8.ctypes.data_as(C.c_void_p), C.c_int(2), C.c_int(64), u8.ctypes.data_as(C.c_void_p))
             rb["unquant4_mf"] = DeviceArray(lib, u4.shape, np.int32, u4)
             rb["unquant8_mf"] = DeviceArray(lib, u8.shape, np.int32, u8)
-            if aq_mode:
-                rb["aq_energy"] = DeviceArray(lib, (B, n), np.int32)
-                rb["aq_offset"] = DeviceArray(lib, (B, n), np.float32)
             self.rd_bufs = rb
             self.payload_cap = cap
         self.i_frame, self.i_frame_stride = 0, 0      # shard.py sets both when the chains are the GOPs of one stream
@@ -178,8 +175,23 @@ class ChainEncoder:
         self.bopt = dict(bframes=bframes, weightb=int(bool(weightb)), direct_spatial=int(direct_pred != 2))
         self.dpb = max(n_refs, 2 if bframes else 1)
         self.pool = [self.ctx.new_picture() for _ in range(self.dpb + 1)]
-        self.states = [DeviceState(self.ctx) for _ in range(self.dpb + 1)]
+        if not levels and not self.rd_opt["write"]:
+            raise ValueError("levels=False: the coefficient levels are the only product unless the sweep writes the payload (write=1)")
+        self.states = [DeviceState(self.ctx, levels) for _ in range(self.dpb + 1)]
         self.refs = []                 # [(picture, state, poc)], newest first
+        # lanes: the B frames between two anchors predict from the anchors only, never from each other, so they are independent
+        # of one another and of the NEXT anchor.  With lanes = K each B frame is enqueued on one of K extra streams (own
+        # reconstruction, state and payload buffers), ordered behind the anchor it needs by an event, and runs beside the
+        # following anchor: a launch's slow chains no longer hold the whole device.  Same results, bit for bit.
+        self.lanes, self.lane_i, self.anchor_ev, self.b_readers = [], 0, None, []
+        if lanes and bframes:
+            if not self.raster:
+                raise ValueError("lanes: B frames run in the raster variant")
+            d = self.ctx.dims
+            for _ in range(lanes):
+                lc = FrameCtx(lib, width, height, batch=batch)
+                self.lanes.append(dict(ctx=lc, recon=lc.new_picture(source_only=True), state=DeviceState(lc, levels),
+                                       bufs=self._frame_bufs(batch, d.mb_w * d.mb_h, self.payload_cap, aq_mode)))
         self.t = 0
         self.last_idr = 0
         self.profile = None            # DeviceArray [batch][mb_h][8] int64 when phase timing is wanted
@@ -190,6 +202,21 @@ class ChainEncoder:
             self.ctx.check(lib.x264hip_nr_state_alloc(self.ctx.h, C.byref(self.nr)), "nr_state_alloc")
         lib.x264hip_event_create.restype = C.c_void_p
         lib.x264hip_event_elapsed_ms.restype = C.c_float
+
+    def _frame_bufs(self, B, n, cap, aq_mode):
+        """What one frame in flight writes: the payload, its length, the bit position after every macroblock, the AQ arrays."""
+        lib = self.lib
+        rb = dict(payload=DeviceArray(lib, (B, cap), np.uint8), payload_len=DeviceArray(lib, (B,), np.int32), mb_bits=DeviceArray(lib, (B, n), np.int32))
+        if aq_mode:
+            rb["aq_energy"] = DeviceArray(lib, (B, n), np.int32)
+            rb["aq_offset"] = DeviceArray(lib, (B, n), np.float32)
+        return rb
+
+    def sync(self):
+        """Everything enqueued so far, on the main stream and on the lanes, has finished."""
+        self.ctx.sync()
+        for ln in self.lanes:
+            ln["ctx"].sync()
 
     def cost_table(self, qp):
         if qp not in self.cost:
@@ -204,6 +231,8 @@ class ChainEncoder:
         return self._fenc
 
     def upload(self, y, u, v, b=0):
+        for ln in self.lanes:          # a B frame still in flight on a lane may be reading this picture
+            ln["ctx"].sync()
         self.ctx.upload(self.fenc, y, u, v, b=b)
 
     def encode_frame(self, src=None, stype=None, disp=None):
@@ -221,8 +250,26 @@ class ChainEncoder:
             self.refs, self.last_idr = [], disp
         poc = 2 * (disp - self.last_idr)
         used = [r[0] for r in self.refs]
-        pic_i = next(i for i, p in enumerate(self.pool) if not any(p is q for q in used))
-        recon, state = self.pool[pic_i], self.states[pic_i]
+        lane = None
+        if is_b and self.lanes:        # a lane's stream: behind the last anchor's filters, beside whatever else is in flight
+            lane = self.lanes[self.lane_i % len(self.lanes)]
+            self.lane_i += 1
+            c, recon, state = lane["ctx"], lane["recon"], lane["state"]
+            if self.anchor_ev:
+                L.x264hip_stream_wait_event(C.c_void_p(c.stream), C.c_void_p(self.anchor_ev))
+        else:
+            pic_i = next(i for i, p in enumerate(self.pool) if not any(p is q for q in used))
+            recon, state = self.pool[pic_i], self.states[pic_i]
+            keep = []
+            for ev, reads in self.b_readers:       # B frames on the lanes that still read the picture / state about to be overwritten
+                if pic_i in reads:
+                    L.x264hip_stream_wait_event(C.c_void_p(c.stream), C.c_void_p(ev))
+                    reads.discard(pic_i)
+                if reads:
+                    keep.append((ev, reads))
+                else:
+                    L.x264hip_event_destroy(C.c_void_p(ev))
+            self.b_readers = keep
         # x264_reference_build_list (R/encoder/encoder.c:911-981): list 0 = earlier pictures, nearest first; list 1 = later ones
         refs = sorted([r for r in self.refs if r[2] < poc], key=lambda r: -r[2])[:o["n_refs"]]
         refs1 = sorted([r for r in self.refs if r[2] > poc], key=lambda r: r[2])[:1] if is_b else []
@@ -238,7 +285,8 @@ class ChainEncoder:
                         profile=self.profile.ptr if self.profile else None,
                         noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless)
         if self.raster:
-            rb, ro = self.rd_bufs, self.rd_opt
+            rb, ro = dict(self.rd_bufs, **lane["bufs"]) if lane else self.rd_bufs, self.rd_opt
+            self.last_bufs = rb
             if ro["aq_mode"]:                  # x264_adaptive_quant_frame on the source (R/encoder/encoder.c:1421)
                 L.x264hip_adaptive_quant_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
                 c.check(L.x264hip_adaptive_quant_frame(c.h, C.byref(fenc), C.c_float(ro["aq_strength"]), rb["aq_energy"].p, rb["aq_offset"].p), "adaptive_quant_frame")
@@ -267,7 +315,13 @@ class ChainEncoder:
             self.events.append((ev[0], ev[1], stype, len(refs) + len(refs1)))
         if self.nr:                            # x264_noise_reduction_update at the end of every frame (R/encoder/encoder.c:1755)
             c.check(L.x264hip_noise_reduction_update(c.h, C.byref(self.nr), o["noise_reduction"]), "noise_reduction_update")
+        if lane:                               # whoever overwrites one of the pictures this frame reads waits for it
+            ev = L.x264hip_event_create()
+            L.x264hip_event_record(C.c_void_p(ev), C.c_void_p(c.stream))
+            reads = {i for i, p in enumerate(self.pool) if any(p is r[0] for r in refs + refs1)}
+            self.b_readers.append((ev, reads))
         self.last = (recon, state)
+        self.last_ctx = c
         return stype, qp, state
 
     def finish_frame(self):
@@ -288,12 +342,17 @@ class ChainEncoder:
         c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
         self.refs.insert(0, (recon, state, getattr(self, "last_poc", 2 * (self.t - self.last_idr))))
         del self.refs[self.dpb:]
+        if self.lanes:                         # the point the B frames that predict from this anchor wait for
+            if self.anchor_ev:
+                L.x264hip_event_destroy(C.c_void_p(self.anchor_ev))
+            self.anchor_ev = L.x264hip_event_create()
+            L.x264hip_event_record(C.c_void_p(self.anchor_ev), C.c_void_p(c.stream))
         self.t += 1
         self.i_frame += 1
 
     def payloads(self):
         """slice_data() of the last frame of every chain (valid after ctx.sync()): list of bytes objects."""
-        rb = self.rd_bufs
+        rb = getattr(self, "last_bufs", None) or self.rd_bufs
         n = rb["payload_len"].get()
         raw = rb["payload"].get()
         return [bytes(raw[b, PAYLOAD_LEAD:PAYLOAD_LEAD + n[b]]) for b in range(len(n))]
@@ -302,9 +361,16 @@ class ChainEncoder:
         c = self.ctx
         if getattr(self, "last", None) is None:          # nothing launched yet
             return
-        c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(self.last[1].st)), "slice_sweep_status")
+        c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(self.last[1].st if not self.lanes or not self.last_is_b else self.states[0].st)), "slice_sweep_status")
+        for ln in self.lanes:                  # each lane's context keeps its own sticky abort count
+            ln["ctx"].check(self.lib.x264hip_slice_sweep_status(ln["ctx"].h, C.byref(ln["state"].st)), "slice_sweep_status")
 
     def close(self):
+        for ev, _ in self.b_readers:
+            self.lib.x264hip_event_destroy(C.c_void_p(ev))
+        if self.anchor_ev:
+            self.lib.x264hip_event_destroy(C.c_void_p(self.anchor_ev))
+        self.b_readers, self.anchor_ev = [], None
         if self.nr:
             self.lib.x264hip_nr_state_free(self.ctx.h, C.byref(self.nr))
             self.nr = None

@@ -126,7 +126,9 @@ def main():
                     "preset's --bframes 3 without b-adapt; 0 with --wavefront 1)")
     ap.add_argument("--weightb", type=int, default=1)
     ap.add_argument("--payload-cap", type=int, default=1 << 20, help="bytes of payload buffer per chain and frame in flight (the library's default, 800 B per macroblock, is x264's worst case)")
-    ap.add_argument("--lanes", type=int, default=-1, help="streams for the B frames of a mini-GOP, which run beside the next anchor (-1: one per B frame of the pattern; 0: one stream)")
+    ap.add_argument("--lanes", type=int, default=0, help="extra streams for the B frames of a mini-GOP, which then run beside the next anchor (0: one stream, frames in lock step -- "
+                    "with every wave slot taken by a launch's chains the lanes gain nothing, DESIGN.md 3.1c; -1: one per B frame of the pattern -- with half the chains, 1024, "
+                    "they reach 90%% of the default's rate in half the memory)")
     ap.add_argument("--psy-rd", type=float, default=1.0)
     ap.add_argument("--aq-mode", type=int, default=1)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0: one per host core)")

@@ -341,8 +341,6 @@ int  x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc
                                const x264hip_mb_state *l0, x264hip_mb_state *out);
 /* synchronises; -1 if a wavefront gave up waiting for its neighbours (the frame is then invalid) */
 int  x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st);
-int  x264hip_slice_sweep_occupancy(int b_slice);   /* raster variant: chains the runtime keeps resident per CU (I / P kernel, or the B one); <0 on error */
-int  x264hip_slice_sweep_lds_bytes(int raster, int b_slice);   /* dynamic LDS per wavefront of the sweep variant (occupancy planning; host only) */
 
 /* Inter residual pipeline for every macroblock (x264_macroblock_encode's
  * inter branch, R/encoder/macroblock.c:596-768, without trellis/denoise):

@@ -254,12 +254,11 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
-    const size_t lds_bytes = sw_lds_bytes<false, false>();
     switch (a.lossless ? 0 : wpe) {
-    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, lds_bytes, c->stream, a, t, r); break;
-    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, lds_bytes, c->stream, a, t, r); break;
-    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, lds_bytes, c->stream, a, t, r); break;
-    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, lds_bytes, c->stream, a, t, r); break;
+    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t, r); break;
+    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t, r); break;
+    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t, r); break;
+    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t, r); break;
     }
     }
     if (!prd && is_p && a.flags_intra)
@@ -273,23 +272,6 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         out->inv_ref_poc[i] = delta ? (256 + delta / 2) / delta : 0;
     }
     return 0;
-}
-
-// dynamic LDS one wavefront of the sweep is launched with (the kernels' static LDS -- the CABAC tables of the raster variants -- comes
-// on top): what bounds the chains resident per CU (tests/test_build_resources.py)
-extern "C" int x264hip_slice_sweep_lds_bytes(int raster, int b_slice)
-{
-    return (int)(!raster ? sw_lds_bytes<false, false>() : b_slice ? sw_lds_bytes<true, true>() : sw_lds_bytes<true, false>());
-}
-
-// chains (one-wavefront workgroups) of the raster variant the runtime will keep resident per CU -- what a caller sizes its batch by
-int x264hip_occupancy_slice_rd(void);
-int x264hip_occupancy_slice_b(void);
-extern "C" int x264hip_slice_sweep_occupancy(int b_slice)
-{
-    const int n = b_slice ? x264hip_occupancy_slice_b() : x264hip_occupancy_slice_rd();
-    if (n < 0) set_error("slice_sweep_occupancy: no device");
-    return n;
 }
 
 extern "C" int x264hip_slice_sweep_status(x264hip_frame_ctx *c, const x264hip_mb_state *st)

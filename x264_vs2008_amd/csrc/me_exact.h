@@ -23,7 +23,7 @@
 #include "device_prims.h"
 
 #define MX_COST_MAX (1 << 28)
-#define MX_COST_LDS 128           // half-width of the LDS copy of p_cost_mv (quarter-pels = 32 pixels either side of the predictor; beyond it the table in HBM)
+#define MX_COST_LDS 256           // half-width of the LDS copy of p_cost_mv (quarter-pels = 64 pixels either side of the predictor; beyond it the table in HBM)
 
 // R/encoder/me.c:34-50: subpel_iterations
 static __constant__ int c_subpel_iters[10][4] = {{0,0,0,0},{1,1,0,0},{0,1,1,0},{0,2,1,0},{0,2,1,1},{0,2,1,2},{0,0,2,2},{0,0,2,2},{0,0,4,10},{0,0,4,10}};

@@ -116,8 +116,10 @@ struct SwLds {
     u8 e4[16], edge8[40];
     __attribute__((aligned(4))) u8 pt4[48];   // the current 4x4 / 8x8 block's prediction table (intra_pred.h: RAW | F1 | F2 | DC..)
     __attribute__((aligned(4))) u8 pt8[80];
+    u32 p4lut[48], p8lut[192];  // c_plut4 / c_plut8
     u16 nr_off4[16], nr_off8[64];   // h->nr_offset[0] / [1] of this chain (--nr)
     __attribute__((aligned(16))) u8 patch[MX_PATCH_BYTES];   // the motion search's staged sub-pel neighbourhood (me_exact.h)
+    u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     i16 lv_y8[256];             // levels of the 8x8 transform (h->dct.luma8x8), separate from the 4x4 ones like the reference's
     i16 t8[256];                // 8x8 transform: intermediate between the two 1-D passes
     signed char left_i4[4];     // the left macroblock's modes of blocks 5, 7, 13, 15
@@ -179,6 +181,7 @@ struct SwLdsRd {
     signed char cref[48], sub[4];
     i16 cmv[48][2], cmvd[48][2];
     u8 nz_l[4], nz_t[4], nz_lc[2][2], nz_tc[2][2];
+    i16 i4_dct[256], i8_dct[256];   // h->mb.pic.i4x4_dct_buf / i8x8_dct_buf (i_skip_intra == 2)
     int fenc_satd[16], fenc_sa8d[4];   // h->mb.pic.fenc_satd / fenc_sa8d (psy-RD)
     int unq4[4][16], unq8[2][64];   // unquant rows of the current QPs
     i16 left_mvd[4][2];             // the left macroblock's mvd of blocks 3, 7, 11, 15
@@ -189,21 +192,8 @@ struct SwLdsRd {
     int tmp_i[4];                   // lane 0 -> wave: bit count / QP after the writer
     TdWave tw;
 };
-// c_plut4 / c_plut8 (intra_pred.h) as words, read where they are (constant memory, cache-resident: 960 bytes of LDS per chain bought a
-// few hundred nanoseconds per intra block; the LDS is worth more as occupancy)
-#define SW_PLUT4 ((const u32 *)&c_plut4)
-#define SW_PLUT8 ((const u32 *)&c_plut8)
-// the lane-parallel trellis' scratch beyond SwLdsRd::tw (trellis_wave.h): the level lists at the head of the motion search's patch, TdAux
-// behind them, the candidates' scores in the 8x8 transform's intermediate -- none of them holds anything while a block is quantised
-#define SW_TD_AUX(s) (*(TdAux *)((s).patch + 4 * TDW_TREE_WORDS))
-#define SW_TD_CSCORE(s) ((TdCscore *)(s).t8)
-static_assert(4 * TDW_TREE_WORDS + sizeof(TdAux) <= MX_PATCH_BYTES && (4 * TDW_TREE_WORDS) % 8 == 0, "trellis scratch in the patch");
-static_assert(TDW_CSCORE_BYTES <= sizeof(((SwLds *)0)->t8) && offsetof(SwLds, t8) % 8 == 0 && offsetof(SwLds, patch) % 16 == 0, "trellis candidates in t8");
 struct SwLdsNone { int unused; };
 struct SwLdsRdB { SwLdsRd r; SwLdsB b; };
-template <bool RD, bool BS> struct SwLdsOf { typedef typename std::conditional<BS, SwLdsRdB, typename std::conditional<RD, SwLdsRd, SwLdsNone>::type>::type type; };
-#define SW_LDS_ALIGN(n) (((n) + 15) & ~(size_t)15)
-template <bool RD, bool BS> constexpr size_t sw_lds_bytes() { return SW_LDS_ALIGN(sizeof(SwLds)) + SW_LDS_ALIGN(sizeof(typename SwLdsOf<RD, BS>::type)); }
 // the record cabac_dev.h's writer walks (same member names as MbSyn): scalars in registers, arrays where the kernel keeps them in LDS
 struct MbSynDev {
     int slice_type, type, partition, i16mode, chroma_mode, cbp_luma, cbp_chroma, t8, qp, n_ref, pps_t8, t8_allowed;
@@ -471,7 +461,7 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const 
         WAVE_SYNC();
 #pragma nounroll
         for (int it = 0; it < 4; it++)
-            td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, &s.coef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
+            td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.coef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
                             d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16, lane);
         WAVE_SYNC();
     }
@@ -581,7 +571,7 @@ __device__ __forceinline__ int sw_encode_i16x16(SwLds &s, const SwArgs &a, const
     }
     if (tq.on) {                                       // x264_quant_dc_trellis( .., DCT_LUMA_DC, 1 ), macroblock.c:247-248
         WAVE_SYNC();
-        td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, &s.dc16[0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16, lane);
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.dc16[0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 0, d_trellis_lambda2[1][Q.qp], 0, 1, 16, lane);
         WAVE_SYNC();
     }
     if (lane == 0) {
@@ -654,7 +644,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
         WAVE_SYNC();
 #pragma nounroll
         for (int it = 0; it < 2; it++)
-            td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, &s.ccoef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16, lane);
+            td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.ccoef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, 4, d_trellis_lambda2[!b_inter][Q.qpc], 1, 0, 16, lane);
         WAVE_SYNC();
     }
     if (lane < 8) {
@@ -685,7 +675,7 @@ __device__ __forceinline__ int sw_encode_chroma(SwLds &s, const SwArgs &a, const
     }
     if (tq.on) {                                      // x264_quant_dc_trellis( .., DCT_CHROMA_DC, !b_inter ), macroblock.c:325-326
         WAVE_SYNC();
-        td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, &s.cdcout[4 * ((lane >> 4) & 1)], lane < 32, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4, lane);
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.cdcout[4 * ((lane >> 4) & 1)], lane < 32, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz2, tq.r->cabac, 3, d_trellis_lambda2[!b_inter][Q.qpc], 0, 1, 4, lane);
         WAVE_SYNC();
     }
     if (lane < 2) {
@@ -844,7 +834,7 @@ __device__ __forceinline__ void sw_luma8x8_fwd(SwLds &s, const SwQp &Q, SwTq tq,
 #pragma nounroll
         for (int j = 0; j < 4; j++)
             if ((mask >> j) & 1)
-                td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, coef + 64 * j, lane < 16, s.q8mf[cat], tq.r->unq8[cat], tq.r->w8z, tq.r->zz8, tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64, lane);
+                td_trellis_wave(tq.r->tw, (u32 *)s.patch, coef + 64 * j, lane < 16, s.q8mf[cat], tq.r->unq8[cat], tq.r->w8z, tq.r->zz8, tq.r->cabac, 5, d_trellis_lambda2[cat == 0][Q.qp], 0, 0, 64, lane);
         WAVE_SYNC();
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -978,7 +968,7 @@ __device__ __forceinline__ void sw_encode_i4x4(SwLds &s, const SwArgs &a, const 
     if (tq.on) {                                      // x264_quant_4x4_trellis( .., DCT_LUMA_4x4, 1, idx ), macroblock.c:134
         if (lane < 16) s.coef[idx][l16] = (i16)v;
         WAVE_SYNC();
-        td_trellis_wave(tq.r->tw, SW_TD_AUX(s), SW_TD_CSCORE(s), (u32 *)s.patch, &s.coef[idx][0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16, lane);
+        td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.coef[idx][0], lane < 16, s.qmf[0], tq.r->unq4[0], tq.r->w4z, tq.r->zz4, tq.r->cabac, 2, d_trellis_lambda2[1][Q.qp], 0, 0, 16, lane);
         WAVE_SYNC();
         q = s.coef[idx][l16];
     } else
@@ -1285,13 +1275,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
 #define IS_SKIP_T(t) (BS ? ((t) == T_P_SKIP || (t) == T_B_SKIP) : (t) == T_P_SKIP)      /* BS is a template constant: the other kernels keep their single compare */
     __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
                                                         // kernel argument is copied to scratch memory whole)
-    // dynamic LDS (the launchers pass sw_lds_bytes<RD, BS>()): with a static allocation the compiler derives the occupancy from
-    // the LDS size and ignores amdgpu_waves_per_eu; the register budget of the raster variants (WPE = 3: 168 VGPRs) is what lets
-    // more than two chains share a SIMD once the LDS per chain allows it
-    extern __shared__ __attribute__((aligned(16))) unsigned char sw_dyn_lds[];
-    SwLds &s = *(SwLds *)sw_dyn_lds;
-    typedef typename SwLdsOf<RD, BS>::type SrT;
-    SrT &sr_ = *(SrT *)(sw_dyn_lds + SW_LDS_ALIGN(sizeof(SwLds)));
+    __shared__ SwLds s;
+    __shared__ typename std::conditional<BS, SwLdsRdB, typename std::conditional<RD, SwLdsRd, SwLdsNone>::type>::type sr_;
     SwLdsRd &sr = *(SwLdsRd *)&sr_;                     // only touched when RD
     SwLdsB &sb = *(SwLdsB *)((char *)&sr_ + sizeof(SwLdsRd));    // only touched when BS (then sr_ is an SwLdsRdB)
     const int lane_id = threadIdx.x, lane = lane_id;
@@ -1332,6 +1317,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     load_qp_tables(lane);
     {
         if (a.nr) { s.nr_off8[lane] = a.nr_offset[(size_t)bz * 128 + 64 + lane]; if (lane < 16) s.nr_off4[lane] = a.nr_offset[(size_t)bz * 128 + lane]; }
+        if (lane < 48) s.p4lut[lane] = ((const u32 *)&c_plut4)[lane];
+        for (int k = lane; k < 192; k += 64) s.p8lut[k] = ((const u32 *)&c_plut8)[k];
     }
     // the entropy coder of this chain's slice (x264_slice_write, R/encoder/encoder.c:1155-1165)
     DCabac cab = {0, 0x1FE, -1, 0, nullptr, 0};
@@ -1494,9 +1481,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         SwTq tq = {RD && rd.trellis > 1 && mbrd, &sr};
         int skip_intra = a.lossless ? 0 : mbrd ? 2 : (RD ? (!rd.trellis && !a.nr) : 1);
         (void)skip_intra;
-        // what the reference keeps of the intra analysis when i_skip_intra is set (h->mb.pic.i4x4_fdec_buf / i8x8_fdec_buf, _nnz_buf, and
-        // with the RD levels _dct_buf): each lane keeps its own four bytes / four levels, in registers
-        u32 ski4_f = 0, ski8_f = 0, ski4_n = 0, ski8_n = 0, ski4_d0 = 0, ski4_d1 = 0, ski8_d0 = 0, ski8_d1 = 0;
 
         // x264_mb_analyse_intra_chroma, R/encoder/analyse.c:539-610
         auto analyse_chroma = [&]() {
@@ -1576,7 +1560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         u32 key = 0xffffffffu;
                         if (g < n) {
                             const int mode = (int)((list >> (4 * g)) & 15);
-                            const u32 o0 = SW_PLUT8[(mode * 8 + r) * 2], o1 = SW_PLUT8[(mode * 8 + r) * 2 + 1];
+                            const u32 o0 = s.p8lut[(mode * 8 + r) * 2], o1 = s.p8lut[(mode * 8 + r) * 2 + 1];
                             const u32 f0 = *(const u32 *)(s.fe + (by + r) * 16 + bx), f1 = *(const u32 *)(s.fe + (by + r) * 16 + bx + 4);
                             int d[8];
 #pragma unroll
@@ -1607,7 +1591,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (lane == 0) s.pred8[idx] = (signed char)bmode;
                     if (idx == 3 || cost > thresh) break;
                     {
-                        int v = s.pt8[(SW_PLUT8[(bmode * 8 + (lane >> 3)) * 2 + ((lane >> 2) & 1)] >> (8 * (lane & 3))) & 255];
+                        int v = s.pt8[(s.p8lut[(bmode * 8 + (lane >> 3)) * 2 + ((lane >> 2) & 1)] >> (8 * (lane & 3))) & 255];
                         if (a.lossless && bmode < 2) v = sw_ll_px(s, 0, bmode, bx + (lane & 7), by + (lane >> 3));
                         WAVE_SYNC();
                         s.fd[FDY + (by + (lane >> 3)) * FD + bx + (lane & 7)] = (u8)v;
@@ -1618,9 +1602,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 }
                 if (idx == 3) {
                     satd_i8 = cost; i8_cbp = acbp;
-                    if constexpr (RD) { if (skip_intra == 2) { ski8_d0 = (u32)(u16)s.lv_y8[lane] | (u32)(u16)s.lv_y8[lane + 64] << 16; ski8_d1 = (u32)(u16)s.lv_y8[lane + 128] | (u32)(u16)s.lv_y8[lane + 192] << 16; } }
-                    ski8_f = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
-                    ski8_n = s.nnz[lane & 15];
+                    if constexpr (RD) { if (skip_intra == 2) for (int k = lane; k < 256; k += 64) sr.i8_dct[k] = s.lv_y8[k]; }
+                    *(u32 *)(s.i8_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
+                    if (lane < 16) s.i8_nnz[lane] = s.nnz[lane];
                     WAVE_SYNC();
                 } else {
                     satd_i8 = MX_COST_MAX;
@@ -1647,7 +1631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         const int g = lane >> 2, r = lane & 3;
                         if (g < n) {
                             const int mode = (int)((list >> (4 * g)) & 15);
-                            const u32 off = SW_PLUT4[mode * 4 + r], fw = *(const u32 *)(s.fe + (by + r) * 16 + bx);
+                            const u32 off = s.p4lut[mode * 4 + r], fw = *(const u32 *)(s.fe + (by + r) * 16 + bx);
                             int d0 = (int)(fw & 255) - (int)s.pt4[off & 255], d1 = (int)((fw >> 8) & 255) - (int)s.pt4[(off >> 8) & 255];
                             int d2 = (int)((fw >> 16) & 255) - (int)s.pt4[(off >> 16) & 255], d3 = (int)(fw >> 24) - (int)s.pt4[off >> 24];
                             if (a.lossless && mode < 2) {
@@ -1666,16 +1650,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     if (lane == 0) s.pred4[idx] = (signed char)bmode;
                     if (cost > thresh || idx == 15) break;
                     if (lane < 16) dst[(lane >> 2) * FD + (lane & 3)] = a.lossless && bmode < 2 ? (u8)sw_ll_px(s, 0, bmode, bx + (lane & 3), by + (lane >> 2))
-                                                                         : s.pt4[(SW_PLUT4[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
+                                                                         : s.pt4[(s.p4lut[bmode * 4 + (lane >> 2)] >> (8 * (lane & 3))) & 255];
                     if (lane == 0) s.i4c[sw_scan8(idx)] = (signed char)bmode;
                     WAVE_SYNC();
                     sw_encode_i4x4(s, a, Q, tq, idx, acbp, lane);
                 }
                 if (idx == 15) {
                     satd_i4 = cost; i4_cbp = acbp;
-                    if constexpr (RD) { if (skip_intra == 2) { ski4_d0 = (u32)(u16)s.lv_y[lane] | (u32)(u16)s.lv_y[lane + 64] << 16; ski4_d1 = (u32)(u16)s.lv_y[lane + 128] | (u32)(u16)s.lv_y[lane + 192] << 16; } }
-                    ski4_f = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
-                    ski4_n = s.nnz[lane & 15];
+                    if constexpr (RD) { if (skip_intra == 2) for (int k = lane; k < 256; k += 64) sr.i4_dct[k] = s.lv_y[k]; }
+                    *(u32 *)(s.i4_fdec + lane * 4) = *(const u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4);
+                    if (lane < 16) s.i4_nnz[lane] = s.nnz[lane];
                     WAVE_SYNC();
                 } else
                     satd_i4 = MX_COST_MAX;
@@ -1721,15 +1705,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 if (lane < 16) s.i4c[sw_scan8(lane)] = i8 ? s.pred8[lane >> 2] : s.pred4[lane];
                 analyse_chroma();
                 if (skip_intra) {
-                    *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = i8 ? ski8_f : ski4_f;
-                    if (lane < 16) s.nnz[lane] = (u8)(i8 ? ski8_n : ski4_n);
+                    *(u32 *)(s.fd + FDY + (lane >> 2) * FD + (lane & 3) * 4) = *(const u32 *)((i8 ? s.i8_fdec : s.i4_fdec) + lane * 4);
+                    if (lane < 16) s.nnz[lane] = i8 ? s.i8_nnz[lane] : s.i4_nnz[lane];
                     cbp_luma = i8 ? i8_cbp : i4_cbp;
                     if constexpr (RD) {                  // "In RD mode, restore the now-overwritten DCT data", macroblock.c:543
-                        if (skip_intra == 2) {
-                            const u32 d0 = i8 ? ski8_d0 : ski4_d0, d1 = i8 ? ski8_d1 : ski4_d1;
-                            i16 *lv = i8 ? s.lv_y8 : s.lv_y;
-                            lv[lane] = (i16)(d0 & 0xffff); lv[lane + 64] = (i16)(d0 >> 16); lv[lane + 128] = (i16)(d1 & 0xffff); lv[lane + 192] = (i16)(d1 >> 16);
-                        }
+                        if (skip_intra == 2) for (int k = lane; k < 256; k += 64) { if (i8) s.lv_y8[k] = sr.i8_dct[k]; else s.lv_y[k] = sr.i4_dct[k]; }
                     }
                 }
                 WAVE_SYNC();

@@ -14,19 +14,13 @@
 struct TdWave {                          // per-wavefront scratch, [group] first
     long long nscore[4][2][8];           // score of node j of generation 0 / 1
     u32 nst[4][2][8][3];                 // its ten level-coding context states, packed
-};
-// the rest of the scratch lives in LDS that is idle while a block is quantised (the caller names it): TdAux behind the level lists in
-// the motion search's patch, the candidates' scores (TDW_CSCORE_BYTES) in the 8x8 transform's intermediate
-struct TdAux {
-    u16 nlv[4][2][8];                    // head of node j's level list
-    u8 ctgt[4][16];                      // the candidates' target nodes (0xff: none)
+    u16 nlv[4][2][8];                    // head of its level list
+    long long cscore[4][16];             // the candidates of the current coefficient
+    u8 ctgt[4][16];                      // their target nodes (0xff: none)
     u16 abs_c[64];                       // |coefficient| by scan position: group g at [16 g] for 16-coefficient blocks, one group for 64
     u8 st_sig[64], st_last[64];          // the states of the significance / last flags by scan position, same layout
 };
-typedef long long TdCscore[16];          // [group][lane of the group]: the candidates of the current coefficient
-#define TDW_CSCORE_BYTES (4 * sizeof(TdCscore))
 #define TDW_TREE_STRIDE 132              // level-list entries per group for blocks of up to 16 coefficients (1 + 16 * 8, padded)
-#define TDW_TREE_WORDS 528               // max(4 * TDW_TREE_STRIDE, TDW_TREE_ENTRIES)
 #define TDW_TREE_ENTRIES 516             // ... and what one 64-coefficient block needs (1 + 64 * 8, padded): the area holds max(4 * 132, 516) words
 
 __device__ __forceinline__ int tdw_st_get(const u32 w[3], int i) { const u32 v = i < 4 ? w[0] : i < 8 ? w[1] : w[2]; return (int)((v >> (8 * (i & 3))) & 255u); }
@@ -40,9 +34,9 @@ __device__ __forceinline__ void tdw_st_set(u32 w[3], int i, int s)
 
 // Every lane of the wavefront calls this.  Group g = lane >> 4 quantises the block at `dct` (its own pointer) when `active`; mf, unq,
 // weight, zz, st, cat, lambda2, b_ac, dc, n_coef as td_trellis_quant and the same for all groups.  n_coef == 64: only group 0 may be
-// active.  tree: TDW_TREE_WORDS words of LDS.  Returns "some level of this group's block is not zero" (0 for an inactive group).
+// active.  tree: TDW_TREE_ENTRIES words of LDS.  Returns "some level of this group's block is not zero" (0 for an inactive group).
 template <class DCT, class MF, class UNQ, class WT, class ZZ, class ST>
-__device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cscore, u32 *tree_all, DCT dct, bool active, MF mf, UNQ unq, WT weight, ZZ zz, ST st,
+__device__ __forceinline__ int td_trellis_wave(TdWave &w, u32 *tree_all, DCT dct, bool active, MF mf, UNQ unq, WT weight, ZZ zz, ST st,
                                                int cat, int lambda2, int b_ac, int dc, int n_coef, int lane)
 {
     const int f = 1 << 15, g = lane >> 4, c = lane & 15, j = c & 7, lvsel = c >> 3;
@@ -60,9 +54,9 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
     if (active && last_nnz < b_ac) { for (int i = c; i < n_coef; i += 16) dct[i] = 0; }
     if (active && last_nnz >= b_ac) {
         for (int i = c; i < n_coef; i += 16) {
-            if (i >= b_ac && i <= last_nnz) x.abs_c[cb + i] = (u16)cd_abs((int)dct[zz[i]]);
-            if (n_coef == 64) { if (i < 63) { x.st_sig[i] = st[CD_SIG_OFF(5) + CD_SIG8(i)]; x.st_last[i] = st[CD_LAST_OFF(5) + CD_LAST8(i)]; } }
-            else if (i < ((!dc || cat != 3) ? 15 : 3)) { x.st_sig[cb + i] = st[CD_SIG_OFF(cat) + i]; x.st_last[cb + i] = st[CD_LAST_OFF(cat) + i]; }
+            if (i >= b_ac && i <= last_nnz) w.abs_c[cb + i] = (u16)cd_abs((int)dct[zz[i]]);
+            if (n_coef == 64) { if (i < 63) { w.st_sig[i] = st[CD_SIG_OFF(5) + CD_SIG8(i)]; w.st_last[i] = st[CD_LAST_OFF(5) + CD_LAST8(i)]; } }
+            else if (i < ((!dc || cat != 3) ? 15 : 3)) { w.st_sig[cb + i] = st[CD_SIG_OFF(cat) + i]; w.st_last[cb + i] = st[CD_LAST_OFF(cat) + i]; }
         }
         if (lvsel == 0) {
             w.nscore[g][0][j] = j == 0 ? 0 : TD_INF;
@@ -72,7 +66,7 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
 #pragma unroll
                 for (int k = 0; k < 10; k++) tdw_st_set(s3, k, st[lo + k]);
                 w.nst[g][0][0][0] = s3[0]; w.nst[g][0][0][1] = s3[1]; w.nst[g][0][0][2] = s3[2];
-                x.nlv[g][0][0] = 0;
+                w.nlv[g][0][0] = 0;
                 tree[0] = 0;                                        // the list's end: level 0, next = itself
             }
         }
@@ -80,12 +74,12 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
         int cur = 0, slot = 1;
 #pragma nounroll
         for (int i = last_nnz; i >= b_ac; i--, slot += 8) {
-            const int coef = x.abs_c[cb + i], q = (f + coef * (dc ? (int)mf[0] >> 1 : (int)mf[zz[i]])) >> 16;
+            const int coef = w.abs_c[cb + i], q = (f + coef * (dc ? (int)mf[0] >> 1 : (int)mf[zz[i]])) >> 16;
             if (q == 0) {                                          // only "not significant" to pay, for every live node but 0
                 if (lvsel == 0 && j > 0 && w.nscore[g][cur][j] != TD_INF) {
-                    const u32 c0 = (u32)((unsigned long long)CD_ENT(x.st_sig[cb + i], 0) * (unsigned)lambda2 >> 4);
-                    tree[slot + j] = (u32)x.nlv[g][cur][j] << 16;
-                    x.nlv[g][cur][j] = (u16)(slot + j);
+                    const u32 c0 = (u32)((unsigned long long)CD_ENT(w.st_sig[cb + i], 0) * (unsigned)lambda2 >> 4);
+                    tree[slot + j] = (u32)w.nlv[g][cur][j] << 16;
+                    w.nlv[g][cur][j] = (u16)(slot + j);
                     w.nscore[g][cur][j] += c0;
                 }
                 TDW_SYNC();
@@ -97,15 +91,15 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
             // ---- this lane's candidate ----
             int cost_sig0 = 0, cost_sig1 = 0, cost_last0 = 0, cost_last1 = 0;
             if (i < n_coef - 1) {
-                cost_sig0 = CD_ENT(x.st_sig[cb + i], 0); cost_sig1 = CD_ENT(x.st_sig[cb + i], 1);
-                cost_last0 = CD_ENT(x.st_last[cb + i], 0); cost_last1 = CD_ENT(x.st_last[cb + i], 1);
+                cost_sig0 = CD_ENT(w.st_sig[cb + i], 0); cost_sig1 = CD_ENT(w.st_sig[cb + i], 1);
+                cost_last0 = CD_ENT(w.st_last[cb + i], 0); cost_last1 = CD_ENT(w.st_last[cb + i], 1);
             }
             const int lvl = q - lvsel;
             long long score = w.nscore[g][prv][j];
             const bool live = score != TD_INF;
             int node = j;
             u32 s3[3] = {w.nst[g][prv][j][0], w.nst[g][prv][j][1], w.nst[g][prv][j][2]};
-            const int lv_prev = x.nlv[g][prv][j];
+            const int lv_prev = w.nlv[g][prv][j];
             if (live) {
                 const int unq_lvl = ((dc ? (int)unq[0] << 1 : (int)unq[zz[i]]) * lvl + 128) >> 8, d = coef - unq_lvl;
                 const long long ssd = (long long)d * d * (dc ? 256 : (int)weight[i]);
@@ -134,21 +128,21 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
                 }
                 score += ssd;
             }
-            cscore[g][c] = score; x.ctgt[g][c] = (u8)(live ? node : 0xff);
+            w.cscore[g][c] = score; w.ctgt[g][c] = (u8)(live ? node : 0xff);
             TDW_SYNC();
             // ---- the first cheapest candidate of a node takes it ----
             if (live) {
                 bool win = true;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const long long so = cscore[g][k];
-                    if (x.ctgt[g][k] == node && (so < score || (so == score && k < c))) win = false;
+                    const long long so = w.cscore[g][k];
+                    if (w.ctgt[g][k] == node && (so < score || (so == score && k < c))) win = false;
                 }
                 if (win) {
                     w.nscore[g][cur][node] = score;
                     w.nst[g][cur][node][0] = s3[0]; w.nst[g][cur][node][1] = s3[1]; w.nst[g][cur][node][2] = s3[2];
                     tree[slot + node] = (u32)lvl | (u32)lv_prev << 16;
-                    x.nlv[g][cur][node] = (u16)(slot + node);
+                    w.nlv[g][cur][node] = (u16)(slot + node);
                 }
             }
             TDW_SYNC();
@@ -157,7 +151,7 @@ __device__ __forceinline__ int td_trellis_wave(TdWave &w, TdAux &x, TdCscore *cs
         if (c == 0) {
             int b = 0;
             for (int k = 1; k < 8; k++) if (w.nscore[g][cur][k] < w.nscore[g][cur][b]) b = k;
-            int e = x.nlv[g][cur][b];
+            int e = w.nlv[g][cur][b];
             for (int i = b_ac; i < n_coef; i++) {
                 const u32 t = tree[e];
                 const int a = (int)(t & 0xffffu);

@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--dct8", type=int, default=1, help="param.analyse.b_transform_8x8")
     ap.add_argument("--cpu-frames", type=int, default=0, help="0: 12 (raster variant) / 40 (--wavefront 1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--host-sources", action="store_true", help="fill the source ring with one host upload per chain and picture instead of device-side copies "
+                    "(slow set-up; rocprofv3 --pmc of ROCm 7.2 crashes on the runtime's own copy kernels)")
     args = ap.parse_args()
     wf = bool(args.wavefront)
     args.steps = args.steps or (24 if wf else 12)
@@ -195,9 +197,9 @@ def main():
     pool_n = max(pool_n, n_src + 1)
     pool = [synth.frame(args.width, args.height, rank * 97 + i) for i in range(pool_n)]
     srcs = []
-    if wf or B < pool_n:
+    if wf or B < pool_n or args.host_sources:
         for i in range(n_src):
-            pic = ctx.new_picture()
+            pic = ctx.new_picture(source_only=not wf)
             for b in range(B):
                 ctx.upload(pic, *pool[(i + 3 * b) % pool_n], b=b)
             srcs.append(pic)
@@ -276,10 +278,11 @@ def main():
         kinds = collections.Counter(("I" if st == sl.SLICE_I else "B" if st == sl.SLICE_B else "P", nr) for _, _, st, nr in enc.events)
         (kname, knr), _ = kinds.most_common(1)[0]
         hit = [l for l in tj["launches"] if l["slice"] == kname and l["refs"] == knr]
-        if hit and tj["batch"] == B and tj.get("bframes", 0) == args.bframes:
-            traffic = hit[0]["fetch_bytes"] + hit[0]["write_bytes"]
+        if hit and tj.get("bframes", 0) == args.bframes:
+            # (measured with tj["batch"] chains per launch; per macroblock it is the same work, scaled to this run's batch)
+            traffic = int((hit[0]["fetch_bytes"] + hit[0]["write_bytes"]) * (B / tj["batch"]))
             traffic_note = ("FETCH_SIZE + WRITE_SIZE of one %s launch with %d reference pictures (the most frequent launch of the timed region), rocprofv3 --pmc, "
-                            "separate passes, raw request-granular counters (profiles/%s)" % (kname, knr, tname))
+                            "separate passes, raw request-granular counters, measured at %d chains per launch and scaled to %d (profiles/%s)" % (kname, knr, tj["batch"], B, tname))
 
     if rank == 0:
         fps = world * B * args.steps / dt

@@ -1,0 +1,234 @@
+/* encode_chain.c -- a plain C consumer of libx264hip.so's slice level (include/x264hip.h), the way an encoder written in C binds it.
+ *
+ *   encode_chain in.yuv width height frames out.bin [bframes]
+ *
+ * Reads `frames` I420 pictures, codes them as one closed GOP I P (B B B) P ... with the medium preset's analysis options at constant
+ * QP 26 (hex, subme 7, trellis 1, psy-rd 1.0, aq-mode 1, 3 references, mixed refs, 8x8dct, p8x8 / b8x8 / i8x8 / i4x4, weightb, spatial
+ * direct, CABAC, in-loop deblocking) and writes every frame's slice_data() in coding order: int32 display index, int32 slice type,
+ * int32 length, the bytes.  What the host keeps of x264_encoder_encode around the macroblock loop is here in C: the quantiser tables
+ * of x264_cqm_init for flat matrices, the frame order of a fixed B pattern, list 0 / list 1 by POC, the DPB, the QP of each slice
+ * type, psy-rd's chroma QP offset.  tests/test_gpu_c_consumer.py compares the output with the Python host's (ChainEncoder) byte for
+ * byte -- both are pinned to the reference by the fixtures of tests/golden.
+ *
+ * No HIP header, no C++: only x264hip.h.  Build: cc -std=c99 -O2 -Iinclude examples/encode_chain.c -o examples/encode_chain
+ *                                                   -Lx264_vs2008_amd -lx264hip -lm -Wl,-rpath,'$ORIGIN/../x264_vs2008_amd' */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "x264hip.h"
+
+#define CHECK(call) do { if ((call) != 0) { fprintf(stderr, "%s failed: %s\n", #call, x264hip_last_error()); exit(1); } } while (0)
+#define COST_SPAN (2 * 4 * 2048)                 /* p_cost_mv reaches +-2*4*2048 quarter-pels (R/encoder/analyse.c:191-198) */
+#define MAX_REFS 3
+#define QP 26
+
+/* x264_lambda_tab, R/encoder/analyse.c:140-149 */
+static const int lambda_tab[52] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6,
+                                   6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+
+/* ---- x264_cqm_init for flat matrices (R/common/set.c:27-66,75-180) ---- */
+static const int dequant4_scale[6][3] = {{10, 13, 16}, {11, 14, 18}, {13, 16, 20}, {14, 18, 23}, {16, 20, 25}, {18, 23, 29}};
+static const int quant4_scale[6][3] = {{13107, 8066, 5243}, {11916, 7490, 4660}, {10082, 6554, 4194}, {9362, 5825, 3647}, {8192, 5243, 3355}, {7282, 4559, 2893}};
+static const int quant8_scan[16] = {0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1};
+static const int dequant8_scale[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                         {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+static const int quant8_scale[6][6] = {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290},
+                                       {10082, 8943, 15978, 9675, 12710, 11985}, {9362, 8228, 14913, 8931, 11984, 11259},
+                                       {8192, 7346, 13159, 7740, 10486, 9777}, {7282, 6428, 11570, 6830, 9118, 8640}};
+static int div_round(int n, int d) { return (n + (d >> 1)) / d; }
+static int shift_round(int x, int s) { return s < 0 ? x << -s : s == 0 ? x : (x + (1 << (s - 1))) >> s; }
+
+typedef struct {
+    uint16_t quant4_mf[4][52][16], quant4_bias[4][52][16], quant8_mf[2][52][64], quant8_bias[2][52][64];
+    int32_t dequant4_mf[4][6][16], dequant8_mf[2][6][64];
+    int32_t quant4_mf6[4][6][16], quant8_mf6[2][6][64];   /* the unshifted multipliers x264hip_unquant_table starts from */
+} cqm_tables;
+
+static void cqm_init_flat(cqm_tables *t)
+{
+    const int deadzone[4] = {32 - 11, 32 - 21, 32 - 11, 32 - 21};     /* luma_deadzone {21, 11}: intra Y, inter Y, intra C, inter C */
+    for (int q = 0; q < 6; q++) {
+        for (int l = 0; l < 4; l++)
+            for (int i = 0; i < 16; i++) {
+                const int j = (i & 1) + ((i >> 2) & 1);
+                t->dequant4_mf[l][q][i] = dequant4_scale[q][j] * 16;
+                t->quant4_mf6[l][q][i] = div_round(quant4_scale[q][j] * 16, 16);
+            }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 64; i++) {
+                const int j = quant8_scan[((i >> 1) & 12) | (i & 3)];
+                t->dequant8_mf[l][q][i] = dequant8_scale[q][j] * 16;
+                t->quant8_mf6[l][q][i] = div_round(quant8_scale[q][j] * 16, 16);
+            }
+    }
+    for (int q = 0; q < 52; q++) {
+        for (int l = 0; l < 4; l++)
+            for (int i = 0; i < 16; i++) {
+                const int j = shift_round(t->quant4_mf6[l][q % 6][i], q / 6 - 1), b = div_round(deadzone[l] << 10, j), m = (1 << 15) / j;
+                t->quant4_mf[l][q][i] = (uint16_t)j;
+                t->quant4_bias[l][q][i] = (uint16_t)(b < m ? b : m);
+            }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 64; i++) {
+                const int j = shift_round(t->quant8_mf6[l][q % 6][i], q / 6), b = div_round(deadzone[l] << 10, j), m = (1 << 15) / j;
+                t->quant8_mf[l][q][i] = (uint16_t)j;
+                t->quant8_bias[l][q][i] = (uint16_t)(b < m ? b : m);
+            }
+    }
+}
+
+static void *to_device(const void *host, size_t bytes)
+{
+    void *d = x264hip_malloc(bytes);
+    if (!d || x264hip_memcpy_h2d(d, host, bytes) != 0) { fprintf(stderr, "device upload: %s\n", x264hip_last_error()); exit(1); }
+    return d;
+}
+static int clip3(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+typedef struct { x264hip_picture pic; x264hip_mb_state st; int poc, used; } dpb_entry;
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s in.yuv width height frames out.bin [bframes]\n", argv[0]); return 2; }
+    const int width = atoi(argv[2]), height = atoi(argv[3]), frames = atoi(argv[4]), bframes = argc > 6 ? atoi(argv[6]) : 0;
+    FILE *in = fopen(argv[1], "rb"), *out = fopen(argv[5], "wb");
+    if (!in || !out) { perror("open"); return 1; }
+
+    x264hip_cfg cfg = {0, 0};
+    CHECK(x264hip_init(&cfg));
+    x264hip_frame_dims dims;
+    memset(&dims, 0, sizeof(dims));
+    dims.width = width; dims.height = height; dims.batch = 1;
+    x264hip_frame_ctx *ctx = x264hip_frame_ctx_new(&dims, NULL);
+    if (!ctx) { fprintf(stderr, "frame_ctx_new: %s\n", x264hip_last_error()); return 1; }
+    const int n_mb = dims.mb_w * dims.mb_h;
+
+    /* ---- tables (x264_encoder_open: x264_cqm_init, x264_analyse_init_costs) ---- */
+    cqm_tables *t = malloc(sizeof(*t));
+    cqm_init_flat(t);
+    uint16_t *d_q4mf = to_device(t->quant4_mf, sizeof(t->quant4_mf)), *d_q4b = to_device(t->quant4_bias, sizeof(t->quant4_bias));
+    uint16_t *d_q8mf = to_device(t->quant8_mf, sizeof(t->quant8_mf)), *d_q8b = to_device(t->quant8_bias, sizeof(t->quant8_bias));
+    int32_t *d_dq4 = to_device(t->dequant4_mf, sizeof(t->dequant4_mf)), *d_dq8 = to_device(t->dequant8_mf, sizeof(t->dequant8_mf));
+    int32_t *unq4 = malloc(sizeof(int32_t) * 4 * 52 * 16), *unq8 = malloc(sizeof(int32_t) * 2 * 52 * 64);
+    x264hip_unquant_table(&t->quant4_mf6[0][0][0], 4, 16, unq4);
+    x264hip_unquant_table(&t->quant8_mf6[0][0][0], 2, 64, unq8);
+    int32_t *d_unq4 = to_device(unq4, sizeof(int32_t) * 4 * 52 * 16), *d_unq8 = to_device(unq8, sizeof(int32_t) * 2 * 52 * 64);
+    const size_t cost_n = 2 * COST_SPAN + 1;
+    int16_t *cost_all = malloc(sizeof(int16_t) * 52 * cost_n);
+    for (int q = 0; q < 52; q++) x264hip_cost_mv_table(lambda_tab[q], COST_SPAN, cost_all + q * cost_n);
+    int16_t *d_cost_all = to_device(cost_all, sizeof(int16_t) * 52 * cost_n);
+
+    /* ---- per-frame buffers ---- */
+    const int payload_cap = n_mb * 800 + 4096 + X264HIP_PAYLOAD_LEAD;
+    uint8_t *d_payload = x264hip_malloc((size_t)payload_cap), *payload = malloc((size_t)payload_cap);
+    int32_t *d_len = x264hip_malloc(sizeof(int32_t)), *d_energy = x264hip_malloc(sizeof(int32_t) * n_mb);
+    float *d_aq = x264hip_malloc(sizeof(float) * n_mb);
+    x264hip_picture fenc;
+    CHECK(x264hip_picture_alloc_source(ctx, &fenc));
+    const int dpb_size = bframes ? (MAX_REFS > 2 ? MAX_REFS : 2) : MAX_REFS;         /* sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200 */
+    dpb_entry pool[MAX_REFS + 2];
+    memset(pool, 0, sizeof(pool));
+    for (int i = 0; i < dpb_size + 1; i++) { CHECK(x264hip_picture_alloc(ctx, &pool[i].pic)); CHECK(x264hip_mb_state_alloc(ctx, &pool[i].st)); }
+    dpb_entry bslot;                              /* a B frame is neither filtered nor kept */
+    memset(&bslot, 0, sizeof(bslot));
+    if (bframes) { CHECK(x264hip_picture_alloc_source(ctx, &bslot.pic)); CHECK(x264hip_mb_state_alloc(ctx, &bslot.st)); }
+
+    /* ---- the frame order of a fixed B pattern (x264_slicetype_decide without b-adapt + x264_encoder_encode's reordering) ---- */
+    int *disp = malloc(sizeof(int) * frames), *stype = malloc(sizeof(int) * frames), n = 0;
+    for (int f = 0; f < frames;) {
+        if (f == 0) { disp[n] = 0; stype[n++] = 2; f++; continue; }
+        int anchor = f + bframes < frames - 1 ? f + bframes : frames - 1;
+        disp[n] = anchor; stype[n++] = 0;
+        for (int b = f; b < anchor; b++) { disp[n] = b; stype[n++] = 1; }
+        f = anchor + 1;
+    }
+
+    const size_t ysz = (size_t)width * height, csz = ysz / 4;
+    uint8_t *yuv = malloc(ysz + 2 * csz);
+    const int psy_rd_fix8 = 256;                  /* FIX8(1.0) */
+    const int chroma_qp_offset = clip3(0 - 2, -12, 12);      /* psy-rd >= 0.25 lowers it by 2 (R/encoder/encoder.c:509-514) */
+    const int qp_i = clip3((int)(QP - 6.0 * log((double)1.4f) / log(2.0) + 0.5), 0, 51);     /* rc->qp_constant[], R/encoder/ratecontrol.c:369-372 */
+    const int qp_b = clip3((int)(QP + 6.0 * log((double)1.3f) / log(2.0) + 0.5), 0, 51);
+
+    for (int k = 0; k < frames; k++) {
+        const int is_i = stype[k] == 2, is_b = stype[k] == 1, poc = 2 * disp[k], qp = is_i ? qp_i : is_b ? qp_b : QP;
+        if (fseek(in, (long)((ysz + 2 * csz) * (size_t)disp[k]), SEEK_SET) != 0 || fread(yuv, 1, ysz + 2 * csz, in) != ysz + 2 * csz) { fprintf(stderr, "short read\n"); return 1; }
+        CHECK(x264hip_picture_upload(ctx, &fenc, yuv, width, yuv + ysz, width / 2, yuv + ysz + csz, width / 2));
+        if (is_i) for (int i = 0; i < dpb_size + 1; i++) pool[i].used = 0;
+        /* x264_reference_build_list (R/encoder/encoder.c:911-981): list 0 = earlier pictures, nearest first; list 1 = the next anchor */
+        const x264hip_picture *l0[MAX_REFS];
+        dpb_entry *e0[MAX_REFS], *e1 = NULL;
+        int n0 = 0;
+        for (;;) {
+            dpb_entry *best = NULL;
+            for (int i = 0; i < dpb_size + 1; i++) {
+                dpb_entry *e = &pool[i];
+                int taken = 0;
+                for (int j = 0; j < n0; j++) taken |= e0[j] == e;
+                if (e->used && e->poc < poc && !taken && (!best || e->poc > best->poc)) best = e;
+            }
+            if (!best || n0 == MAX_REFS) break;
+            e0[n0] = best; l0[n0++] = &best->pic;
+        }
+        if (is_b) for (int i = 0; i < dpb_size + 1; i++) if (pool[i].used && pool[i].poc > poc && (!e1 || pool[i].poc < e1->poc)) e1 = &pool[i];
+        dpb_entry *cur = &bslot;
+        if (!is_b) { cur = NULL; for (int i = 0; i < dpb_size + 1 && !cur; i++) if (!pool[i].used) cur = &pool[i]; }
+
+        CHECK(x264hip_adaptive_quant_frame(ctx, &fenc, 1.0f, d_energy, d_aq));           /* x264_adaptive_quant_frame, R/encoder/encoder.c:1421 */
+        x264hip_slice_rd rd;
+        memset(&rd, 0, sizeof(rd));
+        rd.trellis = 1; rd.psy_rd = psy_rd_fix8; rd.write = 1; rd.i_frame = k; rd.qp_min = 0; rd.qp_max = 51; rd.f_qpm = (float)qp;
+        rd.aq_offset = d_aq; rd.cost_mv_all = d_cost_all; rd.unquant4_mf = d_unq4; rd.unquant8_mf = d_unq8;
+        rd.payload = d_payload; rd.payload_cap = payload_cap; rd.payload_len = d_len;
+        x264hip_slice_b sb;
+        memset(&sb, 0, sizeof(sb));
+        x264hip_slice_params p;
+        memset(&p, 0, sizeof(p));
+        p.slice_type = stype[k]; p.qp = qp; p.chroma_qp_offset = chroma_qp_offset;
+        p.me_method = 1; p.me_range = 16; p.subme = 7; p.chroma_me = 1; p.mv_range = 512;
+        p.fast_pskip = 1; p.dct_decimate = 1; p.cabac = 1; p.transform8x8 = 1;
+        p.analyse_inter = 0x113; p.analyse_intra = 0x3;          /* I4x4 | I8x8 | PSUB16x16 | BSUB16x16 */
+        p.quant4_mf = d_q4mf; p.quant4_bias = d_q4b; p.quant8_mf = d_q8mf; p.quant8_bias = d_q8b; p.dequant4_mf = d_dq4; p.dequant8_mf = d_dq8;
+        p.cost_mv = d_cost_all + (size_t)qp * cost_n; p.cost_mv_range = COST_SPAN;
+        p.poc = poc; p.mixed_refs = 1; p.rd = &rd;
+        for (int i = 0; i < n0; i++) p.ref_poc[i] = e0[i]->poc;
+        if (is_b) { sb.fref1 = &e1->pic; sb.l1_state = &e1->st; sb.ref1_poc = e1->poc; sb.weightb = 1; sb.direct_spatial = 1; p.b = &sb; }
+        CHECK(x264hip_slice_sweep_frame(ctx, &fenc, n0 ? l0 : NULL, n0, &cur->pic, &p, n0 ? &e0[0]->st : NULL, &cur->st));
+        CHECK(x264hip_slice_sweep_status(ctx, &cur->st));
+
+        int32_t len = 0;
+        CHECK(x264hip_memcpy_d2h(&len, d_len, sizeof(len)));
+        CHECK(x264hip_memcpy_d2h(payload, d_payload, (size_t)X264HIP_PAYLOAD_LEAD + (size_t)len));
+        const int32_t head[3] = {disp[k], stype[k], len};
+        fwrite(head, sizeof(head), 1, out);
+        fwrite(payload + X264HIP_PAYLOAD_LEAD, 1, (size_t)len, out);
+
+        if (!is_b) {                              /* x264_fdec_filter_row, then x264_reference_update (R/encoder/encoder.c:983-1068) */
+            x264hip_deblock_params dp;
+            memset(&dp, 0, sizeof(dp));
+            dp.mb_type = (const uint8_t *)cur->st.mb_type; dp.qp = (const uint8_t *)cur->st.qp; dp.nnz = cur->st.nnz; dp.transform8x8 = (const uint8_t *)cur->st.t8;
+            dp.mv = cur->st.mv; dp.ref = cur->st.ref;
+            dp.chroma_qp_offset = chroma_qp_offset; dp.state_layout = 1;
+            CHECK(x264hip_deblock_frame(ctx, &cur->pic, &dp));
+            CHECK(x264hip_expand_border(ctx, &cur->pic, 0));
+            CHECK(x264hip_hpel_filter_frame(ctx, &cur->pic));
+            cur->used = 1; cur->poc = poc;
+            int held = 0;
+            for (int i = 0; i < dpb_size + 1; i++) held += pool[i].used;
+            while (held > dpb_size) {             /* the oldest picture leaves the DPB */
+                dpb_entry *old = NULL;
+                for (int i = 0; i < dpb_size + 1; i++) if (pool[i].used && (!old || pool[i].poc < old->poc)) old = &pool[i];
+                old->used = 0; held--;
+            }
+        }
+        fprintf(stderr, "frame %d (display %d, %c, qp %d): %d bytes\n", k, disp[k], "PBI"[stype[k]], qp, (int)len);
+    }
+    CHECK(x264hip_sync(ctx));
+    fclose(out); fclose(in);
+    x264hip_frame_ctx_delete(ctx);
+    x264hip_shutdown();
+    return 0;
+}

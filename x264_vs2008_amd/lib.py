@@ -29,6 +29,15 @@ def build(verbose=False):
     return SO_PATH
 
 
+def build_examples():
+    """examples/encode_chain: a C99 program that drives the slice level through include/x264hip.h (gcc, no HIP headers)."""
+    root = os.path.dirname(_HERE)
+    exe = os.path.join(root, "examples", "encode_chain")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "encode_chain.c"),
+                           "-o", exe, "-L" + _HERE, "-lx264hip", "-lm", "-Wl,-rpath,$ORIGIN/../x264_vs2008_amd"])
+    return exe
+
+
 def open_library():
     """dlopen only (no device needed): used to check exported symbols."""
     if not os.path.exists(SO_PATH):

@@ -163,6 +163,11 @@ def main():
     if args.bframes:
         args.inter |= 0x100                          # X264_ANALYSE_BSUB16x16: the medium preset's b8x8
 
+    # stdout carries ONE line, the JSON: everything else any library prints there (gloo announces its connections on stdout) goes
+    # to stderr -- file descriptor 1 points at stderr until the result is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -332,7 +337,8 @@ def main():
         }
         if world == 1 and not args.no_cpu and args.cpu_frames > 0:
             line["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     enc.close()
     if dist is not None:
         dist.destroy_process_group()

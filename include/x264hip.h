@@ -246,6 +246,8 @@ typedef struct {
     int16_t *mvr1;         /* [n][2] */
     int16_t *mvd1;         /* [n][16][2] */
     uint8_t *skipbp;       /* [n] */
+    int ref_poc[8];        /* fdec->ref_poc[0][]: the POCs of the list-0 pictures this frame was coded from, filled by the sweep (a later B
+                              frame's temporal direct prediction maps its co-located references through them, h->mb.map_col_to_list0) */
 } x264hip_mb_state;
 
 /* ---- round 2: the raster-order variant of the sweep ------------------------------------------------
@@ -273,6 +275,12 @@ typedef struct x264hip_slice_rd {
     int payload_cap;
     int32_t *payload_len;          /* device [batch] */
     int32_t *mb_bits;              /* optional device [batch][n_mb]: x264_cabac_pos after every macroblock */
+    int16_t *stale;                /* device [batch][8] (zero before a chain's first frame), or NULL: the h->mb.cache.ref / mv entry of block 12 of
+                                      both lists {ref0, mvx0, mvy0, ref1, mvx1, mvy1}.  x264_macroblock_cache_load never rewrites the cache's inner
+                                      entries, so this one survives from macroblock to macroblock and from frame to frame, and a B macroblock whose
+                                      TEMPORAL direct prediction fails (a co-located reference outside list 0) offers it to its 16x16 searches as the
+                                      "direct" candidate (x264_mb_predict_mv_ref16x16, R/common/macroblock.c:376-386).  Every sweep of a chain that
+                                      uses temporal direct prediction reads and updates it; without it temporal direct is refused */
     int i_frame_stride;            /* chain b of the batch has coded i_frame + b * i_frame_stride frames before this one: the chains of a
                                       launch may be the closed GOPs of ONE stream (GOP g starts keyint frames after GOP g - 1), see
                                       x264_vs2008_amd/shard.py.  0: every chain counts alike */
@@ -315,7 +323,7 @@ typedef struct x264hip_slice_b {
     const x264hip_mb_state *l1_state;    /* the state it was coded with: mb_type / ref / mv of the co-located macroblocks (x264_mb_predict_mv_direct16x16) */
     int ref1_poc;                        /* h->fref1[0]->i_poc (x264_macroblock_bipred_init, R/common/macroblock.c:1374-1408) */
     int weightb;                         /* param.analyse.b_weighted_bipred */
-    int direct_spatial;                  /* sh.b_direct_spatial_mv_pred; 0 (temporal) is refused for now */
+    int direct_spatial;                  /* sh.b_direct_spatial_mv_pred; 0 = temporal (R/common/macroblock.c:155-224): needs rd.stale in every sweep of the chain */
 } x264hip_slice_b;
 
 /* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:

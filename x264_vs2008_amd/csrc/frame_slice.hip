@@ -128,7 +128,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     const x264hip_slice_b *pb = is_b ? p->b : nullptr;
     if (is_b) {
         if (!pb || !pb->fref1 || !pb->l1_state || !p->rd) { set_error("slice_sweep: a B slice needs x264hip_slice_params.b (list 1) and .rd (the raster variant)"); return -1; }
-        if (!pb->direct_spatial) { set_error("slice_sweep: temporal direct prediction is not built in the kernel yet (spatial is)"); return -1; }
+        if (!pb->direct_spatial && !p->rd->stale) { set_error("slice_sweep: temporal direct prediction needs x264hip_slice_rd.stale (in every sweep of the chain)"); return -1; }
         if (p->subme < 2 || p->subme > 7 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 2..7 with the CABAC writer in the loop"); return -1; }
         if (p->noise_reduction || p->lossless) { set_error("slice_sweep: B slices with --nr / lossless are not built"); return -1; }
         if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
@@ -221,13 +221,20 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
                 const int tx = (16384 + (abs(td) >> 1)) / td;
                 dsf = (tb * tx + 32) >> 6; dsf = dsf < -1024 ? -1024 : dsf > 1023 ? 1023 : dsf;
             }
+            t.dsf[i] = dsf;                                            // h->mb.dist_scale_factor[i][0]
             dsf >>= 2;
             t.biw[i] = pb->weightb && dsf >= -64 && dsf <= 128 ? 64 - dsf : 32;
+        }
+        // h->mb.map_col_to_list0 (x264_macroblock_slice_init, R/common/macroblock.c:790-804): the co-located picture's list 0 by POC in ours
+        for (int i = 0; i < SW_MAX_REFS; i++) {
+            t.map_col[i] = -2;
+            if (i < pb->l1_state->n_ref0)
+                for (int j = 0; j < n_refs; j++) if (p->ref_poc[j] == pb->l1_state->ref_poc[i]) { t.map_col[i] = j; break; }
         }
     } else {
         for (int k = 0; k < 4; k++) t.y1[k] = t.y[0][k];
         t.u1 = t.u[0]; t.v1 = t.v[0];
-        for (int i = 0; i < SW_MAX_REFS; i++) t.biw[i] = 32;
+        for (int i = 0; i < SW_MAX_REFS; i++) { t.biw[i] = 32; t.dsf[i] = 256; t.map_col[i] = -2; }
     }
     HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
     static int wpe = 0;
@@ -246,7 +253,9 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         r.unq4 = prd->unquant4_mf; r.unq8 = prd->unquant8_mf;
         r.payload = prd->payload; r.payload_cap = prd->payload_cap; r.payload_len = prd->payload_len; r.mb_bits = prd->mb_bits;
         r.mvd = out->mvd;
+        r.stale = prd->stale;
         if (is_b) {
+            r.direct_temporal = !pb->direct_spatial;
             r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
             x264hip_launch_slice_b(a, t, r, c->stream);
@@ -266,7 +275,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
                            (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
     HIPCHK(hipGetLastError());
     // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
-    out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;     /* (a B frame's state is never read by later frames) */
+    out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;
+    for (int i = 0; i < 8; i++) out->ref_poc[i] = i < n_refs ? p->ref_poc[i] : 0;     /* (a B frame's state is never read by later frames) */
     for (int i = 0; i < SW_MAX_REFS; i++) {
         int delta = i < n_refs && is_p ? p->poc - p->ref_poc[i] : 0;
         out->inv_ref_poc[i] = delta ? (256 + delta / 2) / delta : 0;

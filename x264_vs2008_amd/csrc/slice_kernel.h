@@ -61,6 +61,7 @@ struct SwRefs {
     // B slices: the list-1 picture (x264 core 66 without b-pyramid has one) and h->mb.bipred_weight[list-0 reference][0]
     const u8 *y1[4], *u1, *v1;
     int biw[SW_MAX_REFS];
+    int dsf[SW_MAX_REFS], map_col[SW_MAX_REFS];     // temporal direct: h->mb.dist_scale_factor[i][0], h->mb.map_col_to_list0[i]
 };
 struct SwArgs {
     int mb_w, mb_h, sy, sc, batch, batch_pad;
@@ -156,6 +157,8 @@ struct SwRd {                       // kernel argument
     u8 *skipbp;
     const signed char *col_type, *col_ref;
     const i16 *col_mv;
+    int direct_temporal;            // !sh.b_direct_spatial_mv_pred
+    i16 *stale;                     // [batch][8]: the cache entry of block 12 that survives macroblocks and frames (x264hip_slice_rd.stale)
 };
 // what a B slice adds to the wavefront's LDS: list 1 of the motion caches, the direct prediction, the analysis records
 struct SwLdsB {

@@ -11,7 +11,7 @@ from oracle.gen_golden_slice import CASES2, case_inputs
 from x264_vs2008_amd import slice as sl
 
 pytestmark = pytest.mark.gpu
-B_CASES = [c for c in CASES2 if c[5].get("bframes") and c[5].get("direct_pred", 1) == 1]      # temporal direct: the twin only, for now
+B_CASES = [c for c in CASES2 if c[5].get("bframes")]      # spatial and temporal direct prediction
 STATE = ["mb_type", "partition", "sub_partition", "ref", "mv", "i4mode", "i16mode", "chroma_mode", "qp", "cbp", "t8", "nnz", "luma", "luma_dc", "chroma_dc", "chroma_ac"]
 
 
@@ -60,10 +60,13 @@ def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, fra
     finally:
         enc.close()
     t = gold["mb_type"]
-    assert (t == 18).any() and (t == 16).any() and (t == 17).any()
+    assert (t == 16).any() and (t == 17).any() and ((t == 18).any() or gold["frame_info"][:, 1].min() < 26)      # B_BI_BI, B_8x8, B_SKIP (none at the low-QP case)
 
 
-@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", B_CASES[:2], ids=[c[0] for c in B_CASES[:2]])
+LANE_CASES = [c for c in B_CASES if c[5].get("direct_pred", 1) == 1][:2]      # (temporal direct prediction chains the frames: no lanes)
+
+
+@pytest.mark.parametrize("name,size,frames,kind,kw,ekw", LANE_CASES, ids=[c[0] for c in LANE_CASES])
 def test_b_frames_on_lanes_run_beside_the_next_anchor(hip_lib, cqm, name, size, frames, kind, kw, ekw):
     """lanes = 3: every B frame on a stream of its own, ordered by events only (no host synchronisation until the clip is
     enqueued).  The frames still resident at the end -- the last anchor and the B frames after it -- match the reference."""

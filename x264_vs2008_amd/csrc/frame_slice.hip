@@ -5,6 +5,7 @@
 
 void x264hip_launch_slice_rd(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_b(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
+void x264hip_launch_slice_bt(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 
 // b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
 // knowing it (it could not change their type) recorded the statistics term for the other answer in cost_alt.
@@ -258,7 +259,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
             r.direct_temporal = !pb->direct_spatial;
             r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
-            x264hip_launch_slice_b(a, t, r, c->stream);
+            if (r.direct_temporal) x264hip_launch_slice_bt(a, t, r, c->stream); else x264hip_launch_slice_b(a, t, r, c->stream);
         } else
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {

@@ -35,6 +35,10 @@
         sr.cref[lane] = -2; sr.cmv[lane][0] = 0; sr.cmv[lane][1] = 0; sb.cref1[lane] = -2; sb.cmv1[lane][0] = 0; sb.cmv1[lane][1] = 0;
         sb.cskip[lane] = 0; sb.cmvd1[lane][0] = 0; sb.cmvd1[lane][1] = 0;
     }
+    if (TD && lane == 30) {         // ... except the entry of block 12, which the reference's cache keeps from the previous macroblock (SwRd::stale)
+        sr.cref[30] = (signed char)sb.stale[0]; sr.cmv[30][0] = sb.stale[1]; sr.cmv[30][1] = sb.stale[2];
+        sb.cref1[30] = (signed char)sb.stale[3]; sb.cmv1[30][0] = sb.stale[4]; sb.cmv1[30][1] = sb.stale[5];
+    }
     WAVE_SYNC();
     {
         const signed char *r0 = a.ref, *r1 = rd.ref1 + cb4;
@@ -274,6 +278,7 @@
     // ================================================================== the macroblock ====
     enum { BS_PRE, BS_CAND, BS_AFTER_EARLY, BS_AN2, BS_SELECT, BS_T8, BS_I16, BS_I4, BS_I8, BS_FINAL };
     int bstep = BS_PRE, kcand = 0, pass = 0, bthresh = 0, bskip_cost = MX_COST_MAX;
+    bool direct_ok = true;          // x264_mb_predict_mv_direct16x16's return value: temporal prediction fails when a co-located reference is not in list 0
     int i_type_b = T_B_L0_L0, i_part_b = 16, i_cost_b = MX_COST_MAX, i_satd_inter_b = 0;
 #pragma nounroll
     for (;;) {
@@ -281,6 +286,23 @@
         if (bstep == BS_PRE) {
             cache_fenc_satd();
             type = T_B_SKIP;
+            if constexpr (TD) {
+                // ---- x264_mb_predict_mv_direct16x16, temporal (R/common/macroblock.c:155-224; direct_8x8_inference: the corner blocks) ----
+                const int type_col = UNI((rd.col_type + cb)[mb]);
+                cache_set_b(1, 0, 0, 4, 4, 0, 0, 0, 1, 0);
+                if (IS_INTRA_T(type_col)) { cache_set_b(0, 0, 0, 4, 4, 0, 0, 0, 1, 1); cache_set_b(1, 0, 0, 4, 4, 0, 0, 0, 0, 1); }
+                else
+                    for (int i8 = 0; i8 < 4; i8++) {
+                        const int x8 = i8 & 1, y8 = i8 >> 1, cr = UNI((rd.col_ref + cb4)[mb * 4 + i8]);
+                        const int i_ref = cr < 0 ? cr : refs.map_col[cr];
+                        if (i_ref < 0) { direct_ok = false; break; }           // (what was written so far stays, as in the reference)
+                        const i16 *mvcol = rd.col_mv + cb32 + ((size_t)mb * 16 + 3 * x8 + 12 * y8) * 2;
+                        const int cx0 = UNI(mvcol[0]), cy0 = UNI(mvcol[1]), dsf = refs.dsf[i_ref];
+                        const int l0x = (dsf * cx0 + 128) >> 8, l0y = (dsf * cy0 + 128) >> 8;
+                        cache_set_b(0, 2 * x8, 2 * y8, 2, 2, i_ref, (i16)l0x, (i16)l0y, 1, 1);
+                        cache_set_b(1, 2 * x8, 2 * y8, 2, 2, 0, (i16)(l0x - cx0), (i16)(l0y - cy0), 0, 1);
+                    }
+            } else {
             // ---- x264_mb_predict_mv_direct16x16, spatial (R/common/macroblock.c:226-309) ----
             auto dref_of = [&](int l) -> int {
                 const int ra = CREF(l, 11), rb = CREF(l, 4);
@@ -312,27 +334,32 @@
                         }
                     }
             }
+            }
             WAVE_SYNC();
-            if (lane < 16) {
+            if (direct_ok && lane < 16) {
                 const int k = 12 + (lane & 3) + 8 * (lane >> 2);
                 sb.dmv[0][lane][0] = sr.cmv[k][0]; sb.dmv[0][lane][1] = sr.cmv[k][1]; sb.dmv[1][lane][0] = sb.cmv1[k][0]; sb.dmv[1][lane][1] = sb.cmv1[k][1];
             }
-            if (lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); sb.dref[0][lane] = sr.cref[k]; sb.dref[1][lane] = sb.cref1[k]; }
-            finals_from_cache();
-            mc_b();
-            bool b_skip;
-            if (mbrd) { bskip_cost = ssd_mb(); b_skip = bskip_cost <= ((6 * Q.lambda2 + 128) >> 8); }      // "6 = minimum cavlc cost of a non-skipped MB"
-            else b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;   // x264_macroblock_probe_bskip
+            if (direct_ok && lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); sb.dref[0][lane] = sr.cref[k]; sb.dref[1][lane] = sb.cref1[k]; }
+            bool b_skip = false;
+            if (direct_ok) {
+                finals_from_cache();
+                mc_b();
+                if (mbrd) { bskip_cost = ssd_mb(); b_skip = bskip_cost <= ((6 * Q.lambda2 + 128) >> 8); }      // "6 = minimum cavlc cost of a non-skipped MB"
+                else b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;   // x264_macroblock_probe_bskip
+            }
             if (b_skip) { skip_mc = 1; fin = true; }
             else {
                 skip_mc = 0;
                 // ---- x264_mb_analyse_inter_direct: the direct prediction is in fdec ----
-                cost16direct = Q.lambda * 1;
-                for (int i = 0; i < 4; i++) {
-                    const int c8d = satd_region(s.fd + FDY, FD, 8 * (i & 1), 8 * (i >> 1), 8, 8);
-                    cost16direct += c8d;
-                    if (lane == 0) sb.cost8direct[i] = c8d + Q.lambda * 1;
-                }
+                if (direct_ok) {
+                    cost16direct = Q.lambda * 1;
+                    for (int i = 0; i < 4; i++) {
+                        const int c8d = satd_region(s.fd + FDY, FD, 8 * (i & 1), 8 * (i >> 1), 8, 8);
+                        cost16direct += c8d;
+                        if (lane == 0) sb.cost8direct[i] = c8d + Q.lambda * 1;
+                    }
+                } else if (lane < 4) sb.cost8direct[lane] = MX_COST_MAX;
                 // ---- x264_mb_analyse_inter_b16x16 ----
                 for (int l = 0; l < 2; l++) {
                     const int n = l ? 1 : a.n_refs;
@@ -395,7 +422,7 @@
             }
         } else if (bstep == BS_CAND) {                          // x264_mb_analyse_b_rd: the next candidate within the threshold
             for (; kcand < 7; kcand++) {
-                const bool ok = kcand == 0 ? rd_direct == MX_COST_MAX
+                const bool ok = kcand == 0 ? (direct_ok && rd_direct == MX_COST_MAX)
                               : kcand == 1 ? (ME(0, 0, 2) <= bthresh && rd_l0 == MX_COST_MAX) : kcand == 2 ? (ME(1, 0, 2) <= bthresh && rd_l1 == MX_COST_MAX)
                               : kcand == 3 ? (cost16bi <= bthresh && rd_bi == MX_COST_MAX) : kcand == 4 ? (cost8bi <= bthresh && rd_8 == MX_COST_MAX)
                               : kcand == 5 ? (cost16x8bi <= bthresh && rd_168 == MX_COST_MAX) : (cost8x16bi <= bthresh && rd_816 == MX_COST_MAX);
@@ -614,5 +641,10 @@
         } else if (bstep == BS_I16) { satd_i16 = cst; bstep = BS_I4; }
         else if (bstep == BS_I4) { satd_i4 = cst; bstep = BS_I8; }
         else { satd_i8 = cst; bstep = BS_FINAL; }
+    }
+    // the cache entry of block 12 as this macroblock leaves it: the next one inherits it (SwRd::stale)
+    if (TD && lane == 30) {         // (lane 30 is the only writer of entry 30: cache_set_b)
+        sb.stale[0] = sr.cref[30]; sb.stale[1] = sr.cmv[30][0]; sb.stale[2] = sr.cmv[30][1];
+        sb.stale[3] = sb.cref1[30]; sb.stale[4] = sb.cmv1[30][0]; sb.stale[5] = sb.cmv1[30][1];
     }
 }

@@ -171,6 +171,7 @@ struct SwLdsB {
     i16 left_mv4_1[4][2], left_mvd1[4][2], left_mvr1[2];
     signed char left_r8_1[2];
     u8 left_skipbp;
+    i16 stale[6];                       // SwRd::stale while the slice is coded: {ref, mv x, mv y} of cache entry 30, list 0 | list 1
     int me[2][9][6];                    // x264_me_t records of a->l0 / a->l1: [list][me16x16, me8x8 x 4, me16x8 x 2, me8x16 x 2][mv x, y, cost, cost_mv, mvp x, y]
     int cost8direct[4];
 };
@@ -1270,10 +1271,11 @@ static __device__ const int d_lambda2_tab[52] = {14, 18, 22, 28, 36, 45, 57, 72,
 static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
                                               29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
-template <int WPE, bool LL = false, bool RD = false, bool BS = false>
+template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false>       // TD: a B slice with temporal direct prediction
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
 {
     static_assert(!BS || RD, "B slices run in the raster variant");
+    static_assert(!TD || BS, "temporal direct prediction is a B-slice matter");
 #undef IS_SKIP_T
 #define IS_SKIP_T(t) (BS ? ((t) == T_P_SKIP || (t) == T_B_SKIP) : (t) == T_P_SKIP)      /* BS is a template constant: the other kernels keep their single compare */
     __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
@@ -1325,6 +1327,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
     // the entropy coder of this chain's slice (x264_slice_write, R/encoder/encoder.c:1155-1165)
     DCabac cab = {0, 0x1FE, -1, 0, nullptr, 0};
+    // h->mb.cache.ref / mv [list][x264_scan8[12]] as the previous macroblock (or frame) left it: x264_macroblock_cache_load never rewrites
+    // the cache's inner entries (SwRd::stale; only a B macroblock whose temporal direct prediction fails ever looks at it)
+    int st0r = 0, st0x = 0, st0y = 0, st1r = 0, st1x = 0, st1y = 0;
+    if constexpr (RD) {
+        if (rd.stale) {
+            const i16 *sp = rd.stale + (size_t)bz * 8;
+            st0r = __builtin_amdgcn_readfirstlane(sp[0]); st0x = __builtin_amdgcn_readfirstlane(sp[1]); st0y = __builtin_amdgcn_readfirstlane(sp[2]);
+            st1r = __builtin_amdgcn_readfirstlane(sp[3]); st1x = __builtin_amdgcn_readfirstlane(sp[4]); st1y = __builtin_amdgcn_readfirstlane(sp[5]);
+        }
+        if constexpr (TD) {         // the B flow keeps it in LDS (slice_b_flow.h)
+            if (lane == 30) { sb.stale[0] = (i16)st0r; sb.stale[1] = (i16)st0x; sb.stale[2] = (i16)st0y; sb.stale[3] = (i16)st1r; sb.stale[4] = (i16)st1x; sb.stale[5] = (i16)st1y; }
+        }
+    }
     u8 *payload0 = nullptr;
     int last_qp = a.qp, last_dqp = 0, prev_coded = 0, intra_before = 0;      // h->mb.i_last_qp / i_last_dqp; the previous macroblock "has coefficients"
     if constexpr (RD) {
@@ -1900,6 +1915,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     cref_v = s.left_r8[i >> 1]; cmvx_v = s.left_mv4[i][0]; cmvy_v = s.left_mv4[i][1];
                 }
             }
+            if constexpr (RD) { if (is_p && lane == 30) { cref_v = st0r; cmvx_v = st0x; cmvy_v = st0y; } }      // the entry cache_load does not rewrite
             if constexpr (RD) {     // the neighbours' part of the motion cache, for the entropy coder's x264_mb_predict_mv / ref contexts
                 if (is_p) {
                     if (lane < 48) { sr.cref[lane] = (signed char)cref_v; sr.cmv[lane][0] = (i16)cmvx_v; sr.cmv[lane][1] = (i16)cmvy_v; }
@@ -2259,6 +2275,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             if (part == 16) { vx = me16x; vy = me16y; vr = me16r; }
                             if (lane < 16) { s.mv4[lane][0] = (i16)vx; s.mv4[lane][1] = (i16)vy; }
                             if (lane < 4) s.ref8[lane] = (signed char)vr;
+                            {   // the motion cache's copy of block 12 (raster block 10, 8x8 block 3) follows the candidate
+                                const int nx = __shfl(vx, 10, 64), ny = __shfl(vy, 10, 64), nr = __shfl(vr, 3, 64);
+                                if (lane == 30) { cref_v = nr; cmvx_v = nx; cmvy_v = ny; }
+                            }
                             mvx = me16x; mvy = me16y; ref = me16r;
                             WAVE_SYNC();
                         };
@@ -2392,6 +2412,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             else satd_i8 = c;
                         }
                     }
+                }
+            }
+            if constexpr (RD) {     // what the next macroblock finds in the cache's entry of block 12 (oracle/slice_oracle.c: stale_ref)
+                if (is_p && rd.stale) {
+                    if (type == T_P_SKIP) { st0r = 0; st0x = pskx; st0y = psky; }
+                    else if (!IS_INTRA_T(type) && encoded) { st0r = UNI(s.ref8[3]); st0x = UNI(s.mv4[10][0]); st0y = UNI(s.mv4[10][1]); }
+                    else { st0r = __builtin_amdgcn_readlane(cref_v, 30); st0x = __builtin_amdgcn_readlane(cmvx_v, 30); st0y = __builtin_amdgcn_readlane(cmvy_v, 30); }
                 }
             }
         }
@@ -2560,6 +2587,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
   }   // rows
     if constexpr (RD) {     // x264_slice_write's end (R/encoder/encoder.c:1269-1273)
         if (rd.write && lane == 0) { cd_encode_flush(cab, rd.i_frame + bz * rd.i_frame_stride); rd.payload_len[bz] = (int)(cab.p - payload0); }
+        if constexpr (TD) {
+            if (rd.stale && lane == 30) { i16 *sp = rd.stale + (size_t)bz * 8; for (int k = 0; k < 6; k++) sp[k] = sb.stale[k]; }
+        } else if (!BS && rd.stale && is_p && lane == 0) {            // (an I slice never touches the motion cache)
+            i16 *sp = rd.stale + (size_t)bz * 8;
+            sp[0] = (i16)st0r; sp[1] = (i16)st0x; sp[2] = (i16)st0y;
+        }
     }
     if (a.nr) {
         if (lane >= 1 && lane < 16 && nr_acc4) atomicAdd(a.nr_sum + (size_t)bz * 128 + lane, (u32)nr_acc4);

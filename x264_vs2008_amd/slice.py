@@ -28,7 +28,8 @@ STATE_FIELDS = [("mb_type", np.int8, ()), ("partition", np.int8, ()), ("sub_part
 class MbState(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _, _ in STATE_FIELDS] + \
                [("progress", C.c_void_p), ("poc", C.c_int), ("n_ref0", C.c_int), ("inv_ref_poc", C.c_int * 8), ("mvd", C.c_void_p),
-                ("mv1", C.c_void_p), ("ref1", C.c_void_p), ("mvr1", C.c_void_p), ("mvd1", C.c_void_p), ("skipbp", C.c_void_p)]
+                ("mv1", C.c_void_p), ("ref1", C.c_void_p), ("mvr1", C.c_void_p), ("mvd1", C.c_void_p), ("skipbp", C.c_void_p),
+                ("ref_poc", C.c_int * 8)]
 
 
 class SliceB(C.Structure):
@@ -41,7 +42,7 @@ class SliceRd(C.Structure):
     _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_int), ("write", C.c_int), ("cabac_init_idc", C.c_int), ("i_frame", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("f_qpm", C.c_float), ("aq_offset", C.c_void_p), ("cost_mv_all", C.c_void_p),
                 ("unquant4_mf", C.c_void_p), ("unquant8_mf", C.c_void_p), ("payload", C.c_void_p), ("payload_cap", C.c_int),
-                ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p), ("i_frame_stride", C.c_int)]
+                ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p), ("stale", C.c_void_p), ("i_frame_stride", C.c_int)]
 
 
 PAYLOAD_LEAD = 64
@@ -166,6 +167,9 @@ class ChainEncoder:
             lib.x264hip_unquant_table(q8.ctypes.data_as(C.c_void_p), C.c_int(2), C.c_int(64), u8.ctypes.data_as(C.c_void_p))
             rb["unquant4_mf"] = DeviceArray(lib, u4.shape, np.int32, u4)
             rb["unquant8_mf"] = DeviceArray(lib, u8.shape, np.int32, u8)
+            # x264hip_slice_rd.stale: the motion-cache entry that survives macroblocks and frames (read when temporal direct prediction
+            # fails); one record per chain, zero like the reference's freshly allocated x264_t
+            rb["stale"] = DeviceArray(lib, (B, 8), np.int16)
             self.rd_bufs = rb
             self.payload_cap = cap
         self.i_frame, self.i_frame_stride = 0, 0      # shard.py sets both when the chains are the GOPs of one stream
@@ -187,6 +191,8 @@ class ChainEncoder:
         if lanes and bframes:
             if not self.raster:
                 raise ValueError("lanes: B frames run in the raster variant")
+            if direct_pred == 2:
+                raise ValueError("lanes: temporal direct prediction chains every frame to the one coded before it (x264hip_slice_rd.stale)")
             d = self.ctx.dims
             for _ in range(lanes):
                 lc = FrameCtx(lib, width, height, batch=batch)
@@ -294,6 +300,7 @@ class ChainEncoder:
                               qp_min=ro["qp_min"], qp_max=ro["qp_max"], f_qpm=float(qp), aq_offset=rb["aq_offset"].ptr if ro["aq_mode"] else None,
                               cost_mv_all=rb["cost_mv_all"].ptr, unquant4_mf=rb["unquant4_mf"].ptr, unquant8_mf=rb["unquant8_mf"].ptr,
                               payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
+                              stale=rb["stale"].ptr,
                               i_frame_stride=self.i_frame_stride)
             p.rd = C.addressof(self.rd)
         if is_b:

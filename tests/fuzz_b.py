@@ -1,0 +1,48 @@
+"""Seeded random I P B chains for the raster sweep: the configuration generator and the GPU-vs-twin comparison used by
+tests/test_gpu_fuzz_cases.py and scratch/fuzz_gpu_b.py.  The twin (oracle/) is the checker here, as in every parity test: it is pinned
+to the reference by the fixtures of tests/golden and by oracle/gen_golden_slice.py's live comparisons.  A noisy bottom-right corner
+makes a P frame's last macroblocks end intra (their analysis leftovers are what x264hip_slice_rd.stale carries into the next frame)."""
+import numpy as np
+
+from oracle import refslice as rs
+from oracle.gen_golden_slice import case_inputs
+from x264_vs2008_amd import slice as sl
+
+
+def config(i):
+    r = np.random.default_rng(7000 + i)
+    w, h = int(r.integers(5, 12)) * 16, int(r.integers(5, 9)) * 16
+    frames = int(r.integers(5, 10))
+    kw = dict(qp=int(r.integers(16, 40)), subme=int(r.choice([2, 4, 5, 6, 7, 7])), me_method=int(r.choice([0, 1, 1, 2])), me_range=16,
+              n_refs=int(r.integers(1, 4)), inter=int(r.choice([0x100, 0x110, 0x113, 0x113])), intra=int(r.choice([0x1, 0x3])),
+              transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=1, deblock=1, fast_pskip=int(r.integers(0, 2)),
+              dct_decimate=1, chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([0, 0, 6])))
+    if not kw["transform8x8"]:
+        kw["inter"] &= ~0x2; kw["intra"] &= ~0x2
+    ekw = dict(trellis=int(r.choice([0, 1, 2])), psy_rd=float(r.choice([0.0, 1.0])), aq_mode=int(r.integers(0, 2)), bframes=int(r.integers(1, 4)),
+               weightb=int(r.integers(0, 2)), direct_pred=int(r.choice([1, 2, 2])))
+    kind = "moving" if r.integers(0, 2) else "static"
+    y, u, v = case_inputs((w, h), frames, kind)
+    y = y.copy()
+    y[:, -24:, -40:] = np.random.default_rng(i).integers(0, 256, (frames, 24, 40), dtype=np.uint8)      # the last macroblocks: unpredictable
+    return w, h, frames, kind, kw, ekw, y, u, v
+
+
+def compare(hip, twin, cqm, i):
+    """-> (description, [frames whose payload differs], the twin's type of every frame's last macroblock)"""
+    w, h, frames, kind, kw, ekw, y, u, v = config(i)
+    want = rs.run2(twin, "x264o_encode_chain2", rs.make_params(w, h, frames, **kw), rs.make_ext(**ekw), y, u, v)
+    enc = sl.ChainEncoder(hip, w, h, cqm, batch=1, write=1, **kw, **ekw)
+    order = sl.coding_order(frames, kw["keyint"], ekw["bframes"])
+    diffs = []
+    try:
+        for f, (disp, stype) in enumerate(order):
+            enc.upload(y[disp], u[disp], v[disp])
+            enc.encode_frame(stype=stype, disp=disp)
+            enc.status()
+            if enc.payloads()[0] != bytes(want["payload"][f, :want["payload_len"][f]]):
+                diffs.append("f%d(%s d%d)" % (f, "PBI"[stype], disp))
+            enc.finish_frame()
+    finally:
+        enc.close()
+    return "%dx%d x%d %s %s %s" % (w, h, frames, kind, kw, ekw), diffs, [int(want["mb_type"][f, -1]) for f in range(frames)]

@@ -1,0 +1,20 @@
+"""Seeded random I P B chains (tests/fuzz_b.py) through the raster sweep against the CPU twin, payload bytes of every frame: the
+configurations that once differed (adaptive quantisation + a motion search reaching more than 64 pixels from its predictor read the
+SLICE QP's vector-cost table instead of the macroblock's: seeds 0 and 45) and a spread of B-slice options incl. temporal direct
+prediction with P frames whose last macroblocks end intra."""
+import ctypes as C
+import os
+
+import pytest
+
+from fuzz_b import compare
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [0, 45, 3, 7, 11, 19, 23, 58, 59, 101, 137])
+def test_random_chain_matches_twin(hip_lib, cqm, seed):
+    twin = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    what, diffs, _ = compare(hip_lib, twin, cqm, seed)
+    assert not diffs, "%s: payload differs in %s" % (what, diffs)

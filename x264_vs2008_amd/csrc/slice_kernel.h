@@ -1948,7 +1948,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 const MeLimits L = me_limits(mbx, mby, a.mb_w, a.mb_h, a.mv_range);
                 MxCtx c;
                 c.fe = (MX_LDS(u32))s.fe; c.fe_u = (MX_LDS(u8))(s.fe + 256); c.fe_v = (MX_LDS(u8))(s.fe + 320); c.sy = a.sy; c.sc = a.sc; c.lane = lane; c.set_block(16, 16, 0, 0);
-                c.cost_g = (MX_GLB(i16))(a.cost_mv + a.cost_center); c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true; c.patch = (MX_LDS(u8))s.patch; c.has_patch = true; c.patch_on = false;
+                c.cost_g = (MX_GLB(i16))cost_g;           // (the current macroblock's QP: with adaptive quantisation not the slice's)
+                c.cost_l = (MX_LDS(i16))s.costl; c.has_cost_l = true; c.patch = (MX_LDS(u8))s.patch; c.has_patch = true; c.patch_on = false;
                 int thresh = 0x7fffffff, best = 0x7fffffff, bmvpx = 0, bmvpy = 0;
                 bool early_skip = false;
                 for (int r = 0; r < (is_p ? a.n_refs : 0); r++) {

@@ -168,6 +168,8 @@ typedef struct {
     int f;
     /* --nr: h->nr_residual_sum / nr_count / nr_offset, [0] 4x4, [1] 8x8 (R/common/common.h:308-310) */
     int lossless;                            /* h->mb.b_lossless: constant QP 0 (R/encoder/encoder.c:401-421) */
+    int b_nr;                                /* h->mb.b_noise_reduction: 0 while a macroblock is analysed -- the RD levels' trial encodes neither denoise nor
+                                                count (analyse.c:237) -- param.analyse.i_noise_reduction != 0 for the final encode (:2769) */
     /* round 2: RD levels, trellis, the entropy coder, per-macroblock QP */
     const slice_ext *e;
     slice_out2 *o2;
@@ -588,9 +590,9 @@ static void enc_inter_luma(ssl *S, smb *m)
         i16 d8[4][8][8];
         b_decimate &= !S->b_trellis;                     /* "8x8 trellis is inherently optimal decimation", macroblock.c:630 */
         dctf.sub16x16_dct8(d8, m->fe[0], m->fd[0]);
-        if (S->p->noise_reduction && !S->lossless) S->nr_count[1] += 4;
+        if (S->b_nr && !S->lossless) S->nr_count[1] += 4;
         for (int idx = 0; idx < 4; idx++) {
-            if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
+            if (S->b_nr && !S->lossless) quantf.denoise_dct(&d8[idx][0][0], S->nr_sum[1], S->nr_offset[1], 64);   /* macroblock.c:636 */
             int nz = q8(S, d8[idx], 1, 0, S->qp);
             if (nz) {
                 zigf[0].scan_8x8(m->luma8[idx], d8[idx]);
@@ -615,11 +617,11 @@ static void enc_inter_luma(ssl *S, smb *m)
     } else {
         i16 d4[16][4][4];
         dctf.sub16x16_dct(d4, m->fe[0], m->fd[0]);
-        if (S->p->noise_reduction && !S->lossless) S->nr_count[0] += 16;
+        if (S->b_nr && !S->lossless) S->nr_count[0] += 16;
         for (int i8 = 0; i8 < 4; i8++) {
             int dec8 = 0, cbp = 0;
             for (int i4 = 0; i4 < 4; i4++) {
-                if (S->p->noise_reduction && !S->lossless) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
+                if (S->b_nr && !S->lossless) quantf.denoise_dct(&d4[4 * i8 + i4][0][0], S->nr_sum[0], S->nr_offset[0], 16);   /* macroblock.c:694 */
                 int idx = 4 * i8 + i4, nz = q4(S, d4[idx], 1, 2, 0, S->qp);
                 m->nnz[idx] = nz;
                 if (nz) {
@@ -1892,6 +1894,7 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
             set_mb_qp(&S, &m, qp);
             /* x264_mb_analyse_init, analyse.c:235-252 */
             S.b_trellis = S.trellis > 1 && S.mbrd;
+            S.b_nr = 0;
             m.skip_intra = S.lossless ? 0 : S.mbrd ? 2 : !S.trellis && !p->noise_reduction;
             struct banalysis BA;
             memset(&A, 0, sizeof(A)); memset(&BA, 0, sizeof(BA));
@@ -1901,6 +1904,7 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
             else if (S.mbrd) update_cache(&S, &m, &A);     /* :2763 */
             else update_mb(&S, &m);
             S.b_trellis = S.trellis;                       /* :2768-2773 */
+            S.b_nr = p->noise_reduction != 0;
             if (S.b_trellis == 1 || p->noise_reduction) m.skip_intra = 0;
             encode_mb(&S, &m);
             if (b_write) {                                 /* encoder.c:1192-1205 */

@@ -312,6 +312,10 @@ typedef struct {
      * x264_validate_parameters: qp 0 for every slice, chroma_qp_offset 0, fast_pskip 0, noise_reduction 0, 8x8dct only with CABAC */
     int lossless;
     const struct x264hip_slice_rd *rd;   /* NULL: the wavefront schedule of round 1; set: the raster-order variant (below) */
+    /* fenc->lowres_mvs[0][fenc->i_frame - fref0[0]->i_frame - 1] of every chain (h->frames.b_have_lowres): device [batch][n_mb][2]
+     * int16, the lookahead's half-resolution vectors towards reference 0, which x264_mb_predict_mv_ref16x16 offers (doubled) to the
+     * 16x16 search on reference 0 (R/common/macroblock.c:393-398).  NULL, or 0x7fff in a chain's first component: none */
+    const int16_t *lowres_mv;
     const struct x264hip_slice_b *b;     /* slice_type 1 (B): list 1 and what direct prediction reads (below); needs rd */
 } x264hip_slice_params;
 
@@ -323,6 +327,7 @@ typedef struct x264hip_slice_b {
     const x264hip_mb_state *l1_state;    /* the state it was coded with: mb_type / ref / mv of the co-located macroblocks (x264_mb_predict_mv_direct16x16) */
     int ref1_poc;                        /* h->fref1[0]->i_poc (x264_macroblock_bipred_init, R/common/macroblock.c:1374-1408) */
     int weightb;                         /* param.analyse.b_weighted_bipred */
+    const int16_t *lowres_mv1;           /* fenc->lowres_mvs[1][fref1[0]->i_frame - fenc->i_frame - 1], as x264hip_slice_params.lowres_mv, or NULL */
     int direct_spatial;                  /* sh.b_direct_spatial_mv_pred; 0 = temporal (R/common/macroblock.c:155-224): needs rd.stale in every sweep of the chain */
 } x264hip_slice_b;
 

@@ -176,6 +176,9 @@ static int b_predict_mv_ref16x16(const ssl *S, const smb *m, int list, int i_ref
     const int8_t *type = S->fdec->mb_type;
     int i = 0, top = m->mb - S->mb_w;
     if (CREF(m, list)[s_scan8(12)] == i_ref) { mvc[i][0] = CMV(m, list)[s_scan8(12)][0]; mvc[i][1] = CMV(m, list)[s_scan8(12)][1]; i++; }   /* b_direct */
+    if (i_ref == 0 && S->lowres_mv[list]) {                /* the lookahead's vector, :393-398 */
+        mvc[i][0] = (i16)(u16)(S->lowres_mv[list][2 * m->mb] << 1); mvc[i][1] = (i16)(u16)(S->lowres_mv[list][2 * m->mb + 1] << 1); i++;
+    }
 #define SET(o) do { mvc[i][0] = mvr[2 * (o)]; mvc[i][1] = mvr[2 * (o) + 1]; i++; } while (0)
     if ((m->nb & NB_LEFT) && !S_IS_SKIP(type[m->mb - 1])) SET(m->mb - 1);
     if (m->nb & NB_TOP) {

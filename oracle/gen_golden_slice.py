@@ -70,6 +70,11 @@ CASES2 = [
     ("b_rd_2b", (200, 120), 7, "static", dict(qp=31, subme=7, me_method=rs.ME_HEX, n_refs=1, inter=0x113, intra=0x3, transform8x8=1, cabac=1, deblock=1),
      dict(trellis=2, psy_rd=0.0, bframes=2, weightb=0, direct_pred=1)),                                            # one reference, psy off: I_PCM live in B slices
     ("b_temporal_rd", (208, 144), 7, "moving", dict(qp=22, subme=7, keyint=6, **MEDB), dict(trellis=2, psy_rd=0.0, bframes=3, weightb=1, direct_pred=2)),   # co-located references outside list 0
+    # the lookahead's vectors as candidates of the 16x16 searches (h->frames.b_have_lowres, R/common/macroblock.c:393-398); the vectors
+    # themselves are stand-ins (oracle/refslice.py: lowres_vectors), some frames / lists marked "not searched"
+    ("lowres_p", (208, 144), 5, "moving", dict(qp=27, subme=7, **MED), dict(trellis=1, psy_rd=1.0, aq_mode=1, lowres_seed=1)),
+    ("lowres_b", (208, 144), 8, "moving", dict(qp=25, subme=7, **MEDB), dict(trellis=1, psy_rd=1.0, bframes=3, weightb=1, direct_pred=1, lowres_seed=2)),
+    ("lowres_bt", (200, 120), 7, "static", dict(qp=29, subme=6, **MEDB), dict(trellis=1, bframes=2, weightb=0, direct_pred=2, lowres_seed=3)),
 ]
 
 

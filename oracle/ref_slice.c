@@ -47,6 +47,11 @@ typedef struct {
     int bframes;                             /* param.i_bframe */
     int weightb;                             /* param.analyse.b_weighted_bipred */
     int direct_pred;                         /* param.analyse.i_direct_mv_pred: 1 spatial, 2 temporal */
+    /* the lookahead's motion vectors (fenc->lowres_mvs, h->frames.b_have_lowres): x264_mb_predict_mv_ref16x16 offers twice the vector of
+     * the macroblock's half-resolution block as a candidate of every 16x16 search on reference 0 (R/common/macroblock.c:393-398).  The
+     * caller supplies them, [frame in coding order][list][n_mb][2] int16; a frame / list whose first component is 0x7fff has none
+     * (x264_frame_init_lowres' marker, R/common/mc.c:330).  NULL: b_have_lowres = 0 as before */
+    const int16_t *lowres_mv;
 } refslice_ext;
 
 typedef struct {
@@ -181,6 +186,15 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     h->fenc = x264_frame_new(h);
     h->fdec = x264_frame_new(h);
     if (x264_macroblock_cache_init(h) < 0 || x264_ratecontrol_new(h) < 0) return -2;
+    if (e && e->lowres_mv) {                              /* what x264_frame_new would have added with b_have_lowres (R/common/frame.c:80-96,140-142) */
+        h->frames.b_have_lowres = 1;
+        for (i = 0; i < 2; i++)
+            for (k = 0; k <= h->param.i_bframe + 1 && k <= X264_BFRAME_MAX; k++) {
+                h->fenc->lowres_mvs[i][k] = x264_malloc(2 * n * sizeof(int16_t));
+                h->fenc->lowres_mvs[i][k][0][0] = 0x7fff;
+            }
+        if (h->param.rc.i_aq_mode) h->fenc->i_inv_qscale_factor = x264_malloc(n * sizeof(uint16_t));     /* written by x264_adaptive_quant_frame */
+    }
     if (b_write) bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
 
     /* coding order (what x264_slicetype_decide + the frame reordering of x264_encoder_encode give for a fixed B pattern):
@@ -245,6 +259,11 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
         h->sh.i_cabac_init_idc = h->param.i_cabac_init_idc;
         x264_ratecontrol_start(h, 0);
         h->sh.i_qp = x264_ratecontrol_qp(h);
+        if (e && e->lowres_mv) {                         /* this frame's lookahead vectors, filed under the distance to the reference they point at */
+            const int16_t *lm = e->lowres_mv + (size_t)F * 2 * n * 2;
+            if (h->i_ref0 > 0) memcpy(h->fenc->lowres_mvs[0][h->fenc->i_frame - h->fref0[0]->i_frame - 1], lm, 2 * n * sizeof(int16_t));
+            if (h->i_ref1 > 0) memcpy(h->fenc->lowres_mvs[1][h->fref1[0]->i_frame - h->fenc->i_frame - 1], lm + 2 * n, 2 * n * sizeof(int16_t));
+        }
         if (is_b) x264_macroblock_bipred_init(h);            /* encoder.c:1534-1535 */
         x264_macroblock_slice_init(h);
         memset(&h->stat.frame, 0, sizeof(h->stat.frame));

@@ -65,15 +65,35 @@ class Ext(C.Structure):
     """refslice_ext (oracle/ref_slice.c): what refslice_encode_chain2 takes on top of Params."""
     _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_float), ("psy_trellis", C.c_float), ("aq_mode", C.c_int),
                 ("aq_strength", C.c_float), ("write", C.c_int), ("payload_cap", C.c_int), ("cabac_init_idc", C.c_int),
-                ("bframes", C.c_int), ("weightb", C.c_int), ("direct_pred", C.c_int)]
+                ("bframes", C.c_int), ("weightb", C.c_int), ("direct_pred", C.c_int), ("lowres_mv", C.c_void_p)]
 
 
 DIRECT_SPATIAL, DIRECT_TEMPORAL = 1, 2       # R/x264.h:93-96
 
 
 def make_ext(trellis=0, psy_rd=0.0, psy_trellis=0.0, aq_mode=0, aq_strength=1.0, write=1, payload_cap=0, cabac_init_idc=0,
-             bframes=0, weightb=0, direct_pred=DIRECT_SPATIAL):
-    return Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc, bframes, weightb, direct_pred)
+             bframes=0, weightb=0, direct_pred=DIRECT_SPATIAL, lowres_mv=None, lowres_seed=None):
+    """lowres_mv: int16 [frames in coding order][2 lists][n_mb][2], the lookahead's vectors (0x7fff in a frame / list's first component:
+    none); the array must outlive the call.  lowres_seed: run2 makes that array itself with lowres_vectors(seed, ...)."""
+    e = Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc, bframes, weightb, direct_pred, None)
+    if lowres_mv is not None:
+        assert lowres_mv.dtype == np.int16 and lowres_mv.flags["C_CONTIGUOUS"]
+        e.lowres_mv = lowres_mv.ctypes.data
+        e._keep = lowres_mv
+    e._lowres_seed = lowres_seed
+    return e
+
+
+def lowres_vectors(seed, n_frames, n_mb):
+    """Stand-ins for the lookahead's half-resolution vectors (fenc->lowres_mvs): [frame in coding order][list][n_mb][2] int16, small
+    random vectors; about a quarter of the (frame, list) arrays carry the "not searched" marker 0x7fff in their first component."""
+    r = np.random.default_rng(4000 + seed)
+    lm = r.integers(-14, 15, (n_frames, 2, n_mb, 2)).astype(np.int16)
+    for f in range(n_frames):
+        for l in range(2):
+            if r.random() < 0.25:
+                lm[f, l, 0, 0] = 0x7fff
+    return np.ascontiguousarray(lm)
 
 
 OUT2_FIELDS = [("payload", np.uint8, lambda F, n, cap: (F, cap)),
@@ -121,6 +141,9 @@ def run2(lib, fn, p, e, y, u, v):
     mb_w, mb_h = (p.width + 15) // 16, (p.height + 15) // 16
     if not e.payload_cap:
         e.payload_cap = mb_w * mb_h * 800 + 4096
+    if getattr(e, "_lowres_seed", None) is not None and not e.lowres_mv:
+        e._keep = lowres_vectors(e._lowres_seed, p.n_frames, mb_w * mb_h)
+        e.lowres_mv = e._keep.ctypes.data
     arrs, o = alloc_out(p)
     arrs2 = {name: np.zeros(shape(p.n_frames, mb_w * mb_h, e.payload_cap), dt) for name, dt, shape in OUT2_FIELDS}
     o2 = Out2(**{k: v.ctypes.data for k, v in arrs2.items()})

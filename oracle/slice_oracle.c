@@ -50,6 +50,7 @@ typedef struct {
     int aq_mode; float aq_strength;
     int write, payload_cap, cabac_init_idc;
     int bframes, weightb, direct_pred;       /* B slices: param.i_bframe (fixed pattern, no pyramid), b_weighted_bipred, i_direct_mv_pred (1 spatial, 2 temporal) */
+    const i16 *lowres_mv;                    /* the lookahead's vectors [frame in coding order][list][n_mb][2] or NULL (oracle/ref_slice.c: refslice_ext) */
 } slice_ext;
 typedef struct {
     u8 *payload;
@@ -172,6 +173,7 @@ typedef struct {
                                                 count (analyse.c:237) -- param.analyse.i_noise_reduction != 0 for the final encode (:2769) */
     /* round 2: RD levels, trellis, the entropy coder, per-macroblock QP */
     const slice_ext *e;
+    const i16 *lowres_mv[2];                 /* this frame's fenc->lowres_mvs of list 0 / 1 towards reference 0, or NULL (none / marked 0x7fff) */
     slice_out2 *o2;
     int mbrd, psy_rd, trellis, b_trellis;    /* a->i_mbrd, h->mb.i_psy_rd, param i_trellis, h->mb.b_trellis (what the encode functions obey now) */
     int chroma_qp_offset;                    /* after x264_validate_parameters' psy adjustment */
@@ -325,6 +327,9 @@ static int predict_mv_ref16x16(const ssl *S, const smb *m, int i_ref, i16 mvc[8]
     const i16 *mvr = S->mvr + (size_t)i_ref * S->n * 2;
     const int8_t *type = S->fdec->mb_type;
     int i = 0, top = m->mb - S->mb_w;
+    if (i_ref == 0 && S->lowres_mv[0]) {                   /* the lookahead's vector, twice (half resolution -> full), :393-398 */
+        mvc[i][0] = (i16)(u16)(S->lowres_mv[0][2 * m->mb] << 1); mvc[i][1] = (i16)(u16)(S->lowres_mv[0][2 * m->mb + 1] << 1); i++;
+    }
 #define SET(o) do { mvc[i][0] = mvr[2 * (o)]; mvc[i][1] = mvr[2 * (o) + 1]; i++; } while (0)
     if ((m->nb & NB_LEFT) && type[m->mb - 1] != S_P_SKIP) SET(m->mb - 1);
     if (m->nb & NB_TOP) {
@@ -1839,6 +1844,12 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
         S.f = f;
         S.fdec = sframe_new(&S);
         S.fdec->poc = 2 * (disp - last_idr); S.fdec->kept = !is_b;
+        S.lowres_mv[0] = S.lowres_mv[1] = NULL;
+        if (e && e->lowres_mv && !idr) {
+            const i16 *lm = e->lowres_mv + (size_t)F * 2 * S.n * 2;
+            if (lm[0] != 0x7fff) S.lowres_mv[0] = lm;
+            if (is_b && lm[2 * S.n] != 0x7fff) S.lowres_mv[1] = lm + 2 * S.n;
+        }
         /* x264_reference_build_list, R/encoder/encoder.c:911-981: list 0 = earlier pictures, nearest first; list 1 = later pictures, nearest first */
         S.n_ref = S.n_ref1 = 0;
         for (int i = 0; i < n_avail; i++) {

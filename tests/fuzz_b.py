@@ -14,7 +14,9 @@ def config_wide(i):
     offsets, sub-8x8 partitions below the RD levels, more references)."""
     r = np.random.default_rng(9000 + i)
     w, h = int(r.integers(5, 14)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(5, 10)) * 16 - int(r.integers(0, 2)) * 8
-    frames = int(r.integers(4, 9))
+    if i >= 5000:                                  # seeds from 5000: pictures large enough for long vectors and the vector-range clipping
+        w, h = int(r.integers(20, 44)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(12, 26)) * 16 - int(r.integers(0, 2)) * 8
+    frames = int(r.integers(4, 9)) if i < 5000 else int(r.integers(4, 7))
     bframes = int(r.choice([0, 0, 1, 2, 3]))
     subme = int(r.choice([1, 2, 3, 4, 5, 6, 7, 7])) if not bframes else int(r.choice([2, 3, 4, 5, 6, 7, 7]))
     kw = dict(qp=int(r.integers(12, 44)), subme=subme, me_method=int(r.choice([0, 1, 1, 2, 2, 3])), me_range=int(r.choice([8, 16, 24])),
@@ -33,6 +35,8 @@ def config_wide(i):
         kw["inter"] &= ~0x2; kw["intra"] &= ~0x2
     ekw = dict(trellis=int(r.choice([0, 1, 2])), psy_rd=float(r.choice([0.0, 0.4, 1.0])), aq_mode=int(r.integers(0, 2)), aq_strength=float(r.choice([0.6, 1.0, 1.4])),
                bframes=bframes, weightb=int(r.integers(0, 2)), direct_pred=int(r.choice([1, 2])))
+    if i >= 1500 and r.random() < 0.5:
+        ekw["lowres_seed"] = int(i)                # the lookahead's candidates (stand-in vectors, oracle/refslice.py: lowres_vectors)
     kind = "moving" if r.integers(0, 2) else "static"
     y, u, v = case_inputs((w, h), frames, kind)
     y = y.copy()
@@ -66,6 +70,14 @@ def compare(hip, twin, cqm, i):
     w, h, frames, kind, kw, ekw, y, u, v = config(i)
     want = rs.run2(twin, "x264o_encode_chain2", rs.make_params(w, h, frames, **kw), rs.make_ext(**ekw), y, u, v)
     what = "%dx%d x%d %s %s %s" % (w, h, frames, kind, kw, ekw)
+    ekw = dict(ekw)
+    seed = ekw.pop("lowres_seed", None)
+    lowres = None
+    if seed is not None:
+        from x264_vs2008_amd.frame import DeviceArray
+        n = ((w + 15) // 16) * ((h + 15) // 16)
+        lm = rs.lowres_vectors(seed, frames, n)
+        lowres = [tuple(DeviceArray(hip, (1, n, 2), np.int16, np.ascontiguousarray(lm[f, l][None])) for l in range(2)) for f in range(frames)]
     try:
         enc = sl.ChainEncoder(hip, w, h, cqm, batch=1, write=1, **kw, **ekw)
     except (RuntimeError, ValueError) as e:
@@ -77,7 +89,7 @@ def compare(hip, twin, cqm, i):
         for f, (disp, stype) in enumerate(order):
             enc.upload(y[disp], u[disp], v[disp])
             try:
-                enc.encode_frame(stype=stype, disp=disp)
+                enc.encode_frame(stype=stype, disp=disp, **(dict(lowres_mv=lowres[f][0], lowres_mv1=lowres[f][1]) if lowres else {}))
             except RuntimeError as e:                  # an option combination the sweep refuses (it says so): not a difference
                 if "slice_sweep:" in str(e) and f == (1 if stype != sl.SLICE_I else 0):
                     return what + " REFUSED " + str(e)[-90:], [], []

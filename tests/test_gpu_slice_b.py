@@ -27,8 +27,10 @@ def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, fra
     with np.load(os.path.join(GOLDEN, "slice2_%s.npz" % name)) as z:
         gold = {k: z[k] for k in z.files}
     y, u, v = case_inputs(size, frames, kind)
-    kw = dict(kw)
+    kw, ekw = dict(kw), dict(ekw)
     kw.pop("cqm_preset", 0)
+    from test_gpu_slice_rd import lowres_arrays
+    lowres = lowres_arrays(hip_lib, ekw.pop("lowres_seed", None), frames, size)
     enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, **kw, **{k: v_ for k, v_ in ekw.items() if k != "write"})
     order = sl.coding_order(frames, kw.get("keyint", 0), ekw["bframes"])
     assert [d for d, _ in order] == gold["frame_info2"][:, 0].tolist() and [t for _, t in order] == gold["frame_info"][:, 0].tolist()
@@ -36,7 +38,8 @@ def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, fra
     try:
         for f, (disp, stype) in enumerate(order):
             enc.upload(y[disp], u[disp], v[disp])
-            st, qp, state = enc.encode_frame(stype=stype, disp=disp)
+            lw = dict(lowres_mv=lowres[f][0], lowres_mv1=lowres[f][1]) if lowres else {}
+            st, qp, state = enc.encode_frame(stype=stype, disp=disp, **lw)
             enc.status()
             assert (st, qp) == (int(gold["frame_info"][f, 0]), int(gold["frame_info"][f, 1])), "frame %d" % f
             got = {k: state.get(k)[0] for k in STATE}
@@ -63,7 +66,7 @@ def test_b_slices_match_reference_loop_and_payload(hip_lib, cqm, name, size, fra
     assert (t == 16).any() and (t == 17).any() and ((t == 18).any() or gold["frame_info"][:, 1].min() < 26)      # B_BI_BI, B_8x8, B_SKIP (none at the low-QP case)
 
 
-LANE_CASES = [c for c in B_CASES if c[5].get("direct_pred", 1) == 1][:2]      # (temporal direct prediction chains the frames: no lanes)
+LANE_CASES = [c for c in B_CASES if c[5].get("direct_pred", 1) == 1 and "lowres_seed" not in c[5]][:2]      # (temporal direct prediction chains the frames: no lanes)
 
 
 @pytest.mark.parametrize("name,size,frames,kind,kw,ekw", LANE_CASES, ids=[c[0] for c in LANE_CASES])

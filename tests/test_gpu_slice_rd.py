@@ -16,9 +16,22 @@ from test_gpu_slice import STATE, check_frame
 pytestmark = pytest.mark.gpu
 
 
+def lowres_arrays(hip_lib, seed, frames, size, batch=1):
+    """The fixture's stand-in lookahead vectors (oracle/refslice.py: lowres_vectors) on the device: [(list 0, list 1)] per frame in coding order."""
+    if seed is None:
+        return None
+    from oracle.refslice import lowres_vectors
+    from x264_vs2008_amd.frame import DeviceArray
+    n = ((size[0] + 15) // 16) * ((size[1] + 15) // 16)
+    lm = lowres_vectors(seed, frames, n)
+    return [tuple(DeviceArray(hip_lib, (batch, n, 2), np.int16, np.ascontiguousarray(np.broadcast_to(lm[f, l], (batch, n, 2)))) for l in range(2)) for f in range(frames)]
+
+
 def run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw, batch=1):
     kw = dict(kw)
     kw.pop("cqm_preset", 0)
+    ekw = dict(ekw)
+    lowres = lowres_arrays(hip_lib, ekw.pop("lowres_seed", None), frames, size, batch)
     enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=batch, write=1, **kw, **{k: v_ for k, v_ in ekw.items() if k != "write"})
     out = []
     # B frames: the chain in coding order (the golden fixtures of such chains are in coding order too)
@@ -28,7 +41,8 @@ def run_chain2(hip_lib, cqm, size, frames, y, u, v, kw, ekw, batch=1):
             disp = order[f][0] if order else f
             for b in range(batch):
                 enc.upload(y[disp], u[disp], v[disp], b=b)
-            stype, qp, state = enc.encode_frame(stype=order[f][1], disp=disp) if order else enc.encode_frame()
+            lw = dict(lowres_mv=lowres[f][0], lowres_mv1=lowres[f][1]) if lowres else {}
+            stype, qp, state = enc.encode_frame(stype=order[f][1], disp=disp, **lw) if order else enc.encode_frame(**lw)
             enc.status()
             recon = enc.last[0]
             d = {k: state.get(k) for k in STATE + ["mvr", "cost_intra", "cost_inter"]}

@@ -187,6 +187,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     // i8x8 needs the 8x8 transform (x264_validate_parameters, R/encoder/encoder.c:487-491)
     a.flags_intra = (is_p ? p->analyse_inter : p->analyse_intra) & (a.transform8x8 ? 3 : 1);
     a.cost_mv = p->cost_mv; a.cost_center = p->cost_mv_range;
+    a.lowres0 = is_p ? p->lowres_mv : nullptr; a.lowres1 = is_b ? pb->lowres_mv1 : nullptr;
     a.fy = fenc->plane[0]; a.fu = fenc->plane[1]; a.fv = fenc->plane[2];
     a.dy = recon->plane[0]; a.du = recon->plane[1]; a.dv = recon->plane[2];
     if (l0) { a.l0_type = (const signed char *)l0->mb_type; a.l0_ref = (const signed char *)l0->ref; a.l0_mv = l0->mv; }
@@ -259,7 +260,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
             r.direct_temporal = !pb->direct_spatial;
             r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
-            if (r.direct_temporal) x264hip_launch_slice_bt(a, t, r, c->stream); else x264hip_launch_slice_b(a, t, r, c->stream);
+            // the extended B kernel (temporal direct prediction, the lookahead's candidates) only where it is needed: the plain one is 6-8 % faster
+            if (r.direct_temporal || a.lowres0 || a.lowres1) x264hip_launch_slice_bt(a, t, r, c->stream); else x264hip_launch_slice_b(a, t, r, c->stream);
         } else
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {

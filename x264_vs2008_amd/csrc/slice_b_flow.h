@@ -286,7 +286,9 @@
         if (bstep == BS_PRE) {
             cache_fenc_satd();
             type = T_B_SKIP;
-            if constexpr (TD) {
+            bool temporal = false;
+            if constexpr (TD) temporal = rd.direct_temporal != 0;
+            if (temporal) {
                 // ---- x264_mb_predict_mv_direct16x16, temporal (R/common/macroblock.c:155-224; direct_8x8_inference: the corner blocks) ----
                 const int type_col = UNI((rd.col_type + cb)[mb]);
                 cache_set_b(1, 0, 0, 4, 4, 0, 0, 0, 1, 0);
@@ -373,6 +375,10 @@
                             WAVE_SYNC();
 #define SETC(vx_, vy_) do { s.mvc[n_mvc][0] = (i16)(vx_); s.mvc[n_mvc][1] = (i16)(vy_); n_mvc++; } while (0)
                             if (CREF(l, 30) == r) SETC(CMVX(l, 30), CMVY(l, 30));                  // b_direct
+                            if (TD && r == 0 && (l ? a.lowres1 : a.lowres0)) {     // the lookahead's vector, twice (0x7fff in the chain's first component: none)
+                                const i16 *lw = (l ? a.lowres1 : a.lowres0) + 2 * cb;
+                                if (UNI(lw[0]) != 0x7fff) SETC((u16)(UNI(lw[2 * mb]) << 1), (u16)(UNI(lw[2 * mb + 1]) << 1));
+                            }
                             if ((nb & NB_LEFT) && !IS_SKIP_T(left_type)) { if (l) SETC(sb.left_mvr1[0], sb.left_mvr1[1]); else SETC(s.left_mvr[r][0], s.left_mvr[r][1]); }
                             if (nb & NB_TOP) {
                                 if (!IS_SKIP_T(type_top)) SETC(mvr[2 * top], mvr[2 * top + 1]);

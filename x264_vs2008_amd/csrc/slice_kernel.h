@@ -76,6 +76,7 @@ struct SwArgs {
     const int *dq4, *dq8;
     const i16 *cost_mv;
     int cost_center;
+    const i16 *lowres0, *lowres1;   // fenc->lowres_mvs of list 0 / 1 towards reference 0: [batch][n_mb][2], or NULL (x264hip_slice_params.lowres_mv)
     const u8 *fy, *fu, *fv;
     u8 *dy, *du, *dv;
     const signed char *l0_type, *l0_ref;
@@ -109,7 +110,7 @@ struct SwLds {
     int keep8, cmode[2], nzdc16;
     i16 lv_y[256], lv_dc[16], lv_cdc[8], lv_cac[128];
     u8 nnz[32];
-    i16 mvc[8][2];
+    i16 mvc[9][2];              // x264_mb_predict_mv_ref16x16's list: direct, lookahead, four neighbours, three temporal
     i16 left_mvr[SW_MAX_REFS][2];
     // intra 4x4 / 8x8 analysis: prediction-mode cache in x264_scan8 layout, edge arrays, and what the reference keeps
     // when i_skip_intra is set (the partly encoded macroblock of the analysis is the final one, macroblock.c:527-577)
@@ -1271,7 +1272,7 @@ static __device__ const int d_lambda2_tab[52] = {14, 18, 22, 28, 36, 45, 57, 72,
 static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
                                               29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
-template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false>       // TD: a B slice with temporal direct prediction
+template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false>       // TD: the extended B kernel (temporal direct prediction, lookahead candidates)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
 {
     static_assert(!BS || RD, "B slices run in the raster variant");
@@ -1296,6 +1297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     a.mv += 32 * nmb * bz; a.mvr += 2 * SW_MAX_REFS * nmb * bz;
     if (a.l0_type) { a.l0_type += nmb * bz; a.l0_ref += 4 * nmb * bz; a.l0_mv += 32 * nmb * bz; }
     int *prog = a.progress + (size_t)bz * a.mb_h;
+
     const int satd = a.subme > 1 && !a.lossless, is_p = a.slice_type == 0;
     const MeOpts mo = {a.me_method, a.me_range, a.subme, a.chroma_me, a.lossless};
     SwQp Q = {a.qp, a.qpc, a.lambda, d_lambda2_tab[a.qp], a.chroma_skip_thresh};
@@ -1963,6 +1965,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         WAVE_SYNC();                                   // the previous reference's candidates have been read
                         // every lane stores the same values: the list is wave-uniform
 #define SETC(vx_, vy_) do { s.mvc[n_mvc][0] = (i16)(vx_); s.mvc[n_mvc][1] = (i16)(vy_); n_mvc++; } while (0)
+                        if (r == 0 && a.lowres0) {       // the lookahead's vector, twice (R/common/macroblock.c:393-398); 0x7fff in the chain's first component: none
+                            const i16 *lw = a.lowres0 + 2 * cb;      // (re-derived from the argument where it is used: nothing to keep live across the macroblock)
+                            if (UNI(lw[0]) != 0x7fff) SETC((u16)(UNI(lw[2 * mb]) << 1), (u16)(UNI(lw[2 * mb + 1]) << 1));
+                        }
                         if ((nb & NB_LEFT) && left_type != T_P_SKIP) SETC(s.left_mvr[r][0], s.left_mvr[r][1]);
                         if (nb & NB_TOP) {
                             if (type_top != T_P_SKIP) SETC(mvr[2 * top], mvr[2 * top + 1]);

@@ -34,7 +34,8 @@ class MbState(C.Structure):
 
 class SliceB(C.Structure):
     """x264hip_slice_b: list 1 of a B slice and what direct prediction reads."""
-    _fields_ = [("fref1", C.c_void_p), ("l1_state", C.c_void_p), ("ref1_poc", C.c_int), ("weightb", C.c_int), ("direct_spatial", C.c_int)]
+    _fields_ = [("fref1", C.c_void_p), ("l1_state", C.c_void_p), ("ref1_poc", C.c_int), ("weightb", C.c_int), ("lowres_mv1", C.c_void_p),
+                ("direct_spatial", C.c_int)]
 
 
 class SliceRd(C.Structure):
@@ -57,7 +58,7 @@ class SliceParams(C.Structure):
                 ("dequant4_mf", C.c_void_p), ("dequant8_mf", C.c_void_p),
                 ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int), ("poc", C.c_int), ("ref_poc", C.c_int * 8),
                 ("mixed_refs", C.c_int), ("profile", C.c_void_p), ("noise_reduction", C.c_int), ("nr", C.c_void_p), ("lossless", C.c_int),
-                ("rd", C.c_void_p), ("b", C.c_void_p)]
+                ("rd", C.c_void_p), ("lowres_mv", C.c_void_p), ("b", C.c_void_p)]
 
 
 class NrState(C.Structure):
@@ -241,7 +242,7 @@ class ChainEncoder:
             ln["ctx"].sync()
         self.ctx.upload(self.fenc, y, u, v, b=b)
 
-    def encode_frame(self, src=None, stype=None, disp=None):
+    def encode_frame(self, src=None, stype=None, disp=None, lowres_mv=None, lowres_mv1=None):
         """The macroblock sweep for the frame held by `src` (default: the picture upload() fills) in every
         batch element.  Returns (slice_type, qp, state) -- the state's arrays are valid after ctx.sync().
         Without stype: I / P chains in display order (an IDR every keyint frames).  With stype / disp (see coding_order): the
@@ -289,7 +290,8 @@ class ChainEncoder:
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
                         cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
                         profile=self.profile.ptr if self.profile else None,
-                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless)
+                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless,
+                        lowres_mv=lowres_mv.ptr if lowres_mv is not None else None)        # DeviceArray [batch][n_mb][2] int16: the lookahead's vectors
         if self.raster:
             rb, ro = dict(self.rd_bufs, **lane["bufs"]) if lane else self.rd_bufs, self.rd_opt
             self.last_bufs = rb
@@ -305,7 +307,8 @@ class ChainEncoder:
             p.rd = C.addressof(self.rd)
         if is_b:
             self.sb = SliceB(fref1=C.addressof(refs1[0][0]), l1_state=C.addressof(refs1[0][1].st), ref1_poc=refs1[0][2],
-                             weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"])
+                             weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"],
+                             lowres_mv1=lowres_mv1.ptr if lowres_mv1 is not None else None)
             p.b = C.addressof(self.sb)
         for i, r in enumerate(refs):
             p.ref_poc[i] = r[2]

@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="0: 12 (raster variant) / 40 (--wavefront 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-sources", action="store_true", help="fill the source ring with one host upload per chain and picture instead of device-side copies "
-                    "(slow set-up; rocprofv3 --pmc of ROCm 7.2 crashes on the runtime's own copy kernels)")
+                    "(slow set-up; what the rocprofv3 --pmc passes of profiles/ were taken with, at 512 chains: with multi-gigabyte buffers --pmc of ROCm 7.2 crashes)")
     args = ap.parse_args()
     wf = bool(args.wavefront)
     args.steps = args.steps or (24 if wf else 12)

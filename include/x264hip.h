@@ -257,7 +257,8 @@ typedef struct {
  * wavefront owns a whole frame of one chain of the batch and walks it in raster order, and the entropy coder runs inside the
  * loop exactly where x264_slice_write has it (R/encoder/encoder.c:1155-1165,1192-1205,1269-1273): the launch also returns every
  * chain's slice_data() bytes.  Throughput then comes from the number of chains in flight (the batch), not from a wavefront
- * schedule inside the frame.  I and P slices, CABAC; sub-8x8 partitions, psy-trellis and subme >= 8 are refused.        */
+ * schedule inside the frame.  I, P and B slices, CABAC; refused with an error string: sub-8x8 partitions together with the RD levels,
+ * psy-trellis, subme >= 8, CAVLC together with the writer.                                                                */
 typedef struct x264hip_slice_rd {
     int trellis;                   /* param.analyse.i_trellis 0..2 */
     int psy_rd;                    /* h->mb.i_psy_rd = FIX8(param.analyse.f_psy_rd) (0 below subme 6); the caller lowers chroma_qp_offset
@@ -290,7 +291,7 @@ typedef struct x264hip_slice_rd {
 struct x264hip_slice_rd;
 struct x264hip_slice_b;
 typedef struct {
-    int slice_type;                    /* 0 = SLICE_TYPE_P, 2 = SLICE_TYPE_I (R/common/common.h:128-134) */
+    int slice_type;                    /* 0 = SLICE_TYPE_P, 1 = SLICE_TYPE_B (needs .b and .rd), 2 = SLICE_TYPE_I (R/common/common.h:128-134) */
     int qp, chroma_qp_offset;
     int me_method, me_range, subme, chroma_me, mv_range;       /* param.analyse.* */
     int fast_pskip, dct_decimate, cabac, transform8x8;
@@ -319,7 +320,7 @@ typedef struct {
     const struct x264hip_slice_b *b;     /* slice_type 1 (B): list 1 and what direct prediction reads (below); needs rd */
 } x264hip_slice_params;
 
-/* A B slice (slice_type = 1; the raster variant with the entropy coder: rd set, write = 1, subme 7).  x264 core 66 without
+/* A B slice (slice_type = 1; the raster variant with the entropy coder: rd set, write = 1, subme 2..7).  x264 core 66 without
  * b-pyramid has one list-1 picture and its B frames are disposable (never references).  refs / n_refs of the call are list 0
  * (x264_reference_build_list, R/encoder/encoder.c:911-981: earlier pictures, nearest first); l0 = refs[0]'s state as always. */
 typedef struct x264hip_slice_b {

@@ -146,6 +146,9 @@ int x264hip_lookahead_intra_frame(x264hip_frame_ctx *c, const x264hip_picture *p
  * (R/common/set.c:146,158) for every QP from the unshifted multipliers quant_mf6 [n_cat][6][n] -> out [n_cat][52][n]. */
 void x264hip_cost_mv_table(int lambda, int span, int16_t *out);
 void x264hip_unquant_table(const int32_t *quant_mf6, int n_cat, int n, int32_t *out);
+/* x264_nal_encode (R/common/common.c:656): start code (b_annexb) + NAL header + payload with emulation prevention; returns the size.
+ * Host side, no device needed; dst must hold 5 + len * 3 / 2 bytes. */
+int x264hip_nal_encode(uint8_t *dst, int b_annexb, int i_ref_idc, int i_type, const uint8_t *payload, int len);
 int x264hip_aq_var_frame(x264hip_frame_ctx *c, const x264hip_picture *pic, int32_t *out_dev);
 /* x264_adaptive_quant_frame (R/encoder/ratecontrol.c:231-249): fenc->f_qp_offset[batch][n_mb] (float, device) from the energies
  * above; aq_strength = param.rc.f_aq_strength.  energy_dev: scratch [batch][n_mb] int32. */

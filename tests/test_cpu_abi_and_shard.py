@@ -135,3 +135,45 @@ def test_cost_mv_table_built_in_c_matches_twin_and_numpy(oracle_lib):
         twin = np.ctypeslib.as_array((C.c_int16 * (2 * COST_SPAN + 1)).from_address(oracle_lib.x264o_cost_mv_row(qp)))
         assert np.array_equal(got, twin), qp
         assert np.array_equal(got.view(np.uint16), cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)), qp
+
+
+def test_nal_encode_matches_reference():
+    """x264hip_nal_encode (host C of the library) against the reference's own x264_nal_encode (oracle/_ref, built here from the
+    reference's sources) on payloads full of the byte patterns emulation prevention exists for; where the reference library is
+    absent, against the rule's statement in ITU-T H.264 7.4.1 (a 0x03 before any byte <= 3 that follows two zeros)."""
+    import ctypes as C
+    import os
+    from x264_vs2008_amd import lib as L
+
+    lib = L.open_library()
+    lib.x264hip_nal_encode.restype = C.c_int
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
+    ref = None
+    if os.path.exists(ref_so):
+        from oracle import refslice as rs
+        ref = rs.reference_lib()
+
+    class Nal(C.Structure):                      # x264_nal_t, R/x264.h:395-403
+        _fields_ = [("i_ref_idc", C.c_int), ("i_type", C.c_int), ("i_payload", C.c_int), ("p_payload", C.c_void_p)]
+
+    r = np.random.default_rng(5)
+    for trial in range(60):
+        n = int(r.integers(0, 400))
+        pay = r.choice(np.array([0, 0, 0, 1, 2, 3, 4, 255], np.uint8), n) if trial % 2 else r.integers(0, 256, n).astype(np.uint8)
+        pay = np.ascontiguousarray(pay)
+        ref_idc, typ, annexb = int(r.integers(0, 4)), int(r.choice([1, 5, 6, 7, 8])), int(r.integers(0, 2))
+        got = np.zeros(5 + n * 3 // 2 + 8, np.uint8)
+        m = lib.x264hip_nal_encode(got.ctypes.data_as(C.c_void_p), annexb, ref_idc, typ, pay.ctypes.data_as(C.c_void_p), n)
+        if ref is not None:
+            want = np.zeros_like(got)
+            size = C.c_int(0)
+            nal = Nal(ref_idc, typ, n, pay.ctypes.data)
+            ref.x264_nal_encode(want.ctypes.data_as(C.c_void_p), C.byref(size), annexb, C.byref(nal))
+            assert m == size.value and np.array_equal(got[:m], want[:m]), trial
+        out, zeros = ([0, 0, 0, 1] if annexb else []) + [(ref_idc << 5) | typ], 0
+        for v in pay.tolist():
+            if zeros == 2 and v <= 3:
+                out.append(3); zeros = 0
+            zeros = zeros + 1 if v == 0 else 0
+            out.append(v)
+        assert got[:m].tolist() == out, trial

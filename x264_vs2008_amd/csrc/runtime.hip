@@ -119,6 +119,24 @@ extern "C" void *x264hip_malloc(size_t bytes)
     return p;
 }
 
+// x264_nal_encode (R/common/common.c:656-693): Annex B start code (always the long one) or nothing, the NAL header byte, and the payload
+// with an emulation-prevention 0x03 before every byte <= 3 that follows two zero bytes.  Host code, like the reference's: the slice
+// payloads come back from the device once per frame (x264hip_slice_rd.payload).  dst needs 5 + len * 3 / 2 bytes at worst.
+extern "C" int x264hip_nal_encode(uint8_t *dst, int b_annexb, int i_ref_idc, int i_type, const uint8_t *payload, int len)
+{
+    uint8_t *d = dst;
+    int zeros = 0;
+    if (b_annexb) { *d++ = 0; *d++ = 0; *d++ = 0; *d++ = 1; }
+    *d++ = (uint8_t)((i_ref_idc << 5) | i_type);
+    for (int i = 0; i < len; i++) {
+        const uint8_t v = payload[i];
+        if (zeros == 2 && v <= 3) { *d++ = 3; zeros = 0; }
+        zeros = v ? 0 : zeros + 1;
+        *d++ = v;
+    }
+    return (int)(d - dst);
+}
+
 // ---- host tables whose arithmetic is floating point in the reference: built here, in C, with the reference's expression and the
 // build's -ffp-contract=off (a NumPy twin of this lives in x264_vs2008_amd/frame.py only as a cross-check) ----
 // p_cost_mv (x264_mb_analyse_load_costs, R/encoder/analyse.c:182-198; its log2f is the macro of analyse.c:40): out[span + i] =

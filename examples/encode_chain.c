@@ -122,7 +122,7 @@ int main(int argc, char **argv)
     int16_t *d_cost_all = to_device(cost_all, sizeof(int16_t) * 52 * cost_n);
 
     /* ---- per-frame buffers ---- */
-    const int payload_cap = n_mb * 800 + 4096 + X264HIP_PAYLOAD_LEAD;
+    const int payload_cap = n_mb * 800 + 8192 + 128 + X264HIP_PAYLOAD_LEAD;
     uint8_t *d_payload = x264hip_malloc((size_t)payload_cap), *payload = malloc((size_t)payload_cap);
     int32_t *d_len = x264hip_malloc(sizeof(int32_t)), *d_energy = x264hip_malloc(sizeof(int32_t) * n_mb);
     float *d_aq = x264hip_malloc(sizeof(float) * n_mb);

@@ -59,6 +59,16 @@ void  x264hip_free(void *dev);
 int   x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int   x264hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int   x264hip_device_synchronize(void);
+/* pinned host memory, asynchronous copies and streams for hosts without a HIP binding: frame ingest / payload egress overlapped with the
+ * kernels (the staging of R/muxers.c:63-130 read_frame_yuv / write_nalu, with the DMA engines reading / writing the buffers directly) */
+void *x264hip_host_alloc(size_t bytes);
+void  x264hip_host_free(void *host);
+int   x264hip_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *hip_stream);
+int   x264hip_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, void *hip_stream);
+int   x264hip_mem_info(size_t *free_bytes, size_t *total_bytes);      /* hipMemGetInfo of the library's device */
+void *x264hip_stream_create(void);
+void  x264hip_stream_destroy(void *hip_stream);
+int   x264hip_stream_synchronize(void *hip_stream);
 /* HIP events on a named stream (timing of kernels on the stream they run on) */
 void *x264hip_event_create(void);
 void  x264hip_event_destroy(void *ev);
@@ -124,6 +134,14 @@ int   x264hip_frame_ctx_select(x264hip_frame_ctx *c, int batch_index);
  * host I420 -> device planes, then edges replicated into the padding.      */
 int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic,
                            const uint8_t *y, int sy, const uint8_t *u, int su, const uint8_t *v, int sv);
+/* the same without the final synchronisation: y / u / v pinned (x264hip_host_alloc) and left alone until the stream has passed this
+ * point; hip_stream NULL = the context's stream */
+int x264hip_picture_upload_async(x264hip_frame_ctx *c, x264hip_picture *pic, const uint8_t *y, int sy, const uint8_t *u, int su,
+                                 const uint8_t *v, int sv, void *hip_stream);
+/* synthetic source: batch element b becomes frame t0 + b * t_stride of the integer-only test clip (the generator of
+ * x264_vs2008_amd/synth.py, bit for bit), padded to the coded size; asynchronous on the context's stream.  Benchmarks take their input
+ * from here, so every (chain, frame) is a picture of its own and no upload is involved. */
+int x264hip_picture_synth(x264hip_frame_ctx *c, x264hip_picture *pic, int t0, int t_stride);
 int x264hip_picture_download(x264hip_frame_ctx *c, const x264hip_picture *pic, int plane_id /*0..2 Y,U,V; 3..5 H,V,HV; 6..9 lowres*/,
                              uint8_t *dst, int dst_stride, int with_padding);
 /* x264_frame_expand_border / _filtered / _lowres (R/common/frame.c:218-334) */
@@ -145,6 +163,15 @@ int x264hip_lookahead_intra_frame(x264hip_frame_ctx *c, const x264hip_picture *p
  * p_cost_mv for one lambda (R/encoder/analyse.c:182-198), out[2 * span + 1] centred at span; h->unquant4_mf / unquant8_mf
  * (R/common/set.c:146,158) for every QP from the unshifted multipliers quant_mf6 [n_cat][6][n] -> out [n_cat][52][n]. */
 void x264hip_cost_mv_table(int lambda, int span, int16_t *out);
+/* x264_cqm_init (R/common/set.c:68-168) in the library's host C: every table the sweep's x264hip_slice_params / x264hip_slice_rd name,
+ * from the PPS's six scaling lists (raster order; NULL or a NULL entry = flat 16) and param.analyse.i_luma_deadzone ({inter, intra};
+ * NULL = {21, 11}).  -1 + error string on "Quantization overflow" at a QP >= qp_min. */
+typedef struct {
+    uint16_t quant4_mf[4][52][16], quant4_bias[4][52][16], quant8_mf[2][52][64], quant8_bias[2][52][64];
+    int32_t  dequant4_mf[4][6][16], dequant8_mf[2][6][64];
+    int32_t  unquant4_mf[4][52][16], unquant8_mf[2][52][64];
+} x264hip_cqm_tables;
+int x264hip_cqm_init(const uint8_t *const scaling_list[6], const int luma_deadzone[2], int qp_min, x264hip_cqm_tables *out);
 void x264hip_unquant_table(const int32_t *quant_mf6, int n_cat, int n, int32_t *out);
 /* x264_nal_encode (R/common/common.c:656): start code (b_annexb) + NAL header + payload with emulation prevention; returns the size.
  * Host side, no device needed; dst must hold 5 + len * 3 / 2 bytes. */

@@ -177,3 +177,58 @@ def test_nal_encode_matches_reference():
             zeros = zeros + 1 if v == 0 else 0
             out.append(v)
         assert got[:m].tolist() == out, trial
+
+
+# the default scaling lists of ITU-T H.264 tables 7-3 / 7-4 in raster order (what --cqm jvt selects): data of the standard
+JVT4I = [6, 13, 20, 28, 13, 20, 28, 32, 20, 28, 32, 37, 28, 32, 37, 42]
+JVT4P = [10, 14, 20, 24, 14, 20, 24, 27, 20, 24, 27, 30, 24, 27, 30, 34]
+JVT8I = [6, 10, 13, 16, 18, 23, 25, 27, 10, 11, 16, 18, 23, 25, 27, 29, 13, 16, 18, 23, 25, 27, 29, 31, 16, 18, 23, 25, 27, 29, 31, 33,
+         18, 23, 25, 27, 29, 31, 33, 36, 23, 25, 27, 29, 31, 33, 36, 38, 25, 27, 29, 31, 33, 36, 38, 40, 27, 29, 31, 33, 36, 38, 40, 42]
+JVT8P = [9, 13, 15, 17, 19, 21, 22, 24, 13, 13, 17, 19, 21, 22, 24, 25, 15, 17, 19, 21, 22, 24, 25, 27, 17, 19, 21, 22, 24, 25, 27, 28,
+         19, 21, 22, 24, 25, 27, 28, 30, 21, 22, 24, 25, 27, 28, 30, 32, 22, 24, 25, 27, 28, 30, 32, 33, 24, 25, 27, 28, 30, 32, 33, 35]
+
+
+def test_cqm_init_in_library_matches_reference_tables(oracle_lib):
+    """x264hip_cqm_init (the library's host C restatement of x264_cqm_init, R/common/set.c:68-168) against the tables the REFERENCE's
+    x264_cqm_init produced (tests/golden/cqm_flat.npz, cqm_jvt.npz: oracle/gen_golden_cqm.py), flat and JVT matrices, every QP; the
+    unquant tables against the library's older x264hip_unquant_table and the twin's x264o_cqm_unquant."""
+    import ctypes as C
+    from x264_vs2008_amd import lib as L
+    from x264_vs2008_amd.frame import cqm_init
+    lib = L.open_library()
+    for name, lists, qp_min in (("cqm_flat", None, 0), ("cqm_jvt", [JVT4I, JVT4P, JVT4I, JVT4P, JVT8I, JVT8P], 6)):
+        t = cqm_init(lib, lists, qp_min=qp_min)
+        with np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")) as z:
+            for k in z.files:
+                assert np.array_equal(t[k], z[k]), (name, k)
+        preset = int(lists is not None)
+        for cat in range(4):
+            for qp in range(52):
+                unq = np.zeros(16, np.int32)
+                oracle_lib.x264o_cqm_unquant(preset, cat, qp, 0, unq.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(unq, t["unquant4_mf"][cat, qp]), (name, cat, qp)
+        for cat in range(2):
+            for qp in range(52):
+                unq = np.zeros(64, np.int32)
+                oracle_lib.x264o_cqm_unquant(preset, cat, qp, 1, unq.ctypes.data_as(C.c_void_p))
+                assert np.array_equal(unq, t["unquant8_mf"][cat, qp]), (name, cat, qp)
+    with pytest.raises(RuntimeError, match="overflow"):            # the JVT matrices below QP 6: "Quantization overflow", set.c:160-166
+        cqm_init(lib, [JVT4I, JVT4P, JVT4I, JVT4P, JVT8I, JVT8P], qp_min=0)
+
+
+def test_generated_cabac_tables_are_one_file():
+    """oracle/cabac_tables.h (twin) and csrc/cabac_tables.h (product) are both written by oracle/gen_cabac_tables.py: the data must not drift."""
+    import re
+    def body(path):
+        with open(path) as f:
+            return re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S).split()
+    a, b = body(os.path.join(ROOT, "oracle", "cabac_tables.h")), body(os.path.join(ROOT, "x264_vs2008_amd", "csrc", "cabac_tables.h"))
+    strip = lambda toks: [t for t in toks if t not in ("static", "__device__", "const", "__constant__")]
+    ints = lambda toks: re.findall(r"-?\d+", " ".join(toks))
+    assert ints(strip(a)) == ints(strip(b))
+
+
+def test_encode_clip_refuses_what_it_cannot_shard():
+    from x264_vs2008_amd import shard
+    with pytest.raises(ValueError):
+        shard.encode_clip(None, None, [(np.zeros((16, 16), np.uint8),) * 3], 4, lanes=1)

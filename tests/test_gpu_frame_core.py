@@ -101,3 +101,27 @@ def test_aq_var_and_ssd(ctx, hip_lib, oracle_lib):
         st = d.stride_c if i else d.stride_y
         want = oracle_lib.x264o_frame_ssd(ha.ptr(name), st, hb.ptr(name), st, d.width >> (i > 0), d.height >> (i > 0))
         assert ssd[i] == want, name
+
+
+@pytest.mark.parametrize("size,batch", [((200, 120), 3), ((352, 288), 2), ((1920, 1080), 1)])
+def test_synthetic_source_on_the_device_equals_the_host_generator(hip_lib, size, batch):
+    """x264hip_picture_synth (the bench's input: SURVEY 8(d)'s integer generator as a kernel) against x264_vs2008_amd/synth.py,
+    every visible pixel and the mod-16 padding, for several batch elements with their own frame numbers."""
+    from x264_vs2008_amd import synth
+    c = FrameCtx(hip_lib, *size, batch=batch)
+    try:
+        pic = c.new_picture(source_only=True)
+        t0, ts = 37, 12
+        c.synth(pic, t0, ts)
+        c.sync()
+        w, h = size
+        for b in range(batch):
+            want = synth.frame(w, h, t0 + b * ts)
+            for name, pl in zip(("y", "u", "v"), want):
+                got = c.download(pic, name, padded=False, b=b)
+                hh, ww = pl.shape
+                _eq(got[:hh, :ww], pl, "synth %s element %d" % (name, b))
+                # x264_frame_expand_border_mod16: the last column / row repeated up to the coded size
+                assert (got[:hh, ww:] == pl[:, -1:]).all() and (got[hh:, :ww] == pl[-1:, :]).all() and (got[hh:, ww:] == pl[-1, -1]).all()
+    finally:
+        c.close()

@@ -113,3 +113,32 @@ def test_b_frames_on_lanes_run_beside_the_next_anchor(hip_lib, cqm, name, size, 
         assert checked_b >= 2
     finally:
         enc.close()
+
+
+def test_source_only_picture_is_refused_as_a_reference_and_lanes_are_freed(hip_lib, cqm):
+    """A picture without half-pel planes (x264hip_picture_alloc_source) handed to the sweep as a reference is an error string, not a
+    device fault; and an encoder with lanes gives all of its device memory back on close() (allocate / close in a loop)."""
+    import ctypes as C
+    w, h = 208, 144
+    enc = sl.ChainEncoder(hip_lib, w, h, cqm, batch=1, write=1, qp=28, subme=5, me_method=1, n_refs=1, cabac=1, deblock=1)
+    try:
+        y = np.full((h, w), 90, np.uint8); u = np.full((h // 2, w // 2), 128, np.uint8)
+        enc.upload(y, u, u)
+        enc.encode_frame()
+        enc.finish_frame()
+        bad = enc.ctx.new_picture(source_only=True)
+        enc.refs[0] = (bad,) + tuple(enc.refs[0][1:])
+        with pytest.raises(RuntimeError, match="half-pel"):
+            enc.encode_frame()
+    finally:
+        enc.close()
+    hip_lib.x264hip_mem_info.restype = C.c_int
+    free = []
+    for it in range(4):
+        enc = sl.ChainEncoder(hip_lib, 352, 288, cqm, batch=4, write=1, lanes=3, bframes=3, qp=28, subme=7, me_method=1, n_refs=2, inter=0x113, intra=0x3,
+                              transform8x8=1, cabac=1, deblock=1, trellis=1, aq_mode=1)
+        enc.close()
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip_lib.x264hip_mem_info(C.byref(f), C.byref(t)) == 0
+        free.append(f.value)
+    assert free[-1] >= free[0] - (1 << 20), free          # nothing accumulates from one encoder to the next

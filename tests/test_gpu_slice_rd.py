@@ -121,8 +121,8 @@ def test_payload_only_states_and_a_full_payload_buffer(hip_lib, cqm):
             enc.finish_frame()
     finally:
         enc.close()
-    # (at QP 6 the first slice of this clip is far beyond the 2 KB such a buffer leaves before the guard's margin)
-    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, payload_cap=4096 + sl.PAYLOAD_LEAD, **dict(kw, qp=6), **ekw)
+    # (at QP 6 the first slice of this clip is far beyond the 2 KB such a buffer leaves before the guard's margin: one macroblock's proven worst case)
+    enc = sl.ChainEncoder(hip_lib, size[0], size[1], cqm, batch=1, write=1, payload_cap=8192 + 128 + 2048 + sl.PAYLOAD_LEAD, **dict(kw, qp=6), **ekw)
     try:
         enc.upload(y[0], u[0], v[0])
         enc.encode_frame()

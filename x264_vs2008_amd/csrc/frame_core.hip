@@ -30,6 +30,40 @@ __global__ void k_pad_mod16(u8 *p, int stride, int w, int h, int w16, int h16)
     p[y * stride + x] = p[sy * stride + sx];
 }
 
+// The integer-only synthetic I420 source of SURVEY.md 8(d) (x264_vs2008_amd/synth.py is the same generator on the host): a smooth
+// translating texture, a moving 64x64 box and +-3 LSB hash noise, uint32 wrap-around arithmetic.  Frame index of batch element b is
+// t0 + b * t_stride, so every (chain, display index) of a benchmark run is a picture of its own.  One dword (4 pixels) per thread;
+// columns / rows beyond the visible picture replicate its last column / row (x264_frame_expand_border_mod16).
+__device__ __forceinline__ int synth_tri(int v) { const int a = v & 255; return a < 128 ? a - 64 : 191 - a; }
+__device__ __forceinline__ int synth_noise(u32 x, u32 y, u32 t, u32 p, int amp)
+{
+    u32 h = x * 73856093u ^ y * 19349663u ^ t * 83492791u ^ p * 2654435761u ^ 1234u;
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    return (int)(h % (u32)(2 * amp + 1)) - amp;
+}
+__global__ __launch_bounds__(256) void k_synth_plane(u8 *pix, size_t bs, int stride, int plane, int w, int h, int w16, int h16, int full_w, int full_h,
+                                                     int t0, int t_stride)
+{
+    const int xq = (blockIdx.x * blockDim.x + threadIdx.x) * 4, yy = blockIdx.y;
+    if (xq >= w16) return;
+    const int t = t0 + (int)blockIdx.z * t_stride, y = yy < h ? yy : h - 1;
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = xq + i < w ? xq + i : w - 1;
+        int v;
+        if (plane == 0) {
+            v = 128 + (synth_tri((x + 3 * t) * 4) >> 1) + (synth_tri((y - 2 * t) * 6) >> 2) + (synth_tri((x + y + 5 * t) * 9) >> 3);
+            const int bx = (40 + 7 * t) % (full_w - 64), by = (30 + 3 * t) % (full_h - 64);
+            if (x >= bx && x < bx + 64 && y >= by && y < by + 64) v += synth_tri(x * 16) >> 1;
+            v += synth_noise((u32)x, (u32)y, (u32)t, 0, 3);
+        } else if (plane == 1) v = 128 + (synth_tri((x + 2 * t) * 3) >> 2) + synth_noise((u32)x, (u32)y, (u32)t, 1, 1);
+        else v = 128 + (synth_tri((y - t) * 5) >> 2) + synth_noise((u32)x, (u32)y, (u32)t, 2, 1);
+        out |= (u32)clip_u8(v) << (8 * i);
+    }
+    *(u32 *)(pix + bs * blockIdx.z + (size_t)yy * stride + xq) = out;
+}
+
 // plane_expand_border (R/common/frame.c:218-240) for the whole plane at once:
 // every padding byte takes the nearest interior pixel (left/right bands first,
 // then whole rows copied up/down, which is the same thing).
@@ -216,7 +250,7 @@ static int alloc_plane(u8 **out, int stride, int lines, int padh, int padv, int 
 {
     u8 *base = nullptr;
     HIPCHK(hipMalloc((void **)&base, bs * batch + 256));
-    HIPCHK(hipMemsetAsync(base, 0, bs * batch + 256, s));
+    if (zero_async(base, bs * batch + 256, s)) return -1;
     *out = base + (size_t)stride * padv + padh;
     return 0;
 }
@@ -339,6 +373,41 @@ extern "C" int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic
     // the caller owns y/u/v and may release them on return (they are usually
     // pageable): do not leave a DMA reading them in flight
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Synthetic source (k_synth_plane): element b of `pic` becomes frame t0 + b * t_stride of the SURVEY 8(d) clip, padded to the coded size.
+// Asynchronous on the context's stream.  Needs width, height >= 65 (the moving box).
+extern "C" int x264hip_picture_synth(x264hip_frame_ctx *c, x264hip_picture *pic, int t0, int t_stride)
+{
+    const x264hip_frame_dims &d = c->d;
+    if (d.width < 65 || d.height < 65 || t0 < 0 || t_stride < 0) { set_error("picture_synth: needs a picture larger than 64x64 and non-negative frame numbers"); return -1; }
+    for (int i = 0; i < 3; i++) {
+        const int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y, w16 = c->width16 >> !!i, h16 = c->lines16 >> !!i;
+        hipLaunchKernelGGL(k_synth_plane, dim3((w16 / 4 + 255) / 256, h16, c->batch), dim3(256), 0, c->stream, pic->plane[i], i ? c->bs_c : c->bs_y, st, i, w, h, w16, h16,
+                           d.width, d.height, t0, t_stride);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// host I420 -> device planes like x264hip_picture_upload, but asynchronous: the caller's buffers must be pinned (x264hip_host_alloc) and stay
+// untouched until the context's stream has passed this point (x264hip_sync / an event): frame ingest overlapped with the sweep of the frame before
+extern "C" int x264hip_picture_upload_async(x264hip_frame_ctx *c, x264hip_picture *pic, const uint8_t *y, int sy,
+                                            const uint8_t *u, int su, const uint8_t *v, int sv, void *hip_stream)
+{
+    const x264hip_frame_dims &d = c->d;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const u8 *src[3] = {y, u, v};
+    const int ss[3] = {sy, su, sv};
+    for (int i = 0; i < 3; i++) {
+        int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y;
+        u8 *dst = pic->plane[i] + (i ? c->bs_c : c->bs_y) * c->sel;
+        HIPCHK(hipMemcpy2DAsync(dst, st, src[i], ss[i], w, h, hipMemcpyHostToDevice, s));
+        int w16 = c->width16 >> !!i, h16 = c->lines16 >> !!i;
+        if (w16 != w || h16 != h)
+            hipLaunchKernelGGL(k_pad_mod16, dim3((w16 + 255) / 256, h16), dim3(256), 0, s, dst, st, w, h, w16, h16);
+    }
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -59,7 +59,7 @@ extern "C" int x264hip_mb_state_alloc_ex(x264hip_frame_ctx *c, x264hip_mb_state 
         {(void **)&st->mv1, 64 * n}, {(void **)&st->ref1, 4 * n}, {(void **)&st->mvr1, 4 * n}, {(void **)&st->mvd1, 64 * n}, {(void **)&st->skipbp, n}};
     for (auto &it : items) {
         if (no_levels && (it.p == (void **)&st->luma || it.p == (void **)&st->luma_dc || it.p == (void **)&st->chroma_dc || it.p == (void **)&st->chroma_ac)) continue;
-        if (hipMalloc(it.p, it.bytes) != hipSuccess || hipMemsetAsync(*it.p, 0, it.bytes, c->stream) != hipSuccess) {
+        if (hipMalloc(it.p, it.bytes) != hipSuccess || zero_async(*it.p, it.bytes, c->stream) != 0) {
             set_error("mb_state_alloc: %zu bytes", it.bytes);
             x264hip_mb_state_free(c, st);              // what was allocated so far
             return -1;
@@ -135,13 +135,18 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
     }
     if (p->qp < 0 || p->qp > 51) { set_error("slice_sweep: qp out of range"); return -1; }
+    if (is_p && p->subme >= 1) {        /* a source-only picture (x264hip_picture_alloc_source) has no half-pel planes: not a reference */
+        for (int i = 0; i < n_refs; i++)
+            if (!refs[i] || !refs[i]->filtered[1] || !refs[i]->filtered[2] || !refs[i]->filtered[3]) { set_error("slice_sweep: reference %d has no half-pel planes (a source-only picture?)", i); return -1; }
+        if (is_b && (!pb->fref1->filtered[1] || !pb->fref1->filtered[2] || !pb->fref1->filtered[3])) { set_error("slice_sweep: the list-1 reference has no half-pel planes (a source-only picture?)"); return -1; }
+    }
     const x264hip_slice_rd *prd = p->rd;
     const int mbrd = (p->subme - is_b >= 6) + (p->subme - is_b >= 8);       /* one level less in a B slice, R/encoder/analyse.c:222-225 */
     if (p->subme < 0 || p->subme > 7) { set_error("slice_sweep: subme %d (RD refinement of vectors and intra modes) not built", p->subme); return -1; }
     if (mbrd && (!prd || !prd->write || !p->cabac)) { set_error("slice_sweep: subme %d prices its trial encodes against the live CABAC contexts: it needs x264hip_slice_params.rd with write = 1 and cabac = 1", p->subme); return -1; }
     if (prd) {
         if (prd->write && !p->cabac) { set_error("slice_sweep: the in-loop entropy coder is CABAC only"); return -1; }
-        if (prd->write && (!prd->payload || !prd->payload_len || prd->payload_cap < 4096)) { set_error("slice_sweep: payload buffers missing"); return -1; }
+        if (prd->write && (!prd->payload || !prd->payload_len || prd->payload_cap < SW_MB_BYTES_MAX + 128)) { set_error("slice_sweep: payload buffers missing or smaller than one macroblock's worst case (%d bytes)", SW_MB_BYTES_MAX + 128); return -1; }
         if (prd->trellis && (!prd->write || !prd->unquant4_mf || (p->transform8x8 && !prd->unquant8_mf))) { set_error("slice_sweep: trellis needs write = 1 and the unquant tables"); return -1; }
         if (prd->trellis < 0 || prd->trellis > 2) { set_error("slice_sweep: trellis %d", prd->trellis); return -1; }
         if (prd->aq_offset && !prd->cost_mv_all) { set_error("slice_sweep: adaptive quantisation needs cost_mv_all"); return -1; }

@@ -34,4 +34,7 @@ struct ThreadCtx {
 };
 ThreadCtx *thread_ctx();         // lazily created; aborts loudly if HIP is unusable
 
+// device fill with zeros in pieces of at most 1 GiB (one fill kernel over several GiB is what rocprofv3 --pmc of ROCm 7.2 was seen to die in)
+int zero_async(void *dev, size_t bytes, hipStream_t s);
+
 }  // namespace x264hip

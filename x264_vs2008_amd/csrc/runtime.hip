@@ -61,6 +61,14 @@ ThreadCtx *thread_ctx()
     return &ctx;
 }
 
+int zero_async(void *dev, size_t bytes, hipStream_t s)
+{
+    const size_t piece = (size_t)1 << 30;
+    for (size_t o = 0; o < bytes; o += piece)
+        HIPCHK(hipMemsetAsync((char *)dev + o, 0, bytes - o < piece ? bytes - o : piece, s));
+    return 0;
+}
+
 }  // namespace x264hip
 
 using namespace x264hip;
@@ -114,7 +122,7 @@ extern "C" void *x264hip_malloc(size_t bytes)
     void *p = nullptr;
     if (!initialised() || hipSetDevice(g_device) != hipSuccess) return nullptr;
     if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
-    (void)hipMemset(p, 0, bytes);
+    (void)zero_async(p, bytes, nullptr);
     (void)hipDeviceSynchronize();      // the frame contexts' streams are non-blocking: nothing may touch the buffer before the clear has landed
     return p;
 }
@@ -155,6 +163,68 @@ extern "C" void x264hip_unquant_table(const int32_t *quant_mf6, int n_cat, int n
             for (int i = 0; i < n; i++)
                 out[((size_t)c * 52 + q) * n + i] = (int32_t)((1ULL << (q / 6 + (n == 64 ? 16 : 15) + 8)) / (uint64_t)quant_mf6[((size_t)c * 6 + q % 6) * n + i]);
 }
+
+// x264_cqm_init (R/common/set.c:68-168): the quantiser / dequantiser / unquant tables of every QP from the six scaling lists of the PPS
+// (4x4 intra Y, inter Y, intra C, inter C; 8x8 intra Y, inter Y -- raster order, NULL = flat 16) and the two luma dead zones
+// (param.analyse.i_luma_deadzone: {inter, intra}, default {21, 11}).  Integer arithmetic only.  Returns 0, or -1 with the error string
+// set when a multiplier overflows 16 bits at a QP >= qp_min ("Quantization overflow", set.c:160-166): such a matrix set needs a larger qp_min.
+extern "C" int x264hip_cqm_init(const uint8_t *const scaling_list[6], const int luma_deadzone[2], int qp_min, x264hip_cqm_tables *t)
+{
+    static const int dequant4_scale[6][3] = {{10, 13, 16}, {11, 14, 18}, {13, 16, 20}, {14, 18, 23}, {16, 20, 25}, {18, 23, 29}};
+    static const int quant4_scale[6][3] = {{13107, 8066, 5243}, {11916, 7490, 4660}, {10082, 6554, 4194}, {9362, 5825, 3647}, {8192, 5243, 3355}, {7282, 4559, 2893}};
+    static const int quant8_scan[16] = {0, 3, 4, 3, 3, 1, 5, 1, 4, 5, 2, 5, 3, 1, 5, 1};
+    static const int dequant8_scale[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                             {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+    static const int quant8_scale[6][6] = {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290},
+                                           {10082, 8943, 15978, 9675, 12710, 11985}, {9362, 8228, 14913, 8931, 11984, 11259},
+                                           {8192, 7346, 13159, 7740, 10486, 9777}, {7282, 6428, 11570, 6830, 9118, 8640}};
+    const int dz_inter = luma_deadzone ? luma_deadzone[0] : 21, dz_intra = luma_deadzone ? luma_deadzone[1] : 11;
+    const int deadzone[4] = {32 - dz_intra, 32 - dz_inter, 32 - 11, 32 - 21};
+    auto sl = [&](int l, int i) -> int { return scaling_list && scaling_list[l] ? scaling_list[l][i] : 16; };
+    auto div_round = [](int n, int d) { return (n + (d >> 1)) / d; };
+    auto shift_round = [](int x, int sh) { return sh < 0 ? x << -sh : sh == 0 ? x : (x + (1 << (sh - 1))) >> sh; };
+    static int q4[4][6][16], q8[2][6][64];
+    int max_qp_err = -1;
+    for (int l = 0; l < 6; l++)
+        for (int i = 0; i < (l < 4 ? 16 : 64); i++)
+            if (sl(l, i) < 1) { set_error("cqm_init: scaling list %d has a zero entry", l); return -1; }
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int q = 0; q < 6; q++) {
+        for (int l = 0; l < 4; l++)
+            for (int i = 0; i < 16; i++) {
+                const int j = (i & 1) + ((i >> 2) & 1);
+                t->dequant4_mf[l][q][i] = dequant4_scale[q][j] * sl(l, i);
+                q4[l][q][i] = div_round(quant4_scale[q][j] * 16, sl(l, i));
+            }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 64; i++) {
+                const int j = quant8_scan[((i >> 1) & 12) | (i & 3)];
+                t->dequant8_mf[l][q][i] = dequant8_scale[q][j] * sl(4 + l, i);
+                q8[l][q][i] = div_round(quant8_scale[q][j] * 16, sl(4 + l, i));
+            }
+    }
+    for (int q = 0; q < 52; q++) {
+        for (int l = 0; l < 4; l++)
+            for (int i = 0; i < 16; i++) {
+                const int j = shift_round(q4[l][q % 6][i], q / 6 - 1), b = div_round(deadzone[l] << 10, j), m = (1 << 15) / j;
+                t->unquant4_mf[l][q][i] = (int32_t)((1ULL << (q / 6 + 15 + 8)) / (uint64_t)q4[l][q % 6][i]);
+                t->quant4_mf[l][q][i] = (uint16_t)j;
+                t->quant4_bias[l][q][i] = (uint16_t)(b < m ? b : m);
+                if (j > 0xffff && q > max_qp_err) max_qp_err = q;
+            }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 64; i++) {
+                const int j = shift_round(q8[l][q % 6][i], q / 6), b = div_round(deadzone[l] << 10, j), m = (1 << 15) / j;
+                t->unquant8_mf[l][q][i] = (int32_t)((1ULL << (q / 6 + 16 + 8)) / (uint64_t)q8[l][q % 6][i]);
+                t->quant8_mf[l][q][i] = (uint16_t)j;
+                t->quant8_bias[l][q][i] = (uint16_t)(b < m ? b : m);
+                if (j > 0xffff && q > max_qp_err) max_qp_err = q;
+            }
+    }
+    if (max_qp_err >= qp_min) { set_error("cqm_init: quantisation overflow -- these matrices need QP >= %d, qp_min is %d", max_qp_err + 1, qp_min); return -1; }
+    return 0;
+}
 extern "C" void x264hip_free(void *p) { if (p) (void)hipFree(p); }
 extern "C" int x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
@@ -164,6 +234,44 @@ extern "C" int x264hip_memcpy_h2d(void *dst_dev, const void *src_host, size_t by
 extern "C" int x264hip_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+// pinned host memory and asynchronous copies on a caller-named stream: frame ingest / payload egress that overlaps the kernels
+// (the staging x264's muxers do with malloc'ed buffers, R/muxers.c:63-130; here the DMA engines read / write them directly)
+extern "C" void *x264hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (!initialised() || hipSetDevice(g_device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void x264hip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int x264hip_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *hip_stream)
+{
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    return 0;
+}
+extern "C" int x264hip_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, void *hip_stream)
+{
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    return 0;
+}
+extern "C" int x264hip_mem_info(size_t *free_bytes, size_t *total_bytes)
+{
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return 0;
+}
+extern "C" void *x264hip_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    if (!initialised() || hipSetDevice(g_device) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return (void *)s;
+}
+extern "C" void x264hip_stream_destroy(void *s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+extern "C" int x264hip_stream_synchronize(void *s)
+{
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
     return 0;
 }
 extern "C" int x264hip_device_synchronize(void)

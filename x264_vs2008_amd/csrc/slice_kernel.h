@@ -41,6 +41,11 @@ using namespace x264hip;
 
 #define SW_MAX_REFS 8
 #define SW_SPIN_LIMIT (1 << 21)
+// Most bytes one macroblock's CABAC syntax can take, proven rather than observed: 384 coefficients x (significance + last flag + 14 prefix
+// bins, each at most -log2(0.01875) < 6 bits when it is the least probable symbol of the most skewed state, + 31 bypass bins of the
+// Exp-Golomb suffix of a 16-bit level + the sign) = 384 x 128 bits = 6144 bytes, + under 400 bytes of header, modes, vector differences
+// of 16 blocks x 2 lists; I_PCM is 384.  The sweep stops (abort flag) before a macroblock that might not fit.
+#define SW_MB_BYTES_MAX 8192
 #define FD 32                      // FDEC_STRIDE
 #define FDY (2 * FD)               // fdec_buf layout, R/common/macroblock.c:721-737
 #define FDU (19 * FD)
@@ -2461,7 +2466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     }
                     const int pos = cd_pos(cab, payload0);
                     if (rd.mb_bits) rd.mb_bits[cb + mb] = pos;
-                    sr.tmp_i[2] = (pos >> 3) + 2048 + 64 > rd.payload_cap;      // the next macroblock may not fit (the twin's rule, oracle/slice_oracle.c)
+                    sr.tmp_i[2] = (pos >> 3) + SW_MB_BYTES_MAX + 64 > rd.payload_cap;      // the next macroblock (and the flush) may not fit
                 }
                 WAVE_SYNC();
                 if (UNI(sr.tmp_i[2])) {          // out of payload space: never write past the chain's buffer; the frame is reported aborted

@@ -122,6 +122,10 @@ class FrameCtx:
     def copy_element(self, dst, dst_b, src, src_b):
         self.check(self.lib.x264hip_picture_copy_element(self.h, C.byref(dst), C.c_int(dst_b), C.byref(src), C.c_int(src_b)), "picture_copy_element")
 
+    def synth(self, pic, t0, t_stride=0):
+        """Element b of `pic` becomes frame t0 + b * t_stride of the synthetic clip (x264hip_picture_synth; synth.frame on the device)."""
+        self.check(self.lib.x264hip_picture_synth(self.h, C.byref(pic), C.c_int(t0), C.c_int(t_stride)), "picture_synth")
+
     def select(self, b):
         """Choose the batch element that upload / download / x264hip_ssd_frame address."""
         self.check(self.lib.x264hip_frame_ctx_select(self.h, b), "frame_ctx_select")
@@ -195,6 +199,39 @@ class CqmDevice:
     def free(self):
         for v in self.bufs.values():
             v.free()
+
+
+class CqmTables(C.Structure):
+    """x264hip_cqm_tables (include/x264hip.h)."""
+    _fields_ = [("quant4_mf", C.c_uint16 * (4 * 52 * 16)), ("quant4_bias", C.c_uint16 * (4 * 52 * 16)),
+                ("quant8_mf", C.c_uint16 * (2 * 52 * 64)), ("quant8_bias", C.c_uint16 * (2 * 52 * 64)),
+                ("dequant4_mf", C.c_int32 * (4 * 6 * 16)), ("dequant8_mf", C.c_int32 * (2 * 6 * 64)),
+                ("unquant4_mf", C.c_int32 * (4 * 52 * 16)), ("unquant8_mf", C.c_int32 * (2 * 52 * 64))]
+
+
+CQM_SHAPES = {"quant4_mf": (4, 52, 16), "quant4_bias": (4, 52, 16), "quant8_mf": (2, 52, 64), "quant8_bias": (2, 52, 64),
+              "dequant4_mf": (4, 6, 16), "dequant8_mf": (2, 6, 64), "unquant4_mf": (4, 52, 16), "unquant8_mf": (2, 52, 64)}
+
+
+def cqm_init(lib, scaling_lists=None, luma_deadzone=None, qp_min=0):
+    """The quantiser tables from the library's x264hip_cqm_init (x264_cqm_init, R/common/set.c:68-168): a dict of numpy arrays with the
+    layout of h->quant4_mf ... h->unquant8_mf.  scaling_lists: six raster-order lists (4x4 intra Y, inter Y, intra C, inter C, 8x8
+    intra Y, inter Y) or None for flat matrices.  Needs no GPU."""
+    t = CqmTables()
+    lists = None
+    keep = []
+    if scaling_lists is not None:
+        arr = (C.POINTER(C.c_uint8) * 6)()
+        for i, l in enumerate(scaling_lists):
+            a = np.ascontiguousarray(l, dtype=np.uint8)
+            assert a.size == (16 if i < 4 else 64)
+            keep.append(a)
+            arr[i] = a.ctypes.data_as(C.POINTER(C.c_uint8))
+        lists = arr
+    dz = (C.c_int * 2)(*luma_deadzone) if luma_deadzone is not None else None
+    if lib.x264hip_cqm_init(lists, dz, C.c_int(qp_min), C.byref(t)) != 0:
+        raise RuntimeError("x264hip_cqm_init failed: %s" % lib.x264hip_last_error().decode())
+    return {k: np.ctypeslib.as_array(getattr(t, k)).reshape(shape).copy() for k, shape in CQM_SHAPES.items()}
 
 
 def host_plane(stride, lines, padh, padv):

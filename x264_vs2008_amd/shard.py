@@ -46,6 +46,8 @@ def encode_clip(hip, cqm, frames, keyint, rank=0, world=1, **options):
     only stream-global quantity in a slice's data, the padding bit x264_cabac_encode_flush derives from the number of frames
     coded so far (R/common/cabac.c:918), is given to the kernel per chain (x264hip_slice_rd.i_frame_stride)."""
     from . import slice as sl
+    if options.get("lanes"):
+        raise ValueError("encode_clip: lanes are a scheduling option of single-stream chains, not of a sharded clip")
     n = len(frames)
     gops = gop_bounds(n, keyint)
     mine = [i for i in range(len(gops)) if i % world == rank]

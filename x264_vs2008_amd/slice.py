@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from .frame import CqmDevice, DeblockParams, DeviceArray, FrameCtx, cost_mv_table
+from .frame import CqmDevice, DeblockParams, DeviceArray, FrameCtx
 
 SLICE_P, SLICE_B, SLICE_I = 0, 1, 2
 I_4x4, I_8x8, I_16x16, I_PCM, P_L0, P_8x8, P_SKIP = range(7)
@@ -47,6 +47,7 @@ class SliceRd(C.Structure):
 
 
 PAYLOAD_LEAD = 64
+MB_BYTES_MAX = 8192          # SW_MB_BYTES_MAX (csrc/slice_kernel.h): the sweep stops before a macroblock whose worst case might not fit
 
 
 class SliceParams(C.Structure):
@@ -154,18 +155,21 @@ class ChainEncoder:
         if self.raster:
             d, B = self.ctx.dims, batch
             n = d.mb_w * d.mb_h
-            cap = payload_cap or (n * 800 + 4096 + PAYLOAD_LEAD)
+            cap = payload_cap or (n * 800 + MB_BYTES_MAX + 128 + PAYLOAD_LEAD)
             rb = self._frame_bufs(B, n, cap, aq_mode)
             # p_cost_mv of every QP and the unquant tables, built by the library's host C (x264hip_cost_mv_table / _unquant_table)
             tabs = np.zeros((52, 2 * COST_SPAN + 1), np.int16)
             for q in range(52):
                 lib.x264hip_cost_mv_table(C.c_int(LAMBDA_TAB[q]), C.c_int(COST_SPAN), tabs[q].ctypes.data_as(C.c_void_p))
             rb["cost_mv_all"] = DeviceArray(lib, tabs.shape, np.int16, tabs)
-            q4 = np.ascontiguousarray(cqm["quant4_mf"][:, 6:12, :].astype(np.int32))       # the shift is zero at qp 6..11 (4x4) / 0..5 (8x8)
-            q8 = np.ascontiguousarray(cqm["quant8_mf"][:, 0:6, :].astype(np.int32))
-            u4, u8 = np.zeros((4, 52, 16), np.int32), np.zeros((2, 52, 64), np.int32)
-            lib.x264hip_unquant_table(q4.ctypes.data_as(C.c_void_p), C.c_int(4), C.c_int(16), u4.ctypes.data_as(C.c_void_p))
-            lib.x264hip_unquant_table(q8.ctypes.data_as(C.c_void_p), C.c_int(2), C.c_int(64), u8.ctypes.data_as(C.c_void_p))
+            if "unquant4_mf" in cqm:                   # tables from frame.cqm_init (x264hip_cqm_init): complete
+                u4, u8 = np.ascontiguousarray(cqm["unquant4_mf"], np.int32), np.ascontiguousarray(cqm["unquant8_mf"], np.int32)
+            else:                                      # a table set without them (the reference's x264_cqm_init output as the tests hold it)
+                q4 = np.ascontiguousarray(cqm["quant4_mf"][:, 6:12, :].astype(np.int32))       # the shift is zero at qp 6..11 (4x4) / 0..5 (8x8)
+                q8 = np.ascontiguousarray(cqm["quant8_mf"][:, 0:6, :].astype(np.int32))
+                u4, u8 = np.zeros((4, 52, 16), np.int32), np.zeros((2, 52, 64), np.int32)
+                lib.x264hip_unquant_table(q4.ctypes.data_as(C.c_void_p), C.c_int(4), C.c_int(16), u4.ctypes.data_as(C.c_void_p))
+                lib.x264hip_unquant_table(q8.ctypes.data_as(C.c_void_p), C.c_int(2), C.c_int(64), u8.ctypes.data_as(C.c_void_p))
             rb["unquant4_mf"] = DeviceArray(lib, u4.shape, np.int32, u4)
             rb["unquant8_mf"] = DeviceArray(lib, u8.shape, np.int32, u8)
             # x264hip_slice_rd.stale: the motion-cache entry that survives macroblocks and frames (read when temporal direct prediction
@@ -226,9 +230,10 @@ class ChainEncoder:
             ln["ctx"].sync()
 
     def cost_table(self, qp):
-        if qp not in self.cost:
-            tab = cost_mv_table(LAMBDA_TAB[qp], COST_SPAN)
-            self.cost[qp] = DeviceArray(self.lib, tab.shape, np.uint16, tab)
+        if qp not in self.cost:                        # p_cost_mv of this QP from the library's host C (x264hip_cost_mv_table), as cost_mv_all
+            tab = np.zeros(2 * COST_SPAN + 1, np.int16)
+            self.lib.x264hip_cost_mv_table(C.c_int(LAMBDA_TAB[qp]), C.c_int(COST_SPAN), tab.ctypes.data_as(C.c_void_p))
+            self.cost[qp] = DeviceArray(self.lib, tab.shape, np.int16, tab)
         return self.cost[qp]
 
     @property
@@ -367,6 +372,14 @@ class ChainEncoder:
         raw = rb["payload"].get()
         return [bytes(raw[b, PAYLOAD_LEAD:PAYLOAD_LEAD + n[b]]) for b in range(len(n))]
 
+    def payload_async(self, b, host_len, host_buf, nbytes):
+        """Enqueue, behind the sweep just launched, the copy of chain b's payload length and of the first `nbytes` bytes of its payload
+        into pinned host memory (x264hip_host_alloc): no synchronisation, the bytes are there once the stream has passed this point."""
+        rb = getattr(self, "last_bufs", None) or self.rd_bufs
+        st = C.c_void_p(self.last_ctx.stream)
+        self.lib.x264hip_memcpy_d2h_async(C.c_void_p(host_len), C.c_void_p(rb["payload_len"].ptr + 4 * b), C.c_size_t(4), st)
+        self.lib.x264hip_memcpy_d2h_async(C.c_void_p(host_buf), C.c_void_p(rb["payload"].ptr + self.payload_cap * b + PAYLOAD_LEAD), C.c_size_t(nbytes), st)
+
     def status(self):
         c = self.ctx
         if getattr(self, "last", None) is None:          # nothing launched yet
@@ -384,6 +397,12 @@ class ChainEncoder:
         if self.nr:
             self.lib.x264hip_nr_state_free(self.ctx.h, C.byref(self.nr))
             self.nr = None
+        for ln in self.lanes:                  # each lane's payload / AQ buffers, state, reconstruction and stream
+            for d in ln["bufs"].values():
+                d.free()
+            ln["state"].free()
+            ln["ctx"].close()
+        self.lanes = []
         for s in self.states:
             s.free()
         for d in self.cost.values():

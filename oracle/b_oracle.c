@@ -14,6 +14,8 @@
  * x264 core 66 uses no B partition smaller than 8x8; the B frames of a chain are disposable (no b-pyramid): one list-1 picture. */
 
 typedef struct { pme me16, me8[4], me16x8[2], me8x16[2]; int i_ref, rd16; } blist;
+static void intra_rd_refine(ssl *S, smb *m);                       /* refine_oracle.c */
+static void refine_b_rd(ssl *S, smb *m, panalysis *A);
 struct banalysis {
     blist l[2];
     int direct_available;
@@ -696,5 +698,7 @@ static void analyse_b(ssl *S, smb *m, panalysis *A, int satd_pcm)
     if (m->satd_i4 < i_cost) { i_cost = m->satd_i4; i_type = S_I_4x4; }
     if (satd_pcm < i_cost) { i_cost = satd_pcm; i_type = S_I_PCM; }
     m->type = i_type; m->partition = i_partition;
+    if (S->mbrd >= 2 && S_IS_INTRA(i_type) && i_type != S_I_PCM) intra_rd_refine(S, m);     /* :2702-2703 */
     if (p->subme >= 5) refine_bidir(S, m, B);
+    if (S->mbrd >= 2) refine_b_rd(S, m, A);                                                    /* :2707-2758 */
 }

@@ -505,3 +505,60 @@ static void cw_macroblock(ssl *S, o_cabac *cb, int rd, smb *m)
         if (m->cbp_chroma & 2) for (int i = 16; i < 24; i++) cw_residual(cb, rd, m, 4, i, m->cac[i - 16] + 1, 15);
     }
 }
+
+/* ------------------------------------------------------------------ the RD-only partial writers, R/encoder/cabac.c:1024-1126
+ * (bit counting only: "doesn't write cbp or chroma dc, doesn't write ref or subpartition") */
+static void cw_partition_size(const ssl *S, o_cabac *cb, smb *m, int i8, int pix)
+{   /* x264_partition_size_cabac, :1032-1081 */
+    static const u8 pix_h[7] = {16, 8, 16, 8, 4, 8, 4};
+    const int b_8x16 = m->partition == S_D_8x16;
+    (void)S;
+    if (m->type == S_P_8x8) cw_mb8x8_mvd(cb, 1, m, i8);
+    else if (m->type == S_P_L0) cw_mvd(cb, 1, m, 4 * i8, 4 >> b_8x16, 2 << b_8x16);
+    else if (m->type > S_B_DIRECT && m->type < S_B_8x8) {
+        if (b_type_uses(m->type, 0, !!i8)) cw_mvd_l(cb, 1, m, 0, 4 * i8, 4 >> b_8x16, 2 << b_8x16);
+        if (b_type_uses(m->type, 1, !!i8)) cw_mvd_l(cb, 1, m, 1, 4 * i8, 4 >> b_8x16, 2 << b_8x16);
+    } else if (m->type == S_B_8x8) {
+        for (int l = 0; l < 2; l++) if (b_sub_uses(m->sub[i8], l)) cw_mvd_l(cb, 1, m, l, 4 * i8, 2, 2);      /* x264_cabac_mb8x8_mvd: no B partition below 8x8 */
+    } else
+        return;
+    for (int j = pix < X264HIP_PIXEL_8x8; j >= 0; j--) {
+        if (m->cbp_luma & (1 << i8)) {
+            if (m->t8) cw_residual(cb, 1, m, 5, 4 * i8, m->luma8[i8], 64);
+            else for (int i4 = 0; i4 < 4; i4++) cw_residual(cb, 1, m, 2, i4 + 4 * i8, m->luma4[i4 + 4 * i8], 16);
+        }
+        cw_residual(cb, 1, m, 4, 16 + i8, m->cac[i8] + 1, 15);
+        cw_residual(cb, 1, m, 4, 20 + i8, m->cac[4 + i8] + 1, 15);
+        i8 += pix_h[pix] >> 3;
+    }
+}
+static void cw_subpartition_size(o_cabac *cb, smb *m, int i4, int pix)
+{   /* x264_subpartition_size_cabac, :1083-1095 */
+    const int b_8x4 = pix == X264HIP_PIXEL_8x4;
+    cw_residual(cb, 1, m, 2, i4, m->luma4[i4], 16);
+    if (pix == X264HIP_PIXEL_4x4) cw_mvd(cb, 1, m, i4, 1, 1);
+    else {
+        cw_mvd(cb, 1, m, i4, 1 + b_8x4, 2 - b_8x4);
+        cw_residual(cb, 1, m, 2, i4 + 2 - b_8x4, m->luma4[i4 + 2 - b_8x4], 16);
+    }
+}
+static void cw_partition_i8x8_size(o_cabac *cb, smb *m, int i8, int mode)
+{   /* x264_partition_i8x8_size_cabac, :1097-1105 */
+    cw_intra4x4_pred_mode(cb, 1, pred_intra4x4_mode(m, 4 * i8), s_fix4[mode + 1]);
+    cw_cbp_luma(cb, 1, m);
+    if (m->cbp_luma & (1 << i8)) cw_residual(cb, 1, m, 5, 4 * i8, m->luma8[i8], 64);
+}
+static void cw_partition_i4x4_size(o_cabac *cb, smb *m, int i4, int mode)
+{   /* x264_partition_i4x4_size_cabac, :1107-1113 */
+    cw_intra4x4_pred_mode(cb, 1, pred_intra4x4_mode(m, i4), s_fix4[mode + 1]);
+    cw_residual(cb, 1, m, 2, i4, m->luma4[i4], 16);
+}
+static void cw_i8x8_chroma_size(o_cabac *cb, smb *m)
+{   /* x264_i8x8_chroma_size_cabac, :1115-1131 */
+    cw_chroma_pred_mode(cb, 1, m);
+    cw_cbp_chroma(cb, 1, m);
+    if (m->cbp_chroma > 0) {
+        cw_residual(cb, 1, m, 3, 25, m->cdc[0], 4); cw_residual(cb, 1, m, 3, 26, m->cdc[1], 4);
+        if (m->cbp_chroma == 2) for (int i = 16; i < 24; i++) cw_residual(cb, 1, m, 4, i, m->cac[i - 16] + 1, 15);
+    }
+}

@@ -20,3 +20,14 @@ extern "C" int devhost_trellis(int16_t *dct, const uint16_t *mf, const int *unq,
     TrellisScratch ts;
     return td_trellis_quant(ts, dct, mf, unq, weight, zz, st, cat, lambda2, b_ac, dc, n_coef);
 }
+
+// the RD-only partial writers: kind 0 partition_size(i8, pix), 1 subpartition_size(i4, pix), 2 partition_i8x8_size(i8, mode),
+// 3 partition_i4x4_size(i4, mode), 4 i8x8_chroma_size
+extern "C" void devhost_cw_part(DCabac *cb, uint8_t *st, MbSyn *m, int kind, int a, int b)
+{
+    if (kind == 0) cw_partition_size(*cb, st, *m, a, b);
+    else if (kind == 1) cw_subpartition_size(*cb, st, *m, a, b);
+    else if (kind == 2) cw_partition_i8x8_size(*cb, st, *m, a, b);
+    else if (kind == 3) cw_partition_i4x4_size(*cb, st, *m, a, b);
+    else cw_i8x8_chroma_size(*cb, st, *m);
+}

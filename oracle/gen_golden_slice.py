@@ -51,6 +51,7 @@ CASES = [
 # (subme 6 / 7), trellis, psy-rd, adaptive quantisation.  (name, size, frames, clip kind, parameters, ext parameters)
 MED = dict(me_method=rs.ME_HEX, n_refs=3, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
 MEDB = dict(MED, inter=0x113, n_refs=2)       # + X264_ANALYSE_BSUB16x16
+SLOW = dict(me_method=rs.ME_UMH, n_refs=5, inter=0x13, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1, deblock=1)
 CASES2 = [
     ("w_medium_ip", (208, 144), 4, "static", dict(qp=26, subme=5, **MED), dict()),                          # the round-1 medium-like chain, now with its payload
     ("rd6", (208, 144), 4, "moving", dict(qp=28, subme=6, **MED), dict()),
@@ -75,6 +76,21 @@ CASES2 = [
     ("lowres_p", (208, 144), 5, "moving", dict(qp=27, subme=7, **MED), dict(trellis=1, psy_rd=1.0, aq_mode=1, lowres_seed=1)),
     ("lowres_b", (208, 144), 8, "moving", dict(qp=25, subme=7, **MEDB), dict(trellis=1, psy_rd=1.0, bframes=3, weightb=1, direct_pred=1, lowres_seed=2)),
     ("lowres_bt", (200, 120), 7, "static", dict(qp=29, subme=6, **MEDB), dict(trellis=1, bframes=2, weightb=0, direct_pred=2, lowres_seed=3)),
+    # round 3: the RD refinement of subme 8-9 (x264_me_refine_qpel_rd, x264_intra_rd_refine).  SLOW = BASELINE's "slow" flag set at
+    # constant QP: --ref 5 --me umh --subme 8 --8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --weightb --mixed-refs --direct spatial
+    ("rd8_slow_ip", (208, 144), 6, "moving", dict(qp=26, subme=8, **SLOW), dict(trellis=1, psy_rd=1.0, aq_mode=1)),
+    ("rd8_t2_psy0", (200, 120), 4, "static", dict(qp=30, subme=8, **MED), dict(trellis=2, psy_rd=0.0)),
+    ("rd9_ip", (208, 144), 4, "moving", dict(qp=22, subme=9, **MED), dict(trellis=1, psy_rd=1.0)),
+    ("rd8_b_slow", (208, 144), 8, "moving", dict(qp=26, subme=8, **dict(SLOW, inter=0x113)), dict(trellis=1, psy_rd=1.0, aq_mode=1, bframes=3, weightb=1, direct_pred=1)),
+]
+# chains that pin the TWIN only (the kernel refuses them and says so): B slices at subme 9 (x264_me_refine_bidir_rd and the list-1 forms of
+# x264_me_refine_qpel_rd), sub-8x8 partitions under the RD levels (x264_rd_cost_subpart, x264_macroblock_encode_p4x4)
+CASES2_TWIN = [
+    ("rd9_b", (208, 144), 7, "moving", dict(qp=27, subme=9, **MEDB), dict(trellis=1, psy_rd=1.0, bframes=2, weightb=1, direct_pred=1)),
+    ("rd9_b_temporal", (200, 120), 7, "static", dict(qp=30, subme=9, **MEDB), dict(trellis=2, psy_rd=0.0, bframes=3, weightb=0, direct_pred=2)),
+    ("rd8_sub8x8", (208, 144), 4, "moving", dict(qp=24, subme=8, **dict(MED, inter=0x33)), dict(trellis=1, psy_rd=1.0)),
+    ("rd9_sub8x8_nodec", (96, 120), 4, "static", dict(qp=21, subme=9, me_method=rs.ME_HEX, me_range=8, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1, cabac=1,
+                                                       deblock=1, dct_decimate=0, chroma_me=0, keyint=4, chroma_qp_offset=-3), dict(trellis=1, psy_rd=1.0)),
 ]
 
 
@@ -113,7 +129,7 @@ def masked2(a):
 
 def main():
     only = sys.argv[1:]                      # optional: regenerate just the named chains
-    for name, size, frames, kind, kw, ekw in CASES2:
+    for name, size, frames, kind, kw, ekw in CASES2 + CASES2_TWIN:
         if only and name not in only:
             continue
         p = rs.make_params(size[0], size[1], frames, **kw)

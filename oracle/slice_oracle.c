@@ -10,9 +10,9 @@
  * followed per frame by the loop filter, border expansion and half-pel planes (the twins above).
  * Supported: every I, P and B macroblock type x264 core 66 produces (I_16x16 / I_4x4 / I_8x8 / I_PCM, P_SKIP, P 16x16 .. 4x4 over
  * several references, B_SKIP / B_DIRECT (spatial and temporal) / B 16x16, 16x8, 8x16, 8x8 with list 0, list 1 and bi-prediction,
- * weighted bi-prediction), the 8x8 transform, DIA / HEX / UMH / ESA, subme 0..7 (mode-decision RD, cabac_oracle.c / rd_oracle.c /
- * b_oracle.c), trellis 1 and 2, psy-rd, adaptive quantisation, --nr, lossless, the CABAC writer.  Not yet: subme 8-9 (RD refinement),
- * psy-trellis, CAVLC with the RD levels, B pyramid, adaptive B placement.  Pinned against the reference's own functions by
+ * weighted bi-prediction), the 8x8 transform, DIA / HEX / UMH / ESA, subme 0..9 (mode-decision RD: cabac_oracle.c / rd_oracle.c /
+ * b_oracle.c; RD refinement of vectors and intra modes, sub-8x8 partitions under the RD levels: refine_oracle.c), trellis 1 and 2, psy-rd,
+ * adaptive quantisation, --nr, lossless, the CABAC writer.  Not yet: psy-trellis, CAVLC with the RD levels, B pyramid, adaptive B placement.  Pinned against the reference's own functions by
  * tests/test_oracle_slice.py (oracle/ref_slice.c runs them for the same inputs).               */
 #include <math.h>
 #include <stdio.h>
@@ -202,6 +202,11 @@ typedef struct {
      * whatever frame) left it, is what x264_mb_predict_mv_ref16x16 reads as its "direct" candidate when temporal direct prediction
      * gave up before writing it */
     int8_t stale_ref[2]; i16 stale_mv[2][2];
+    /* ... and so are the macroblock's own entries of h->mb.cache.non_zero_count and h->mb.cache.mvd: x264_macroblock_cache_load only
+     * rewrites the neighbours' entries.  A full trial encode writes all of its own before anything reads them, but the PARTIAL trials of
+     * the RD refinement / sub-8x8 RD (x264_rd_cost_part: one 8x8 block encoded and priced) read the blocks beside theirs -- whatever the
+     * last trial, or the previous macroblock (of whatever frame), left there (the reference's own FIXME, analyse.c:1976-1977) */
+    u8 carry_nnz[27]; i16 carry_mvd[2][16][2];
 } ssl;
 
 typedef struct {
@@ -223,6 +228,8 @@ typedef struct {
     i16 pskip_mv[2];
     /* analysis */
     int satd_i16, satd_i8, satd_i4, satd_chroma, fast_intra, pred16, pred8[4], pred4[16], predc;
+    int satd_i16_dir[7], satd_c_dir[4], satd_i8_dir[12][4];   /* a->i_satd_i16x16_dir[mode], i_satd_i8x8chroma_dir[list position], i_satd_i8x8_dir[mode][block] */
+    int cbp_i8_rd;                       /* a->i_cbp_i8x8_luma (x264_intra_rd, analyse.c:869) */
     u8 i4_fdec[256], i8_fdec[256], i4_nnz[16], i8_nnz[16];
     int i4_cbp, i8_cbp;
     /* round 2 */
@@ -251,6 +258,7 @@ typedef struct {
     pme me16, me8[4], me16x8[2], me8x16[2];
     sub_me me4[4][4], me84[4][2], me48[4][2];
     int sub[4];
+    int cost_sub[4][3];                  /* a->l0.i_cost4x4 / i_cost8x4 / i_cost4x8 of every 8x8 block (COST_MAX: not searched) */
     int cost8x8, cost16x8, cost8x16, rd16;
     struct banalysis *B;                 /* the B-slice half of x264_mb_analysis_t (b_oracle.c) */
 } panalysis;
@@ -663,24 +671,25 @@ static void mc_16x16(const ssl *S, smb *m, int ref, int mvx, int mvy)
     mcf.mc_chroma(m->fd[1], FDEC, r->plane[1] + oc, S->sc, mvx, mvy, 8, 8);
     mcf.mc_chroma(m->fd[2], FDEC, r->plane[2] + oc, S->sc, mvx, mvy, 8, 8);
 }
+static void mv_clip_frame(const ssl *S, const smb *m, int *mvx, int *mvy)
+{   /* h->mb.mv_min / mv_max, R/encoder/analyse.c:258-259,290-291 */
+    *mvx = clip3i(*mvx, 4 * (-16 * m->mbx - 24), 4 * (16 * (S->mb_w - m->mbx - 1) + 24));
+    *mvy = clip3i(*mvy, 4 * (-16 * m->mby - 24), 4 * (16 * (S->mb_h - m->mby - 1) + 24));
+}
 /* x264_mb_mc for any of the partitions above: per 4x4 block, its vector and its 8x8's reference (R/common/macroblock.c:462-546) */
 static void mc_parts(const ssl *S, smb *m)
 {
     for (int by = 0; by < 4; by++)
         for (int bx = 0; bx < 4; bx++) {
             const sframe *r = S->fref[m->ref8[(by >> 1) * 2 + (bx >> 1)]];
-            const i16 *v = m->mv4[by * 4 + bx];
+            int v[2] = {m->mv4[by * 4 + bx][0], m->mv4[by * 4 + bx][1]};
             int o = (16 * m->mby + 4 * by) * S->sy + 16 * m->mbx + 4 * bx, oc = (8 * m->mby + 2 * by) * S->sc + 8 * m->mbx + 2 * bx;
             u8 *src4[4] = {r->filt[0] + o, r->filt[1] + o, r->filt[2] + o, r->filt[3] + o};
+            mv_clip_frame(S, m, &v[0], &v[1]);                 /* x264_mb_mc_0xywh clips to h->mb.mv_min / mv_max (a vector the RD refinement tries may sit just outside) */
             mcf.mc_luma(m->fd[0] + 4 * by * FDEC + 4 * bx, FDEC, src4, S->sy, v[0], v[1], 4, 4);
             mcf.mc_chroma(m->fd[1] + 2 * by * FDEC + 2 * bx, FDEC, r->plane[1] + oc, S->sc, v[0], v[1], 2, 2);
             mcf.mc_chroma(m->fd[2] + 2 * by * FDEC + 2 * bx, FDEC, r->plane[2] + oc, S->sc, v[0], v[1], 2, 2);
         }
-}
-static void mv_clip_frame(const ssl *S, const smb *m, int *mvx, int *mvy)
-{   /* h->mb.mv_min / mv_max, R/encoder/analyse.c:258-259,290-291 */
-    *mvx = clip3i(*mvx, 4 * (-16 * m->mbx - 24), 4 * (16 * (S->mb_w - m->mbx - 1) + 24));
-    *mvy = clip3i(*mvy, 4 * (-16 * m->mby - 24), 4 * (16 * (S->mb_h - m->mby - 1) + 24));
 }
 /* x264_macroblock_probe_skip, P path (R/encoder/macroblock.c:797-883) */
 static int probe_pskip(ssl *S, smb *m)
@@ -767,6 +776,7 @@ static void analyse_intra_chroma(ssl *S, smb *m)
         int c = (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[1], FDEC, m->fe[1], FENC)
               + (satd ? pixf.satd : pixf.sad)[X264HIP_PIXEL_8x8](m->fd[2], FDEC, m->fe[2], FENC)
               + S->lambda * s_ue_size(s_fix8c[mode[i]]);
+        m->satd_c_dir[i] = c;
         if (c < m->satd_chroma) { m->satd_chroma = c; m->predc = mode[i]; }
     }
     m->chroma_mode = m->predc;
@@ -782,6 +792,7 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
         pred_16x16(S, m, mode[i]);
         int c = cmp[X264HIP_PIXEL_16x16](m->fd[0], FDEC, m->fe[0], FENC) + S->lambda * s_ue_size(s_fix16[mode[i]]);
         if (c < m->satd_i16) { m->satd_i16 = c; m->pred16 = mode[i]; }
+        m->satd_i16_dir[mode[i]] = c;
     }
     if (S->slice_type == S_SLICE_B) m->satd_i16 += S->lambda * 9;      /* i_mb_b_cost_table[I_16x16], analyse.c:659-661 */
     if (m->fast_intra && m->satd_i16 > 2 * satd_inter) return;
@@ -801,6 +812,7 @@ static void analyse_intra(ssl *S, smb *m, int satd_inter)
                 pred_8x8(S, m, idx, mode[i], edge);
                 int c = sa8d(dst, FDEC, src, FENC) + S->lambda * (pm == s_fix4[mode[i] + 1] ? 1 : 4);
                 if (c < best) { best = c; m->pred8[idx] = mode[i]; }
+                m->satd_i8_dir[mode[i]][idx] = c;
             }
             cost += best;
             if (idx == 3 || cost > thresh) break;
@@ -918,6 +930,8 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
     m->cbp_left = m->cbp_top = -1; m->cpm_left = m->cpm_top = 0; m->nb_t8 = 0;
     memset(m->nz_l, 0x80, 4); memset(m->nz_t, 0x80, 4); memset(m->nz_lc, 0x80, 4); memset(m->nz_tc, 0x80, 4);
     memset(m->cmvd, 0, sizeof(m->cmvd));
+    memcpy(m->nnz, S->carry_nnz, 27);                     /* the macroblock's own cache entries: as the previous macroblock left them (see carry_nnz) */
+    for (int i = 0; i < 16; i++) { const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2); m->cmvd[k][0] = S->carry_mvd[0][i][0]; m->cmvd[k][1] = S->carry_mvd[0][i][1]; }
     if (S->cbp) {
         if (m->nb & NB_TOP) {
             const int t = m->mb - S->mb_w;
@@ -937,6 +951,7 @@ static void load_mb(ssl *S, smb *m, int mbx, int mby)
         }
         if (S->slice_type == S_SLICE_B) {                /* list 1 of the mvd cache and the skip flags of direct blocks, macroblock.c:1129-1160 */
             memset(m->cmvd1, 0, sizeof(m->cmvd1)); memset(m->cskip, 0, sizeof(m->cskip));
+            for (int i = 0; i < 16; i++) { const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2); m->cmvd1[k][0] = S->carry_mvd[1][i][0]; m->cmvd1[k][1] = S->carry_mvd[1][i][1]; }
             if (m->nb & NB_TOP) {
                 const int t = m->mb - S->mb_w, sb = S->skipbp[t];
                 for (int i = 0; i < 4; i++) { m->cmvd1[4 + i][0] = S->mvd1[(t * 16 + 12 + i) * 2]; m->cmvd1[4 + i][1] = S->mvd1[(t * 16 + 12 + i) * 2 + 1]; }
@@ -1199,7 +1214,16 @@ static void update_cache(ssl *S, smb *m, const panalysis *A)
         break;
     }
 }
-/* x264_mb_analyse_p_rd, :1935-2005 (sub-8x8 partitions are refused with the RD levels for now) */
+/* x264_mb_analyse_p_rd, :1935-2005 */
+static uint64_t rd_cost_part(ssl *S, smb *m, int lambda2, int i4, int pix);
+static void cache_mv_p8x8(smb *m, const panalysis *A, int i)
+{   /* x264_mb_cache_mv_p8x8, :1058-1075, with the sub-partition type in m->sub[i] */
+    const int x0 = 2 * (i & 1), y0 = 2 * (i >> 1), r = A->me8[i].ref, t = m->sub[i];
+    if (t == S_D_L0_8x8) fill_part(m, x0, y0, 2, 2, r, A->me8[i].mvx, A->me8[i].mvy);
+    else if (t == S_D_L0_8x4) for (int k = 0; k < 2; k++) fill_part(m, x0, y0 + k, 2, 1, r, A->me84[i][k].mvx, A->me84[i][k].mvy);
+    else if (t == S_D_L0_4x8) for (int k = 0; k < 2; k++) fill_part(m, x0 + k, y0, 1, 2, r, A->me48[i][k].mvx, A->me48[i][k].mvy);
+    else for (int k = 0; k < 4; k++) fill_part(m, x0 + (k & 1), y0 + (k >> 1), 1, 1, r, A->me4[i][k].mvx, A->me4[i][k].mvy);
+}
 static void analyse_p_rd(ssl *S, smb *m, panalysis *A, int i_satd)
 {
     const int thresh = i_satd * 5 / 4;
@@ -1216,7 +1240,27 @@ static void analyse_p_rd(ssl *S, smb *m, panalysis *A, int i_satd)
     else A->cost8x16 = S_COST_MAX;
     if (A->cost8x8 <= thresh) {
         m->type = S_P_8x8; m->partition = S_D_8x8;
-        update_cache(S, m, A);
+        if (S->p->inter & 0x20) {                            /* X264_ANALYSE_PSUB8x8: every 8x8 block's sub-partition by RD, :1968-1996 */
+            for (int i = 0; i < 4; i++) cache_set(m, 2 * (i & 1), 2 * (i >> 1), 2, 2, A->me8[i].ref, 0, 0, 0);
+            for (int i = 0; i < 4; i++) {
+                const int costs[4] = {A->cost_sub[i][0], A->cost_sub[i][1], A->cost_sub[i][2], A->me8[i].cost};
+                int mn = costs[0] < costs[1] ? costs[0] : costs[1], btype = S_D_L0_8x8;
+                if (costs[2] < mn) mn = costs[2];
+                if (costs[3] < mn) mn = costs[3];
+                const int th = mn * 5 / 4;
+                uint64_t bcost = (uint64_t)1 << 60;
+                for (int subtype = S_D_L0_4x4; subtype <= S_D_L0_8x8; subtype++) {
+                    if (costs[subtype] > th || (subtype == S_D_L0_8x8 && bcost == (uint64_t)1 << 60)) continue;
+                    m->sub[i] = (int8_t)subtype;
+                    cache_mv_p8x8(m, A, i);
+                    const uint64_t c = rd_cost_part(S, m, S->lambda2, i << 2, X264HIP_PIXEL_8x8);
+                    if (c < bcost) { bcost = c; btype = subtype; }
+                }
+                m->sub[i] = (int8_t)btype; A->sub[i] = btype;
+                cache_mv_p8x8(m, A, i);
+            }
+        } else
+            update_cache(S, m, A);
         A->cost8x8 = rd_cost_mb(S, m, S->lambda2);
     } else A->cost8x8 = S_COST_MAX;
 }
@@ -1227,7 +1271,7 @@ static void intra_rd(ssl *S, smb *m, const panalysis *A, int thresh)
     else m->satd_i16 = S_COST_MAX;
     if (m->satd_i4 <= thresh && m->satd_i4 < S_COST_MAX) { m->type = S_I_4x4; update_cache(S, m, A); m->satd_i4 = rd_cost_mb(S, m, S->lambda2); }
     else m->satd_i4 = S_COST_MAX;
-    if (m->satd_i8 <= thresh && m->satd_i8 < S_COST_MAX) { m->type = S_I_8x8; update_cache(S, m, A); m->satd_i8 = rd_cost_mb(S, m, S->lambda2); }
+    if (m->satd_i8 <= thresh && m->satd_i8 < S_COST_MAX) { m->type = S_I_8x8; update_cache(S, m, A); m->satd_i8 = rd_cost_mb(S, m, S->lambda2); m->cbp_i8_rd = m->cbp_luma; }
     else m->satd_i8 = S_COST_MAX;
 }
 /* x264_mb_analyse_transform_rd, :2127-2150 */
@@ -1246,6 +1290,7 @@ static void transform_rd(ssl *S, smb *m, const panalysis *A, int *i_satd, int *i
 }
 
 #include "b_oracle.c"
+#include "refine_oracle.c"
 static void analyse_mb(ssl *S, smb *m, panalysis *A)
 {
     const slice_params *p = S->p;
@@ -1266,6 +1311,7 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
         if (m->satd_i4 < i_cost) { i_cost = m->satd_i4; m->type = S_I_4x4; }
         if (m->satd_i8 < i_cost) { i_cost = m->satd_i8; m->type = S_I_8x8; }
         if (satd_pcm < i_cost) m->type = S_I_PCM;
+        else if (S->mbrd >= 2) intra_rd_refine(S, m);            /* :2184-2185 */
     } else if (S->slice_type == S_SLICE_B) {
         analyse_b(S, m, A, satd_pcm);
     } else {
@@ -1305,7 +1351,7 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
             cache_set(m, 0, 0, 4, 4, bref, 0, 0, 0);
             /* ---- sub-16x16 partitions (X264_ANALYSE_PSUB16x16), R/encoder/analyse.c:2222-2265 ---- */
             int cost8x8 = S_COST_MAX, cost16x8 = S_COST_MAX, cost8x16 = S_COST_MAX, part = S_D_16x16;
-            for (int i = 0; i < 4; i++) A->sub[i] = S_D_L0_8x8;
+            for (int i = 0; i < 4; i++) { A->sub[i] = S_D_L0_8x8; A->cost_sub[i][0] = A->cost_sub[i][1] = A->cost_sub[i][2] = S_COST_MAX; }
             A->me16.mvx = bmx; A->me16.mvy = bmy; A->me16.cost = best; A->me16.ref = bref; A->me16.ref_cost = S->ref_cost[bref];
             A->me16.mvp[0] = bmvp[0]; A->me16.mvp[1] = bmvp[1];
             A->rd16 = S_COST_MAX;
@@ -1386,6 +1432,7 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
                             }
                             costs[t] = sum + S->ref_cost[r] + S->lambda * subbits[t];
                             if (p->chroma_me && p->subme >= 5) costs[t] += p4x4_chroma(S, m, r, i, t, me);
+                            A->cost_sub[i][t] = costs[t];
                             if (t == 0) {
                                 if (!(costs[0] < A->me8[i].cost)) break;
                                 c8 = costs[0]; A->sub[i] = S_D_L0_4x4;
@@ -1505,6 +1552,11 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
                 intra_rd(S, m, A, satd_inter * 5 / 4);
                 m->type = keep;
             }
+            if (getenv("X264O_DBG_MB") && atoi(getenv("X264O_DBG_MB")) == m->mb && S->f == atoi(getenv("X264O_DBG_F")))
+                fprintf(stderr, "dbg mb %d: satd_inter %d i_cost %d part %d type %d rd16 %d c16x8 %d c8x16 %d c8x8 %d sub %d %d %d %d | me8 cost %d %d %d %d subcosts %d %d %d / %d %d %d / %d %d %d / %d %d %d | i16 %d i8 %d i4 %d t8 %d\n", m->mb, satd_inter, i_cost, part, m->type, A->rd16, A->cost16x8, A->cost8x16, A->cost8x8,
+                        A->sub[0], A->sub[1], A->sub[2], A->sub[3], A->me8[0].cost, A->me8[1].cost, A->me8[2].cost, A->me8[3].cost,
+                        A->cost_sub[0][0], A->cost_sub[0][1], A->cost_sub[0][2], A->cost_sub[1][0], A->cost_sub[1][1], A->cost_sub[1][2], A->cost_sub[2][0], A->cost_sub[2][1], A->cost_sub[2][2], A->cost_sub[3][0], A->cost_sub[3][1], A->cost_sub[3][2],
+                        m->satd_i16, m->satd_i8, m->satd_i4, m->t8);
             int itype = S_I_16x16, icost = m->satd_i16;
             if (m->satd_i8 < icost) { icost = m->satd_i8; itype = S_I_8x8; }
             if (m->satd_i4 < icost) { icost = m->satd_i4; itype = S_I_4x4; }
@@ -1512,6 +1564,7 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
             if (icost < i_cost) { i_cost = icost; m->type = itype; }
             if (icost == S_COST_MAX) icost = i_cost * satd_intra / satd_inter + 1;
             S->stat_intra += icost; S->stat_inter += i_cost; S->stat_n++;
+            if (S->mbrd >= 2 && m->type != S_I_PCM) refine_p_rd(S, m, A);      /* :2406-2464 */
         }
     }
 }
@@ -1773,8 +1826,8 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
     sframe *refs[16] = {0};
     int n_avail = 0, last_idr = 0, cw = p->width / 2, chh = p->height / 2;
     s_setup();
-    if (p->subme > 7 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
-    if (p->subme > 5 && (!b_write || !p->cabac || (p->inter & 0x20) || p->qp == 0)) return -3;  /* RD levels: CABAC with the writer in the loop; not yet sub-8x8 / CAVLC / lossless */
+    if (p->subme > 9 || p->me_method > 3 || (p->me_method == 3 && p->subme < 1)) return -3;   /* ESA at subme 0: the reference never fills the integral plane */
+    if (p->subme > 5 && (!b_write || !p->cabac || p->qp == 0)) return -3;  /* RD levels: CABAC with the writer in the loop; not yet CAVLC / lossless */
     if (b_write && !p->cabac) return -3;
     if (e && e->psy_trellis != 0) return -3;
     const int nb = e ? clip3i(e->bframes, 0, 16) : 0;
@@ -1932,7 +1985,13 @@ static int s_encode_chain(const slice_params *p, const slice_ext *e, const u8 *s
                 o2->mb_bits[F * S.n + mb] = cb_pos(&S.cb);
                 if (o2->mb_bits[F * S.n + mb] / 8 + 2048 > e->payload_cap) return -5;
             }
+            memcpy(S.carry_nnz, m.nnz, 27);                 /* (before save_mb reports an I_PCM macroblock's counts as 16: the cache itself keeps the last trial's) */
             save_mb(&S, &m);
+            for (int i = 0; i < 16; i++) {
+                const int k = 4 + 1 * 8 + (i & 3) + 8 * (i >> 2);
+                S.carry_mvd[0][i][0] = m.cmvd[k][0]; S.carry_mvd[0][i][1] = m.cmvd[k][1];
+                if (is_b) { S.carry_mvd[1][i][0] = m.cmvd1[k][0]; S.carry_mvd[1][i][1] = m.cmvd1[k][1]; }
+            }
             for (int l = 0; l < (is_b ? 2 : idr ? 0 : 1); l++) {      /* the cache entry the next macroblock inherits (see stale_ref) */
                 const int k = s_scan8(12), inter = !S_IS_INTRA(m.type) && !is_b;
                 S.stale_ref[l] = inter ? m.ref8[3] : CREF(&m, l)[k];

@@ -44,7 +44,35 @@ def config_wide(i):
     return w, h, frames, kind, kw, ekw, y, u, v
 
 
+def config_refine(i):
+    """Seeds from 30000 (config(30000 + i)): subme 6..9 -- the RD refinement of vectors and intra modes (x264_me_refine_qpel_rd, _bidir_rd,
+    x264_intra_rd_refine) in I / P / B chains, sub-8x8 partitions under the RD levels, 1..4 references, trellis, psy, AQ."""
+    r = np.random.default_rng(31000 + i)
+    w, h = int(r.integers(5, 12)) * 16 - int(r.integers(0, 2)) * 8, int(r.integers(5, 9)) * 16 - int(r.integers(0, 2)) * 8
+    frames = int(r.integers(3, 7))
+    bframes = int(r.choice([0, 0, 1, 2, 3]))
+    subme = int(r.choice([6, 7, 8, 8, 9, 9]))
+    kw = dict(qp=int(r.integers(14, 42)), subme=subme, me_method=int(r.choice([0, 1, 1, 2])), me_range=int(r.choice([8, 16])),
+              n_refs=int(r.integers(1, 5)), inter=int(r.choice([0, 0x10, 0x13, 0x13, 0x33, 0x33])), intra=int(r.choice([0x1, 0x3])),
+              transform8x8=int(r.integers(0, 2)), mixed_refs=int(r.integers(0, 2)), cabac=1, deblock=int(r.integers(0, 2)), fast_pskip=int(r.integers(0, 2)),
+              dct_decimate=int(r.integers(0, 2)), chroma_me=int(r.integers(0, 2)), keyint=int(r.choice([0, 0, 4])),
+              chroma_qp_offset=int(r.choice([0, 0, -3, 2])), mv_range=int(r.choice([0, 0, 16, 64])))
+    if bframes:
+        kw["inter"] |= int(r.choice([0, 0x100]))
+    if not kw["transform8x8"]:
+        kw["inter"] &= ~0x2; kw["intra"] &= ~0x2
+    ekw = dict(trellis=int(r.choice([0, 1, 2])), psy_rd=float(r.choice([0.0, 0.5, 1.0])), aq_mode=int(r.integers(0, 2)), aq_strength=float(r.choice([0.7, 1.0, 1.3])),
+               bframes=bframes, weightb=int(r.integers(0, 2)), direct_pred=int(r.choice([1, 1, 2])))
+    kind = "moving" if r.integers(0, 2) else "static"
+    y, u, v = case_inputs((w, h), frames, kind)
+    y = y.copy()
+    y[:, -24:, -40:] = np.random.default_rng(i).integers(0, 256, (frames, 24, 40), dtype=np.uint8)
+    return w, h, frames, kind, kw, ekw, y, u, v
+
+
 def config(i):
+    if i >= 30000:
+        return config_refine(i - 30000)
     if i >= 1000:
         return config_wide(i)
     r = np.random.default_rng(7000 + i)

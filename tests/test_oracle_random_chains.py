@@ -17,7 +17,9 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/
 
 # the seeds the GPU test runs (so that both hops cover the same configurations) and a spread of others
 SEEDS = [0, 45, 3, 7, 11, 19, 23, 58, 59, 101, 137, 1002, 1019, 1040, 1071, 1153, 1234, 1300, 1411, 1502, 1507, 1511, 1520,
-         1, 2, 64, 77, 1600, 1777, 2001, 2500]
+         1, 2, 64, 77, 1600, 1777, 2001, 2500,
+         # subme 8-9 (RD refinement), sub-8x8 partitions under the RD levels: 30156 is the chain that showed the cache entries a macroblock inherits
+         30000, 30001, 30003, 30006, 30011, 30013, 30019, 30021, 30023, 30156, 31003, 31404]
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -263,13 +263,23 @@ template <class ST, class MS> CD_FN void cw_chroma_pred_mode(DCabac &cb, ST st, 
         if (mode > 1) cdd_noup(cb, st, rd, 64 + 3, mode > 2);
     }
 }
-template <class ST, class MS> CD_FN void cw_cbp(DCabac &cb, ST st, int rd, const MS &m)
-{   // x264_cabac_mb_cbp_luma + _chroma, :233-263
+template <class ST, class MS> CD_FN void cw_cbp_luma(DCabac &cb, ST st, int rd, const MS &m)
+{   // x264_cabac_mb_cbp_luma, :233-242
     const int cbp = m.cbp_luma, l = m.cbp_left, t = m.cbp_top;
     cdd(cb, st, rd, 76 - ((l >> 1) & 1) - ((t >> 1) & 2), cbp & 1);
     cdd(cb, st, rd, 76 - ((cbp >> 0) & 1) - ((t >> 2) & 2), (cbp >> 1) & 1);
     cdd(cb, st, rd, 76 - ((l >> 3) & 1) - ((cbp << 1) & 2), (cbp >> 2) & 1);
     cdd_noup(cb, st, rd, 76 - ((cbp >> 2) & 1) - ((cbp >> 0) & 2), (cbp >> 3) & 1);
+}
+template <class ST, class MS> CD_FN void cw_cbp_chroma(DCabac &cb, ST st, int rd, const MS &m);
+template <class ST, class MS> CD_FN void cw_cbp(DCabac &cb, ST st, int rd, const MS &m)
+{   // x264_cabac_mb_cbp_luma + _chroma, :233-263
+    cw_cbp_luma(cb, st, rd, m);
+    cw_cbp_chroma(cb, st, rd, m);
+}
+template <class ST, class MS> CD_FN void cw_cbp_chroma(DCabac &cb, ST st, int rd, const MS &m)
+{   // x264_cabac_mb_cbp_chroma, :244-263
+    const int l = m.cbp_left, t = m.cbp_top;
     const int a = l & 0x30, b = t & 0x30;
     int ctx = 0;
     if (a && l != -1) ctx++;
@@ -552,5 +562,60 @@ template <class ST, class MS, class FE> CD_FN void cw_macroblock(DCabac &cb, ST 
             for (int i = 0; i < 16; i++) if (m.cbp_luma & (1 << (i >> 2))) cw_residual(cb, st, rd, m, 2, i, &m.lv4[i][0], 16);
         if (m.cbp_chroma & 3) { cw_residual(cb, st, rd, m, 3, 25, &m.lv_cdc[0][0], 4); cw_residual(cb, st, rd, m, 3, 26, &m.lv_cdc[1][0], 4); }
         if (m.cbp_chroma & 2) for (int i = 16; i < 24; i++) cw_residual(cb, st, rd, m, 4, i, &m.lv_cac[i - 16][1], 15);
+    }
+}
+
+// ---- the RD-only partial writers, R/encoder/cabac.c:1024-1131 (RDO_SKIP_BS build): they only count, on a copy of the contexts.
+// "doesn't write cbp or chroma dc, doesn't write ref or subpartition".  pix: 1 16x8, 2 8x16, 3 8x8 (4 8x4, 5 4x8, 6 4x4 for sub-partitions)
+template <class ST, class MS> CD_FN void cw_partition_size(DCabac &cb, ST st, MS &m, int i8, int pix)
+{   // x264_partition_size_cabac, :1032-1081
+    const int b_8x16 = m.partition == CD_D_8x16;
+    if (m.type == CD_P_8x8) cw_mb8x8_mvd(cb, st, 1, m, i8);
+    else if (m.type == CD_P_L0) cw_mvd(cb, st, 1, m, 4 * i8, 4 >> b_8x16, 2 << b_8x16);
+    else if (m.type > CD_B_DIRECT && m.type < CD_B_8x8) {
+        if (CD_B_USES(m.type, 0, !!i8)) cw_mvd(cb, st, 1, m, 4 * i8, 4 >> b_8x16, 2 << b_8x16, 0);
+        if (CD_B_USES(m.type, 1, !!i8)) cw_mvd(cb, st, 1, m, 4 * i8, 4 >> b_8x16, 2 << b_8x16, 1);
+    } else if (m.type == CD_B_8x8) {
+        for (int l = 0; l < 2; l++) if (CD_SUB_USES(m.sub[i8], l)) cw_mvd(cb, st, 1, m, 4 * i8, 2, 2, l);
+    } else
+        return;
+    for (int j = pix < 3; j >= 0; j--) {
+        if (m.cbp_luma & (1 << i8)) {
+            if (m.t8) cw_residual(cb, st, 1, m, 5, 4 * i8, &m.lv8[i8][0], 64);
+            else for (int i4 = 0; i4 < 4; i4++) cw_residual(cb, st, 1, m, 2, i4 + 4 * i8, &m.lv4[i4 + 4 * i8][0], 16);
+        }
+        cw_residual(cb, st, 1, m, 4, 16 + i8, &m.lv_cac[i8][1], 15);
+        cw_residual(cb, st, 1, m, 4, 20 + i8, &m.lv_cac[4 + i8][1], 15);
+        i8 += pix == 2 ? 2 : 1;                       // x264_pixel_size[pix].h >> 3
+    }
+}
+template <class ST, class MS> CD_FN void cw_subpartition_size(DCabac &cb, ST st, MS &m, int i4, int pix)
+{   // x264_subpartition_size_cabac, :1083-1095
+    const int b_8x4 = pix == 4;
+    cw_residual(cb, st, 1, m, 2, i4, &m.lv4[i4][0], 16);
+    if (pix == 6) cw_mvd(cb, st, 1, m, i4, 1, 1);
+    else {
+        cw_mvd(cb, st, 1, m, i4, 1 + b_8x4, 2 - b_8x4);
+        cw_residual(cb, st, 1, m, 2, i4 + 2 - b_8x4, &m.lv4[i4 + 2 - b_8x4][0], 16);
+    }
+}
+template <class ST, class MS> CD_FN void cw_partition_i8x8_size(DCabac &cb, ST st, const MS &m, int i8, int mode)
+{   // x264_partition_i8x8_size_cabac, :1097-1105
+    cw_intra4x4_pred_mode(cb, st, 1, cd_pred_i4mode(m, 4 * i8), cd_fix4(mode));
+    cw_cbp_luma(cb, st, 1, m);
+    if (m.cbp_luma & (1 << i8)) cw_residual(cb, st, 1, m, 5, 4 * i8, &m.lv8[i8][0], 64);
+}
+template <class ST, class MS> CD_FN void cw_partition_i4x4_size(DCabac &cb, ST st, const MS &m, int i4, int mode)
+{   // x264_partition_i4x4_size_cabac, :1107-1113
+    cw_intra4x4_pred_mode(cb, st, 1, cd_pred_i4mode(m, i4), cd_fix4(mode));
+    cw_residual(cb, st, 1, m, 2, i4, &m.lv4[i4][0], 16);
+}
+template <class ST, class MS> CD_FN void cw_i8x8_chroma_size(DCabac &cb, ST st, const MS &m)
+{   // x264_i8x8_chroma_size_cabac, :1115-1131
+    cw_chroma_pred_mode(cb, st, 1, m);
+    cw_cbp_chroma(cb, st, 1, m);
+    if (m.cbp_chroma > 0) {
+        cw_residual(cb, st, 1, m, 3, 25, &m.lv_cdc[0][0], 4); cw_residual(cb, st, 1, m, 3, 26, &m.lv_cdc[1][0], 4);
+        if (m.cbp_chroma == 2) for (int i = 16; i < 24; i++) cw_residual(cb, st, 1, m, 4, i, &m.lv_cac[i - 16][1], 15);
     }
 }

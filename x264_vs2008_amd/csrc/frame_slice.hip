@@ -6,6 +6,7 @@
 void x264hip_launch_slice_rd(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_b(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_bt(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
+void x264hip_launch_slice_rf(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 
 // b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
 // knowing it (it could not change their type) recorded the statistics term for the other answer in cost_alt.
@@ -130,7 +131,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (is_b) {
         if (!pb || !pb->fref1 || !pb->l1_state || !p->rd) { set_error("slice_sweep: a B slice needs x264hip_slice_params.b (list 1) and .rd (the raster variant)"); return -1; }
         if (!pb->direct_spatial && !p->rd->stale) { set_error("slice_sweep: temporal direct prediction needs x264hip_slice_rd.stale (in every sweep of the chain)"); return -1; }
-        if (p->subme < 2 || p->subme > 7 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 2..7 with the CABAC writer in the loop"); return -1; }
+        if (p->subme < 2 || p->subme > 8 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 2..8 with the CABAC writer in the loop (subme 9 refines a B macroblock's vectors by RD: x264_me_refine_bidir_rd, not built)"); return -1; }
         if (p->noise_reduction || p->lossless) { set_error("slice_sweep: B slices with --nr / lossless are not built"); return -1; }
         if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
     }
@@ -142,7 +143,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     }
     const x264hip_slice_rd *prd = p->rd;
     const int mbrd = (p->subme - is_b >= 6) + (p->subme - is_b >= 8);       /* one level less in a B slice, R/encoder/analyse.c:222-225 */
-    if (p->subme < 0 || p->subme > 7) { set_error("slice_sweep: subme %d (RD refinement of vectors and intra modes) not built", p->subme); return -1; }
+    if (p->subme < 0 || p->subme > 9) { set_error("slice_sweep: subme %d", p->subme); return -1; }
     if (mbrd && (!prd || !prd->write || !p->cabac)) { set_error("slice_sweep: subme %d prices its trial encodes against the live CABAC contexts: it needs x264hip_slice_params.rd with write = 1 and cabac = 1", p->subme); return -1; }
     if (prd) {
         if (prd->write && !p->cabac) { set_error("slice_sweep: the in-loop entropy coder is CABAC only"); return -1; }
@@ -151,7 +152,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         if (prd->trellis < 0 || prd->trellis > 2) { set_error("slice_sweep: trellis %d", prd->trellis); return -1; }
         if (prd->aq_offset && !prd->cost_mv_all) { set_error("slice_sweep: adaptive quantisation needs cost_mv_all"); return -1; }
         if (p->lossless) { set_error("slice_sweep: lossless is not built in the raster variant"); return -1; }
-        if (mbrd && (p->analyse_inter & 0x20)) { set_error("slice_sweep: sub-8x8 partitions with the RD levels (x264_rd_cost_part) not built"); return -1; }
+        if (mbrd && (p->analyse_inter & 0x20)) { set_error("slice_sweep: sub-8x8 partitions with the RD levels not built (their partial bit counts read cache entries the previous macroblock left)"); return -1; }
         if (!out->mvd) { set_error("slice_sweep: mb_state without mvd"); return -1; }
     }
     if (!out->luma && !(prd && prd->write)) { set_error("slice_sweep: an mb_state without level arrays (X264HIP_STATE_NO_LEVELS) needs the entropy coder in the loop (rd.write)"); return -1; }
@@ -267,7 +268,9 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
             // the extended B kernel (temporal direct prediction, the lookahead's candidates) only where it is needed: the plain one is 6-8 % faster
             if (r.direct_temporal || a.lowres0 || a.lowres1) x264hip_launch_slice_bt(a, t, r, c->stream); else x264hip_launch_slice_b(a, t, r, c->stream);
-        } else
+        } else if (mbrd >= 2)
+            x264hip_launch_slice_rf(a, t, r, c->stream);          // subme 8-9: the I / P kernel with the RD refinement (slice_refine.h)
+        else
         x264hip_launch_slice_rd(a, t, r, c->stream);
     } else {
     const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);

@@ -204,6 +204,10 @@ struct SwLdsRd {
 };
 struct SwLdsNone { int unused; };
 struct SwLdsRdB { SwLdsRd r; SwLdsB b; };
+// what the RD refinement (subme 8+, template argument RF) adds: the analysis' per-mode costs (a->i_satd_i16x16_dir[mode],
+// i_satd_i8x8chroma_dir[list position], i_satd_i8x8_dir[mode][block]) and the pixels x264_intra_rd_refine keeps of its best trial
+struct SwLdsRf { int i16dir[8], cdir[4], i8dir[12][4]; u8 pels[16]; };
+struct SwLdsRdF { SwLdsRd r; SwLdsRf f; };
 // the record cabac_dev.h's writer walks (same member names as MbSyn): scalars in registers, arrays where the kernel keeps them in LDS
 struct MbSynDev {
     int slice_type, type, partition, i16mode, chroma_mode, cbp_luma, cbp_chroma, t8, qp, n_ref, pps_t8, t8_allowed;
@@ -278,11 +282,17 @@ __device__ __forceinline__ void sw_mc16(SwLds &s, const SwRefs &refs, const SwAr
 }
 
 // x264_mb_mc for any P partition: every pixel with the vector of its 4x4 block and the reference of its 8x8 (s.mv4 / s.ref8)
-__device__ __forceinline__ void sw_mc_parts(SwLds &s, const SwRefs &refs, const SwArgs &a, ptrdiff_t oy, ptrdiff_t oc, size_t by, size_t bc, int lane)
+// clip: x264_mb_mc_0xywh's clip of the vector to h->mb.mv_min / mv_max (R/common/macroblock.c:465-466); the analysis never leaves a vector
+// outside them, the candidates of the RD refinement (subme 8+) may sit a quarter sample or two beyond
+__device__ __forceinline__ void sw_mc_parts(SwLds &s, const SwRefs &refs, const SwArgs &a, ptrdiff_t oy, ptrdiff_t oc, size_t by, size_t bc, int lane,
+                                            bool clip = false, int mbx = 0, int mby = 0)
 {
+    const int lox = 4 * (-16 * mbx - 24), hix = 4 * (16 * (a.mb_w - mbx - 1) + 24), loy = 4 * (-16 * mby - 24), hiy = 4 * (16 * (a.mb_h - mby - 1) + 24);
     {
         const int r = lane >> 2, x = (lane & 3) * 4, blk = (r >> 2) * 4 + (x >> 2);
-        const int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1], ri = s.ref8[(r >> 3) * 2 + (x >> 3)];
+        int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1];
+        const int ri = s.ref8[(r >> 3) * 2 + (x >> 3)];
+        if (clip) { mvx = clip3(mvx, lox, hix); mvy = clip3(mvy, loy, hiy); }
         const int qx = mvx & 3, qy = mvy & 3, idx = qy * 4 + qx;
         const ptrdiff_t base = oy + (ptrdiff_t)((mvy >> 2) + r) * a.sy + (mvx >> 2) + x + (ptrdiff_t)by;
         const u8 *pa = refs.y[ri][c_qpel_a[idx]] + base + (qy == 3) * a.sy;
@@ -293,7 +303,9 @@ __device__ __forceinline__ void sw_mc_parts(SwLds &s, const SwRefs &refs, const 
     }
     {
         const int cx = lane & 7, cy = lane >> 3, blk = (cy >> 1) * 4 + (cx >> 1);
-        const int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1], ri = s.ref8[(cy >> 2) * 2 + (cx >> 2)];
+        int mvx = s.mv4[blk][0], mvy = s.mv4[blk][1];
+        const int ri = s.ref8[(cy >> 2) * 2 + (cx >> 2)];
+        if (clip) { mvx = clip3(mvx, lox, hix); mvy = clip3(mvy, loy, hiy); }
         const int dx = mvx & 7, dyy = mvy & 7;
         const int ca = (8 - dx) * (8 - dyy), cb = dx * (8 - dyy), cc = (8 - dx) * dyy, cd = dx * dyy;
         const ptrdiff_t cbase = oc + (ptrdiff_t)((mvy >> 3) + cy) * a.sc + (mvx >> 3) + cx + (ptrdiff_t)bc;
@@ -437,10 +449,13 @@ __device__ __forceinline__ int sw_denoise(int v, int off, int &la)
     level -= off;
     return level < 0 ? 0 : (level ^ sign) - sign;
 }
-__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr, int nr_on = 0)
+// mask8: the 8x8 blocks to do (x264_macroblock_encode_p8x8 codes one); lanes of other blocks leave everything of theirs alone
+__device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const SwQp &Q, SwTq tq, int cat, bool dc_out, int lane, int *nr_acc4 = nullptr, int nr_on = 0,
+                                               int mask8 = 0xf)
 {
     i16 c[16], lv[16];
-    if (lane < 16) {
+    const bool mine = lane < 16 && ((mask8 >> (lane >> 2)) & 1);
+    if (mine) {
         int bx, by, r[16];
         sw_blk_xy(lane, bx, by);
 #pragma unroll
@@ -471,11 +486,12 @@ __device__ __forceinline__ void sw_luma4x4_fwd(SwLds &s, const SwArgs &a, const 
         WAVE_SYNC();
 #pragma nounroll
         for (int it = 0; it < 4; it++)
+            if ((mask8 >> it) & 1)
             td_trellis_wave(tq.r->tw, (u32 *)s.patch, &s.coef[4 * it + (lane >> 4)][0], true, s.qmf[cat], tq.r->unq4[cat], tq.r->w4z, tq.r->zz4, tq.r->cabac, dc_out ? 1 : 2,
                             d_trellis_lambda2[cat == 0][Q.qp], dc_out ? 1 : 0, 0, 16, lane);
         WAVE_SYNC();
     }
-    if (lane < 16) {
+    if (mine) {
         const u16 *mf = s.qmf[cat], *bs = s.qbias[cat];
         const int *dq = s.qdq[cat];
         int nz = 0, bits = Q.qp / 6 - 4;
@@ -1277,19 +1293,23 @@ static __device__ const int d_lambda2_tab[52] = {14, 18, 22, 28, 36, 45, 57, 72,
 static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
                                               29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
-template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false>       // TD: the extended B kernel (temporal direct prediction, lookahead candidates)
+// RF: the I / P kernel with the RD refinement of subme 8-9 (x264_me_refine_qpel_rd, x264_intra_rd_refine: slice_refine.h)
+template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false, bool RF = false>       // TD: the extended B kernel (temporal direct prediction, lookahead candidates)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
 {
     static_assert(!BS || RD, "B slices run in the raster variant");
     static_assert(!TD || BS, "temporal direct prediction is a B-slice matter");
+    static_assert(!RF || (RD && !BS), "the RD refinement is built for the raster variant's I / P kernel");
 #undef IS_SKIP_T
 #define IS_SKIP_T(t) (BS ? ((t) == T_P_SKIP || (t) == T_B_SKIP) : (t) == T_P_SKIP)      /* BS is a template constant: the other kernels keep their single compare */
     __builtin_assume(a.lossless == (int)LL);           // the host launches the matching variant; do not write to `a` (a modified
                                                         // kernel argument is copied to scratch memory whole)
     __shared__ SwLds s;
-    __shared__ typename std::conditional<BS, SwLdsRdB, typename std::conditional<RD, SwLdsRd, SwLdsNone>::type>::type sr_;
+    __shared__ typename std::conditional<BS, SwLdsRdB, typename std::conditional<RF, SwLdsRdF, typename std::conditional<RD, SwLdsRd, SwLdsNone>::type>::type>::type sr_;
     SwLdsRd &sr = *(SwLdsRd *)&sr_;                     // only touched when RD
     SwLdsB &sb = *(SwLdsB *)((char *)&sr_ + sizeof(SwLdsRd));    // only touched when BS (then sr_ is an SwLdsRdB)
+    SwLdsRf &sf = *(SwLdsRf *)((char *)&sr_ + sizeof(SwLdsRd));  // only touched when RF (then sr_ is an SwLdsRdF)
+    (void)sf;
     const int lane_id = threadIdx.x, lane = lane_id;
     const int bz = RD ? (int)blockIdx.x : (int)(blockIdx.x % a.batch_pad), mby0 = RD ? 0 : (int)(blockIdx.x / a.batch_pad);
     if (bz >= a.batch) return;
@@ -1516,6 +1536,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 const int m = (int)((list >> (4 * i)) & 15);
                 sw_pred8c(s, m, lane, a.lossless);
                 int c = sw_cmp_chroma(s, satd, lane) + Q.lambda * sw_ue_size(sw_fix8c(m));
+                if constexpr (RF) { if (lane == 0) sf.cdir[i] = c; }
                 if (c < satd_chroma) { satd_chroma = c; predc = m; }
             }
         };
@@ -1554,6 +1575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     const int m = (int)((list >> (4 * i)) & 15);
                     sw_pred16(s, m, lane, a.lossless);
                     int c = sw_cmp_luma16(s, satd, lane) + Q.lambda * sw_ue_size(sw_fix16(m));
+                    if constexpr (RF) { if (lane == 0) sf.i16dir[m] = c; }
                     if (c < satd_i16) { satd_i16 = c; pred16 = m; }
                 }
             }
@@ -1606,6 +1628,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                 c = half_sum8(sd);
                             }
                             key = ((u32)(c + Q.lambda * (pm == sw_fix4(mode) ? 1 : 4)) << 4) | (u32)g;
+                            if constexpr (RF) { if (r == 0) sf.i8dir[mode][idx] = (int)(key >> 4); }
                         }
                         // the reference's in-order strict '<' over the modes = the smallest (cost, slot) key
 #pragma unroll
@@ -1774,7 +1797,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 sw_pred8c(s, predc, lane, a.lossless);
                 cbp_chroma = sw_encode_chroma(s, a, Q, tq, 0, lane);
             } else {
-                if constexpr (!BS) sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane);    // (B slice: the caller has run the bi-predictive motion compensation)
+                if constexpr (!BS) sw_mc_parts(s, refs, a, oy, oc, by_, bc_, lane, RF, mbx, mby);    // (B slice: the caller has run the bi-predictive motion compensation)
                 WAVE_SYNC();
                 // x264_mb_transform_8x8_allowed: a P_8x8 macroblock only with four 8x8 sub-partitions
                 if (!mbrd && a.transform8x8 && !a.lossless && (type != T_P_8x8 || __ballot(lane < 4 && sub_t_mb != 3) == 0)) {
@@ -1821,6 +1844,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                 v8 = ((sa8d_8x8_raw(sr.zero16, 0, fe, 16) + 2) >> 2) - (sad >> 2);
             }
             fenc_satd_sum = wave_sum(v4); fenc_sa8d_sum = wave_sum(v8);
+            if constexpr (RF) {         // h->mb.pic.fenc_satd[y][x] / fenc_sa8d[y][x]: the partial RD costs sum them over their blocks (sum_satd / sum_sa8d, rdo.c:66-91)
+                if (lane < 16) sr.fenc_satd[lane] = v4; else if (lane < 20) sr.fenc_sa8d[lane - 16] = v8;
+                WAVE_SYNC();
+            }
         };
         auto ssd_mb = [&]() -> int {       // ssd_mb / ssd_plane, R/encoder/rdo.c:106-137
             int acc = 0;
@@ -2274,7 +2301,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                         // ---- the raster variant's P macroblock (analyse.c:2228-2405): the rest of the analysis, the RD candidates of
                         // x264_mb_analyse_p_rd / x264_mb_analyse_transform_rd / x264_intra_rd, and the final encode, through ONE copy of
                         // x264_rd_cost_mb: step 0 the early 16x16 trial (:1134-1143), 1 the analysis, 2-5 p_rd, 6 the transform, 7-9 intra, 10 final.
-                        const int me16x = mvx, me16y = mvy, me16r = ref;
+                        int me16x = mvx, me16y = mvy;                    // (the RD refinement moves the 16x16 vector)
+                        const int me16r = ref;
+                        int i8_cbp_rd = 0;                               // a->i_cbp_i8x8_luma (x264_intra_rd, analyse.c:869)
+                        // the RD refinement's state (slice_refine.h): what is being refined, the best cost so far, and the candidate generator of
+                        // x264_me_refine_qpel_rd
+                        int rf_kind = 0, rf_i = 0, rf_n = 0, rf_old16 = 0, rf_best16 = 0, rf_thr = 0;
+                        u32 rf_list = 0;
+                        unsigned long long rf_best = 0;
+                        int q_st = 0, q_j = 0, q_it = 0, q_dir = -2, q_odir = 0, q_tag = 0, q_after_pm = 0;
+                        int q_bmx = 0, q_bmy = 0, q_omx = 0, q_omy = 0, q_pmx = 0, q_pmy = 0, q_m0x = 0, q_m0y = 0, q_mvpx = 0, q_mvpy = 0, q_cx = 0, q_cy = 0;
+                        int q_pix = 0, q_bx = 0, q_by = 0, q_w = 16, q_h = 16, q_slot = -1, q_ref = 0, q_i4 = 0, q_satds = 0;
+                        u32 q_bsatd = 0;
+                        (void)rf_kind; (void)rf_i; (void)rf_n; (void)rf_old16; (void)rf_best16; (void)rf_thr; (void)rf_list; (void)rf_best; (void)i8_cbp_rd;
+                        (void)q_st; (void)q_j; (void)q_it; (void)q_dir; (void)q_odir; (void)q_tag; (void)q_after_pm; (void)q_bmx; (void)q_bmy; (void)q_omx; (void)q_omy;
+                        (void)q_pmx; (void)q_pmy; (void)q_m0x; (void)q_m0y; (void)q_mvpx; (void)q_mvpy; (void)q_cx; (void)q_cy; (void)q_pix; (void)q_bx; (void)q_by;
+                        (void)q_w; (void)q_h; (void)q_slot; (void)q_ref; (void)q_i4; (void)q_satds; (void)q_bsatd;
                         int rd16 = MX_COST_MAX, satd_inter = 0, satd_intra = 0, final_type = T_P_L0, final_part = 16, rd_thresh = 0, rd_isat = 0;
                         bool rd_skip = false;
                         // x264_analyse_update_cache for a P candidate (analyse.c:2803-2846): type / part -> s.mv4 / s.ref8 (and the 16x16 scalars)
@@ -2295,7 +2337,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             WAVE_SYNC();
                         };
 #pragma nounroll
-                        for (int step = 0; step < 11; step++) {
+                        for (int step = 0; step < (RF ? 13 : 11); step++) {      // RF: 10 decides, 11 refines (once per full-macroblock candidate), 12 is the final encode
                             bool fin = false;
                             if (step == 0) {
                                 if (!mbrd) continue;
@@ -2354,8 +2396,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                             } else if (step == 9) {
                                 if (!(satd_i8 <= (is_p ? satd_inter * 5 / 4 : MX_COST_MAX) && satd_i8 < MX_COST_MAX)) { satd_i8 = MX_COST_MAX; continue; }
                                 type = T_I_8x8;
-                            } else {
-                                fin = true;
+                            } else if (!RF || step == 10) {
+                                fin = !RF;
                                 if (!is_p) {                                 // analyse.c:2179-2184: 16x16, then 4x4, then 8x8, then PCM on strict improvement
                                     type = T_I_16x16;
                                     int ic = satd_i16;
@@ -2375,6 +2417,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     stat_intra = icost; analysed = 1;
                                     stat_inter = i_cost;
                                 }
+                                if constexpr (RF) {
+                                    // analyse.c:2184-2185 (I), :2406-2464 (P): with a->i_mbrd >= 2 the winner's intra modes / vectors are refined by RD
+                                    rf_kind = 9;
+                                    if (mbrd >= 2 && type != T_I_PCM && !rd_skip) {
+                                        if (IS_INTRA_T(type)) {
+                                            skip_intra = 0;                  // x264_intra_rd_refine's first statement
+                                            rf_kind = 2;
+                                            if (type == T_I_16x16) {
+                                                rf_kind = 1; rf_list = sw_modes16(nb, rf_n); rf_i = 0; rf_old16 = rf_best16 = pred16;
+                                                rf_thr = UNI(sf.i16dir[pred16]) * 9 / 8; rf_best = (unsigned long long)(u32)satd_i16;
+                                            }
+                                        } else { rf_kind = 3; rf_i = 0; q_st = -1; }
+                                    }
+                                    continue;
+                                } else {
+                                    tq.on = rd.trellis != 0;                                      // :2768-2773
+                                    if (rd.trellis == 1 || a.nr) skip_intra = 0;
+                                }
+                            } else if (step == 11) {
+                                if constexpr (RF) {
+#include "slice_refine.h"
+                                }
+                            } else {
+                                fin = true;
                                 tq.on = rd.trellis != 0;                                          // :2768-2773
                                 if (rd.trellis == 1 || a.nr) skip_intra = 0;
                             }
@@ -2421,7 +2487,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                                     t8 = !t8;
                             } else if (step == 7) satd_i16 = c;
                             else if (step == 8) satd_i4 = c;
-                            else satd_i8 = c;
+                            else if (step == 9) { satd_i8 = c; i8_cbp_rd = cbp_luma; }
+                            else if constexpr (RF) {                     // step 11: the full-macroblock candidate the refinement asked for
+                                if (rf_kind == 1) { if ((unsigned long long)(u32)c < rf_best) { rf_best = (unsigned long long)(u32)c; rf_best16 = pred16; } }
+                                else {
+                                    type = T_P_L0;                       // x264_rd_cost_part( .., PIXEL_16x16 ) restores h->mb.i_type (rdo.c:209-213)
+                                    if ((unsigned long long)(u32)c < rf_best) { rf_best = (unsigned long long)(u32)c; q_bmx = q_cx; q_bmy = q_cy; if (q_tag != -3) q_dir = q_tag; }
+                                }
+                                step = 10;                               // back into the refinement
+                            }
                         }
                     }
                 }

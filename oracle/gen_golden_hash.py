@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 from oracle import refslice as rs
-from oracle.gen_golden_slice import MED, MEDB, masked2
+from oracle.gen_golden_slice import MED, MEDB, SLOW, masked2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -29,6 +29,11 @@ HASH_CASES = [
     ("uhd_umh_medium_rd", (3840, 2160), 2, dict(qp=26, subme=7, **dict(MED, me_method=rs.ME_UMH, n_refs=2)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0)),
     # the medium preset's analysis options with its GOP shape: I P B B B P in coding order (3 disposable B frames, weightb, spatial direct)
     ("hd_medium_b", (1920, 1080), 6, dict(qp=26, subme=7, **dict(MEDB, n_refs=3)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0, bframes=3, weightb=1, direct_pred=1)),
+    # round 3.  BASELINE config 3's analysis (SURVEY 8(d) SLOW_SHARD: --ref 5 --bframes 3 --me umh --subme 8 --8x8dct --trellis 1 --weightb --mixed-refs --direct spatial)
+    # at constant QP, I P B B B P: the RD refinement in the I / P slices, mode-decision RD in the B slices
+    ("hd_slow_b", (1920, 1080), 6, dict(qp=26, subme=8, **dict(SLOW, inter=0x113)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0, bframes=3, weightb=1, direct_pred=1)),
+    # BASELINE config 2 as stated: 3840x2160, the medium set with --me umh, 3 references, 3 B frames
+    ("uhd_umh_medium_b", (3840, 2160), 6, dict(qp=26, subme=7, **dict(MEDB, me_method=rs.ME_UMH, n_refs=3)), dict(trellis=1, psy_rd=1.0, aq_mode=1, aq_strength=1.0, bframes=3, weightb=1, direct_pred=1)),
 ]
 
 

@@ -21,7 +21,7 @@ def load(name):
 
 
 # the twin at 2160p with the RD levels takes ~20 s: keep the CPU suite short, the GPU test covers that size
-CPU_CASES = [c for c in HASH_CASES if c[0] != "uhd_umh_medium_rd"]
+CPU_CASES = [c for c in HASH_CASES if c[0] not in ("uhd_umh_medium_rd", "uhd_umh_medium_b")]
 
 
 @pytest.mark.parametrize("name,size,frames,kw,ekw", CPU_CASES, ids=[c[0] for c in CPU_CASES])

@@ -119,7 +119,7 @@ def compare(hip, twin, cqm, i):
             try:
                 enc.encode_frame(stype=stype, disp=disp, **(dict(lowres_mv=lowres[f][0], lowres_mv1=lowres[f][1]) if lowres else {}))
             except RuntimeError as e:                  # an option combination the sweep refuses (it says so): not a difference
-                if "slice_sweep:" in str(e) and f == (1 if stype != sl.SLICE_I else 0):
+                if "slice_sweep:" in str(e) and ("not built" in str(e) or f == (1 if stype != sl.SLICE_I else 0)):
                     return what + " REFUSED " + str(e)[-90:], [], []
                 raise
             enc.status()

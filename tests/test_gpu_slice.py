@@ -227,14 +227,15 @@ def test_sweep_batched_chains_with_different_content(hip_lib, oracle_lib, cqm):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw,tweak,needle", [
-    (dict(subme=8, cabac=1), None, "subme"),                               # RD refinement (x264_me_refine_qpel_rd, x264_intra_rd_refine): not built
+    (dict(subme=10, cabac=1), None, "subme"),                              # beyond the reference's range (x264_validate_parameters clips to 9)
+    (dict(subme=8, cabac=1, inter=0x33), None, "sub-8x8"),                 # sub-8x8 partitions under the RD refinement: their partial bit counts read the previous macroblock's cache
     (dict(subme=6, cabac=0), None, "CABAC"),                               # the RD levels price against the live CABAC contexts: CAVLC RD is not built
     (dict(subme=7, cabac=1, inter=0x30), None, "sub-8x8"),                 # x264_rd_cost_part
     (dict(subme=5, me_method=4), None, "me method"),                       # TESA: not built
     (dict(subme=0, me_method=3), None, "subme"),                           # ESA at subme 0: undefined in the reference
     (dict(subme=2), "lossless_qp", "lossless"),                            # lossless without x264_validate_parameters' consequences
     (dict(subme=2), "nr_no_state", "noise_reduction"),                     # --nr without the per-chain sums
-], ids=["rd_refine", "rd_cavlc", "rd_sub8x8", "tesa", "esa_subme0", "lossless_qp26", "nr_without_state"])
+], ids=["subme10", "rd8_sub8x8", "rd_cavlc", "rd_sub8x8", "tesa", "esa_subme0", "lossless_qp26", "nr_without_state"])
 def test_sweep_refuses_what_it_does_not_build(hip_lib, cqm, kw, tweak, needle):
     """No fallback: an option the sweep does not implement is an error string, not an approximation."""
     y, u, v = case_inputs((96, 80), 1, "moving")

@@ -142,3 +142,23 @@ def test_source_only_picture_is_refused_as_a_reference_and_lanes_are_freed(hip_l
         assert hip_lib.x264hip_mem_info(C.byref(f), C.byref(t)) == 0
         free.append(f.value)
     assert free[-1] >= free[0] - (1 << 20), free          # nothing accumulates from one encoder to the next
+
+
+def test_subme9_with_b_slices_is_refused_not_approximated(hip_lib, cqm):
+    """subme 9 refines a B macroblock's vectors by RD (x264_me_refine_bidir_rd and the list-1 form of x264_me_refine_qpel_rd): the twin has
+    it (fixtures slice2_rd9_b*.npz), the B kernel does not -- the sweep says so on the first B slice instead of coding it at subme 8."""
+    w, h = 208, 144
+    enc = sl.ChainEncoder(hip_lib, w, h, cqm, batch=1, write=1, qp=28, subme=9, me_method=1, n_refs=2, inter=0x113, intra=0x3, transform8x8=1, cabac=1, deblock=1,
+                          trellis=1, bframes=2, weightb=1)
+    try:
+        y = np.full((h, w), 90, np.uint8); u = np.full((h // 2, w // 2), 128, np.uint8)
+        for disp, stype in sl.coding_order(4, 0, 2)[:2]:      # I and P at subme 9 run (the refinement kernel)
+            enc.upload(y, u, u)
+            enc.encode_frame(stype=stype, disp=disp)
+            enc.status()
+            enc.finish_frame()
+        enc.upload(y, u, u)
+        with pytest.raises(RuntimeError, match="subme 9"):
+            enc.encode_frame(stype=sl.SLICE_B, disp=1)
+    finally:
+        enc.close()

@@ -52,6 +52,13 @@ typedef struct {
      * caller supplies them, [frame in coding order][list][n_mb][2] int16; a frame / list whose first component is 0x7fff has none
      * (x264_frame_init_lowres' marker, R/common/mc.c:330).  NULL: b_have_lowres = 0 as before */
     const int16_t *lowres_mv;
+    /* round 3: the real lookahead and rate control in front of the loop (refslice_encode_stream): x264_slicetype_decide (b-adapt, pre-scenecut)
+     * places the frame types, x264_ratecontrol_start gives every frame its QP (CRF), the lookahead's own vectors feed the 16x16 searches */
+    int b_adapt;                             /* param.i_bframe_adaptive: 0 none, 1 fast, 2 trellis */
+    int pre_scenecut, scenecut_threshold;    /* param.b_pre_scenecut, i_scenecut_threshold (-1: off) */
+    int keyint_min;                          /* param.i_keyint_min (0: keyint_max / 10 ... as x264_validate_parameters leaves the default 25) */
+    float crf;                               /* param.rc.f_rf_constant; < 0: constant QP */
+    int bframe_bias;                         /* param.i_bframe_bias */
 } refslice_ext;
 
 typedef struct {
@@ -62,6 +69,10 @@ typedef struct {
     int16_t *mv1;                            /* [F][n][16][2]: list 1 (B slices) */
     int8_t *ref1;                            /* [F][n][4] */
     int32_t *frame_info2;                    /* [F][4]: display index, i_ref1, kept as reference, 0 */
+    /* the lookahead's results per coded frame (refslice_encode_stream; NULL otherwise) */
+    float *rc_info;                          /* [F][4]: rc->f_qpm (the frame's QP before rounding), fdec->f_qp_avg_rc, fdec->i_satd (x264_rc_analyse_slice), 0 */
+    int16_t *look_mv;                        /* [F][2][n][2]: the lowres vectors offered to the 16x16 searches of this frame (list 0 / 1 towards reference 0; 0x7fff first = none) */
+    int32_t *look_cost;                      /* [F][8]: fenc->i_cost_est[b - p0][p1 - b] of the frame as coded, i_cost_est_aq, i_intra_mbs[b - p0], i_cost_est[0][0], p0, p1, b, 0 */
 } refslice_out2;
 
 typedef struct {
@@ -115,15 +126,20 @@ static const uint8_t flat16[64] = {
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16 };
 
-static int run_chain(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
-                     refslice_out *o, refslice_out2 *o2)
+typedef struct {
+    x264_t *h;
+    uint8_t *bsbuf;
+    int b_write, mb_w, mb_h, n, cw, ch, stream;
+} rctx;
+
+/* the encoder as x264_encoder_open leaves it for this path (R/encoder/encoder.c:628-760) */
+static int setup_encoder(rctx *c, const refslice_params *p, const refslice_ext *e, int stream)
 {
     x264_t *h = calloc(1, sizeof(x264_t));
     uint8_t *bsbuf = NULL;
     const int b_write = e && e->write;
-    x264_frame_t *refs[16] = {0};
-    int n_avail = 0, f, i, k, y, mb_w, mb_h, n, last_idr = 0;
-    int cw = p->width / 2, ch = p->height / 2;
+    int i, k, mb_w, mb_h, n;
+    c->h = h; c->stream = stream;
 
     x264_param_default(&h->param);
     h->param.i_width = p->width; h->param.i_height = p->height;
@@ -138,6 +154,15 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     h->param.analyse.i_noise_reduction = p->noise_reduction; h->param.analyse.f_psy_rd = 0; h->param.analyse.f_psy_trellis = 0;
     h->param.analyse.i_chroma_qp_offset = p->chroma_qp_offset;
     h->param.rc.i_rc_method = X264_RC_CQP; h->param.rc.i_qp_constant = p->qp; h->param.rc.i_aq_mode = 0;
+    h->param.i_keyint_max = p->keyint > 0 ? p->keyint : 1 << 30;
+    if (stream) {                                        /* x264_validate_parameters, R/encoder/encoder.c:455-470 */
+        h->param.i_bframe_adaptive = x264_clip3(e->b_adapt, X264_B_ADAPT_NONE, X264_B_ADAPT_TRELLIS);
+        h->param.i_bframe_bias = x264_clip3(e->bframe_bias, -90, 100);
+        h->param.b_pre_scenecut = e->pre_scenecut; h->param.i_scenecut_threshold = e->scenecut_threshold;
+        h->param.i_keyint_min = e->keyint_min > 0 ? e->keyint_min : h->param.i_keyint_max / 10;
+        h->param.i_keyint_min = x264_clip3(h->param.i_keyint_min, 1, h->param.i_keyint_max / 2 + 1);
+        if (e->crf >= 0) { h->param.rc.i_rc_method = X264_RC_CRF; h->param.rc.f_rf_constant = e->crf; }
+    }
     if (e) {                                             /* x264_validate_parameters, R/encoder/encoder.c:493-522 */
         h->param.analyse.i_trellis = p->cabac ? x264_clip3(e->trellis, 0, 2) : 0;
         h->param.analyse.f_psy_rd = p->subme < 6 ? 0 : x264_clip3f(e->psy_rd, 0, 10);
@@ -181,7 +206,7 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     x264_predict_16x16_init(0, h->predict_16x16); x264_predict_8x8c_init(0, h->predict_8x8c);
     x264_predict_8x8_init(0, h->predict_8x8, &h->predict_8x8_filter); x264_predict_4x4_init(0, h->predict_4x4);
     sel_cmp(h);
-    h->frames.b_have_lowres = 0;
+    h->frames.b_have_lowres = stream;
     h->frames.b_have_sub8x8_esa = !!(h->param.analyse.inter & X264_ANALYSE_PSUB8x8);   /* encoder.c:717: the 4x4 integral plane of ESA */
     h->fenc = x264_frame_new(h);
     h->fdec = x264_frame_new(h);
@@ -196,58 +221,32 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
         if (h->param.rc.i_aq_mode) h->fenc->i_inv_qscale_factor = x264_malloc(n * sizeof(uint16_t));     /* written by x264_adaptive_quant_frame */
     }
     if (b_write) bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
+    c->bsbuf = bsbuf; c->b_write = b_write; c->mb_w = mb_w; c->mb_h = mb_h; c->n = n; c->cw = p->width / 2; c->ch = p->height / 2;
+    return 0;
+}
 
-    /* coding order (what x264_slicetype_decide + the frame reordering of x264_encoder_encode give for a fixed B pattern):
-     * anchors every bframes + 1 frames from the last IDR, the last frame before an IDR / the end of the clip is an anchor too;
-     * each anchor is coded before the B frames that precede it in display order */
-    const int nb = e ? h->param.i_bframe : 0, dpb = X264_MAX(p->n_refs, nb ? 2 : 1);   /* sps->vui.i_max_dec_frame_buffering, set.c */
-    int *order = malloc(sizeof(int) * p->n_frames), *ftype = malloc(sizeof(int) * p->n_frames), n_order = 0;
-    for (int t = 0; t < p->n_frames;) {
-        int is_idr = p->keyint > 0 ? t % p->keyint == 0 : t == 0;
-        if (is_idr) { order[n_order] = t; ftype[n_order++] = X264_TYPE_IDR; t++; continue; }
-        int next_idr = p->keyint > 0 ? (t / p->keyint + 1) * p->keyint : p->n_frames, lim = X264_MIN(next_idr, p->n_frames);
-        int anchor = X264_MIN(t + nb, lim - 1);
-        order[n_order] = anchor; ftype[n_order++] = X264_TYPE_P;
-        for (int b = t; b < anchor; b++) { order[n_order] = b; ftype[n_order++] = X264_TYPE_B; }
-        t = anchor + 1;
+/* x264_frame_copy_picture + x264_frame_expand_border_mod16 (R/encoder/encoder.c:1406-1413) */
+static void load_picture(rctx *c, const refslice_params *p, x264_frame_t *fr, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, size_t D)
+{
+    int y;
+    for (y = 0; y < p->height; y++)
+        memcpy(fr->plane[0] + y * fr->i_stride[0], src_y + (D * p->height + y) * p->width, p->width);
+    for (y = 0; y < c->ch; y++) {
+        memcpy(fr->plane[1] + y * fr->i_stride[1], src_u + (D * c->ch + y) * c->cw, c->cw);
+        memcpy(fr->plane[2] + y * fr->i_stride[2], src_v + (D * c->ch + y) * c->cw, c->cw);
     }
-    for (f = 0; f < p->n_frames; f++) {
-        const int disp = order[f], is_b = ftype[f] == X264_TYPE_B;
-        int idr = ftype[f] == X264_TYPE_IDR;
-        size_t F = f, D = disp;
-        if (idr) {
-            for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
-            n_avail = 0; last_idr = disp;
-        }
-        /* x264_frame_copy_picture + x264_frame_expand_border_mod16 (R/encoder/encoder.c:1406-1413) */
-        for (y = 0; y < p->height; y++)
-            memcpy(h->fenc->plane[0] + y * h->fenc->i_stride[0], src_y + (D * p->height + y) * p->width, p->width);
-        for (y = 0; y < ch; y++) {
-            memcpy(h->fenc->plane[1] + y * h->fenc->i_stride[1], src_u + (D * ch + y) * cw, cw);
-            memcpy(h->fenc->plane[2] + y * h->fenc->i_stride[2], src_v + (D * ch + y) * cw, cw);
-        }
-        x264_frame_expand_border_mod16(h, h->fenc);
-        h->fenc->i_frame = disp; h->fenc->i_poc = 2 * (disp - last_idr);
-        h->fenc->i_type = ftype[f];
-        h->fdec->i_frame = disp; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type;
-        h->fenc->b_kept_as_ref = h->fdec->b_kept_as_ref = !is_b;
-        h->i_frame = f;                                   /* frames coded so far (x264_reference_update, encoder.c:1063) */
-        if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, h->fenc);   /* encoder.c:1421 */
-        /* x264_reference_build_list, R/encoder/encoder.c:911-981: by POC, list 0 downwards from the frame, list 1 upwards */
-        h->i_ref0 = h->i_ref1 = 0;
-        for (i = 0; i < n_avail; i++) {
-            if (refs[i]->i_poc < h->fdec->i_poc) h->fref0[h->i_ref0++] = refs[i];
-            else if (refs[i]->i_poc > h->fdec->i_poc) h->fref1[h->i_ref1++] = refs[i];
-        }
-        for (i = 0; i < h->i_ref0; i++)
-            for (k = i + 1; k < h->i_ref0; k++)
-                if (h->fref0[k]->i_poc > h->fref0[i]->i_poc) { x264_frame_t *t_ = h->fref0[i]; h->fref0[i] = h->fref0[k]; h->fref0[k] = t_; }
-        for (i = 0; i < h->i_ref1; i++)
-            for (k = i + 1; k < h->i_ref1; k++)
-                if (h->fref1[k]->i_poc < h->fref1[i]->i_poc) { x264_frame_t *t_ = h->fref1[i]; h->fref1[i] = h->fref1[k]; h->fref1[k] = t_; }
-        h->i_ref1 = X264_MIN(h->i_ref1, nb ? 1 : 0);                /* h->frames.i_max_ref1 = sps->vui.i_num_reorder_frames */
-        h->i_ref0 = X264_MIN(h->i_ref0, p->n_refs);
-        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = h->i_ref1;
+    x264_frame_expand_border_mod16(c->h, fr);
+}
+
+/* one slice: x264_ratecontrol_start, x264_slice_init's fields, x264_slice_write's loop, the frame end (h->fenc, h->fdec, the lists are set) */
+static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, refslice_out *o, refslice_out2 *o2, size_t F, int disp)
+{
+    x264_t *h = c->h;
+    uint8_t *bsbuf = c->bsbuf;
+    const int b_write = c->b_write, mb_w = c->mb_w, mb_h = c->mb_h, n = c->n, stream = c->stream;
+    const int is_b = IS_X264_TYPE_B(h->fenc->i_type), idr = IS_X264_TYPE_I(h->fenc->i_type);
+    int i, k, y;
+    {
         memset(&h->sh, 0, sizeof(h->sh));
         h->sh.i_type = idr ? SLICE_TYPE_I : is_b ? SLICE_TYPE_B : SLICE_TYPE_P;
         h->sh.b_direct_spatial_mv_pred = h->param.analyse.i_direct_mv_pred == X264_DIRECT_PRED_SPATIAL;   /* x264_slice_header_init, encoder.c:116-122 */
@@ -259,7 +258,13 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
         h->sh.i_cabac_init_idc = h->param.i_cabac_init_idc;
         x264_ratecontrol_start(h, 0);
         h->sh.i_qp = x264_ratecontrol_qp(h);
-        if (e && e->lowres_mv) {                         /* this frame's lookahead vectors, filed under the distance to the reference they point at */
+        if (stream && o2->look_mv) {                     /* what x264_mb_analyse_inter_p16x16 / _b16x16 will be offered (R/encoder/analyse.c:1085-1100) */
+            int16_t *lm = o2->look_mv + (size_t)F * 2 * n * 2;
+            for (i = 0; i < 2 * n * 2; i++) lm[i] = i & 1 ? 0 : 0x7fff;
+            if (h->i_ref0 > 0) memcpy(lm, h->fenc->lowres_mvs[0][h->fenc->i_frame - h->fref0[0]->i_frame - 1], 2 * n * sizeof(int16_t));
+            if (h->i_ref1 > 0) memcpy(lm + 2 * n, h->fenc->lowres_mvs[1][h->fref1[0]->i_frame - h->fenc->i_frame - 1], 2 * n * sizeof(int16_t));
+        }
+        if (!stream && e && e->lowres_mv) {              /* this frame's lookahead vectors, filed under the distance to the reference they point at */
             const int16_t *lm = e->lowres_mv + (size_t)F * 2 * n * 2;
             if (h->i_ref0 > 0) memcpy(h->fenc->lowres_mvs[0][h->fenc->i_frame - h->fref0[0]->i_frame - 1], lm, 2 * n * sizeof(int16_t));
             if (h->i_ref1 > 0) memcpy(h->fenc->lowres_mvs[1][h->fref1[0]->i_frame - h->fenc->i_frame - 1], lm + 2 * n, 2 * n * sizeof(int16_t));
@@ -317,6 +322,7 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
                 if (o2->mb_bits[M] / 8 + 2048 > e->payload_cap) return -5;
             }
             x264_macroblock_cache_save(h);
+            if (stream) x264_ratecontrol_mb(h, mb ? o2->mb_bits[M] - o2->mb_bits[M - 1] : o2->mb_bits[M]);   /* encoder.c:1240 */
             h->stat.frame.i_mb_count[h->mb.i_type]++;
             if (o2) o2->qp_offset[M] = h->param.rc.i_aq_mode ? h->fenc->f_qp_offset[mb] : 0;
 
@@ -375,6 +381,14 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
             if (len > e->payload_cap) return -5;
             o2->payload_len[F] = len;
             memcpy(o2->payload + F * e->payload_cap, bsbuf + 64, len);
+            if (stream) {                                 /* x264_encoder_frame_end, encoder.c:1736: the rate control's state after the frame */
+                x264_ratecontrol_end(h, 8 * len);
+                h->stat.i_slice_size[h->sh.i_type] += len + 5;      /* NALU_OVERHEAD, encoder.c:44 */
+                if (o2->rc_info) {
+                    o2->rc_info[4 * F] = h->sh.i_qp; o2->rc_info[4 * F + 1] = h->fdec->f_qp_avg_rc;
+                    o2->rc_info[4 * F + 2] = h->fdec->i_satd; o2->rc_info[4 * F + 3] = h->fdec->f_qp_avg_aq;
+                }
+            }
         }
         filter_row(h, mb_h);
         x264_noise_reduction_update(h);                      /* x264_encoder_frame_end, R/encoder/encoder.c:1755 */
@@ -386,6 +400,67 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
             memcpy(o->fin_u + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[1] + y * h->fdec->i_stride[1], 8 * mb_w);
             memcpy(o->fin_v + (F * 8 * mb_h + y) * 8 * mb_w, h->fdec->plane[2] + y * h->fdec->i_stride[2], 8 * mb_w);
         }
+    }
+    return 0;
+}
+
+static int run_chain(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
+                     refslice_out *o, refslice_out2 *o2)
+{
+    rctx cx, *c = &cx;
+    int rc_ = setup_encoder(c, p, e, 0);
+    if (rc_) return rc_;
+    x264_t *h = c->h;
+    x264_frame_t *refs[16] = {0};
+    int n_avail = 0, f, i, k, last_idr = 0;
+    const int n = c->n;
+    (void)n;
+
+    /* coding order (what x264_slicetype_decide + the frame reordering of x264_encoder_encode give for a fixed B pattern):
+     * anchors every bframes + 1 frames from the last IDR, the last frame before an IDR / the end of the clip is an anchor too;
+     * each anchor is coded before the B frames that precede it in display order */
+    const int nb = e ? h->param.i_bframe : 0, dpb = X264_MAX(p->n_refs, nb ? 2 : 1);   /* sps->vui.i_max_dec_frame_buffering, set.c */
+    int *order = malloc(sizeof(int) * p->n_frames), *ftype = malloc(sizeof(int) * p->n_frames), n_order = 0;
+    for (int t = 0; t < p->n_frames;) {
+        int is_idr = p->keyint > 0 ? t % p->keyint == 0 : t == 0;
+        if (is_idr) { order[n_order] = t; ftype[n_order++] = X264_TYPE_IDR; t++; continue; }
+        int next_idr = p->keyint > 0 ? (t / p->keyint + 1) * p->keyint : p->n_frames, lim = X264_MIN(next_idr, p->n_frames);
+        int anchor = X264_MIN(t + nb, lim - 1);
+        order[n_order] = anchor; ftype[n_order++] = X264_TYPE_P;
+        for (int b = t; b < anchor; b++) { order[n_order] = b; ftype[n_order++] = X264_TYPE_B; }
+        t = anchor + 1;
+    }
+    for (f = 0; f < p->n_frames; f++) {
+        const int disp = order[f], is_b = ftype[f] == X264_TYPE_B;
+        int idr = ftype[f] == X264_TYPE_IDR;
+        size_t F = f, D = disp;
+        if (idr) {
+            for (i = 0; i < n_avail; i++) x264_frame_delete(refs[i]);
+            n_avail = 0; last_idr = disp;
+        }
+        load_picture(c, p, h->fenc, src_y, src_u, src_v, D);
+        h->fenc->i_frame = disp; h->fenc->i_poc = 2 * (disp - last_idr);
+        h->fenc->i_type = ftype[f];
+        h->fdec->i_frame = disp; h->fdec->i_poc = h->fenc->i_poc; h->fdec->i_type = h->fenc->i_type;
+        h->fenc->b_kept_as_ref = h->fdec->b_kept_as_ref = !is_b;
+        h->i_frame = f;                                   /* frames coded so far (x264_reference_update, encoder.c:1063) */
+        if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, h->fenc);   /* encoder.c:1421 */
+        /* x264_reference_build_list, R/encoder/encoder.c:911-981: by POC, list 0 downwards from the frame, list 1 upwards */
+        h->i_ref0 = h->i_ref1 = 0;
+        for (i = 0; i < n_avail; i++) {
+            if (refs[i]->i_poc < h->fdec->i_poc) h->fref0[h->i_ref0++] = refs[i];
+            else if (refs[i]->i_poc > h->fdec->i_poc) h->fref1[h->i_ref1++] = refs[i];
+        }
+        for (i = 0; i < h->i_ref0; i++)
+            for (k = i + 1; k < h->i_ref0; k++)
+                if (h->fref0[k]->i_poc > h->fref0[i]->i_poc) { x264_frame_t *t_ = h->fref0[i]; h->fref0[i] = h->fref0[k]; h->fref0[k] = t_; }
+        for (i = 0; i < h->i_ref1; i++)
+            for (k = i + 1; k < h->i_ref1; k++)
+                if (h->fref1[k]->i_poc < h->fref1[i]->i_poc) { x264_frame_t *t_ = h->fref1[i]; h->fref1[i] = h->fref1[k]; h->fref1[k] = t_; }
+        h->i_ref1 = X264_MIN(h->i_ref1, nb ? 1 : 0);                /* h->frames.i_max_ref1 = sps->vui.i_num_reorder_frames */
+        h->i_ref0 = X264_MIN(h->i_ref0, p->n_refs);
+        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = h->i_ref1;
+        if ((rc_ = code_frame(c, p, e, o, o2, F, disp)) != 0) return rc_;
         /* x264_reference_update, encoder.c:1060-1093: a disposable frame is dropped, a kept one pushes the oldest out of the DPB */
         if (!is_b) {
             if (n_avail == 16) x264_frame_delete(refs[--n_avail]);
@@ -400,7 +475,7 @@ static int run_chain(const refslice_params *p, const refslice_ext *e, const uint
     x264_ratecontrol_delete(h);
     x264_macroblock_cache_end(h);
     x264_cqm_delete(h);
-    free(bsbuf); free(order); free(ftype);
+    free(c->bsbuf); free(order); free(ftype);
     free(h);
     return 0;
 }
@@ -415,4 +490,114 @@ int refslice_encode_chain2(const refslice_params *p, const refslice_ext *e, cons
                            const uint8_t *src_v, refslice_out *o, refslice_out2 *o2)
 {
     return run_chain(p, e, src_y, src_u, src_v, o, o2);
+}
+
+/* x264_encoder_encode's frame queue with the real lookahead and rate control in front of the slice loop (R/encoder/encoder.c:1340-1600, one thread):
+ * every picture enters frames.next with its half-resolution planes, x264_slicetype_decide types the head of the queue once the delay is filled,
+ * the typed mini-GOP moves to frames.current anchor first, x264_ratecontrol_start prices the frame (CRF reads x264_rc_analyse_slice), and
+ * x264_reference_update hands the source's lowres planes to the reconstructed frame.  The scene cut of the non-"pre" kind re-encodes a frame from
+ * its own statistics (encoder.c:1640-1700) and is refused here: pre_scenecut on, or the threshold off. */
+static int run_stream(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
+                      refslice_out *o, refslice_out2 *o2)
+{
+    rctx cx, *c = &cx;
+    int rc_, i, fed = 0, coded = 0;
+    if (!e || !e->write || !o2) return -4;
+    if (!e->pre_scenecut && e->scenecut_threshold >= 0) return -6;
+    if ((rc_ = setup_encoder(c, p, e, 1)) != 0) return rc_;
+    x264_t *h = c->h;
+    x264_frame_delete(h->fenc); x264_frame_delete(h->fdec);      /* made before b_have_lowres was known to x264_frame_new */
+    h->frames.i_delay = h->param.i_bframe_adaptive == X264_B_ADAPT_TRELLIS ? X264_MAX(h->param.i_bframe, 3) * 4 : h->param.i_bframe;
+    h->frames.i_max_ref0 = h->param.i_frame_reference;
+    h->frames.i_max_ref1 = h->param.i_bframe ? 1 : 0;            /* sps->vui.i_num_reorder_frames, R/encoder/set.c:176 */
+    h->frames.i_max_dpb = X264_MIN(16, X264_MAX(h->param.i_frame_reference, 1 + h->frames.i_max_ref1));
+    h->frames.i_last_idr = -h->param.i_keyint_max;
+    h->frames.i_input = 0; h->frames.last_nonb = NULL;
+    h->fenc = NULL;
+    h->fdec = x264_frame_pop_unused(h);
+    h->i_frame = 0;
+
+    while (coded < p->n_frames) {
+        /* x264_reference_update, encoder.c:1060-1093 */
+        if (h->fdec->i_frame >= 0) h->i_frame++;
+        if (h->fdec->b_kept_as_ref) {
+            for (i = 0; i < 4; i++) {
+                XCHG(uint8_t *, h->fdec->lowres[i], h->fenc->lowres[i]);
+                XCHG(uint8_t *, h->fdec->buffer_lowres[i], h->fenc->buffer_lowres[i]);
+            }
+            if (h->sh.i_type != SLICE_TYPE_B) h->frames.last_nonb = h->fdec;
+            x264_frame_push(h->frames.reference, h->fdec);
+            if (h->frames.reference[h->frames.i_max_dpb]) x264_frame_push_unused(h, x264_frame_shift(h->frames.reference));
+            h->fdec = x264_frame_pop_unused(h);
+        }
+        if (h->fenc) { x264_frame_push_unused(h, h->fenc); h->fenc = NULL; }     /* x264_encoder_frame_end, encoder.c:1722 */
+        h->fdec->i_frame = -1; h->fdec->b_kept_as_ref = 0;                       /* a recycled frame is not "coded" until it is */
+
+        if (fed < p->n_frames) {
+            x264_frame_t *fr = x264_frame_pop_unused(h);
+            load_picture(c, p, fr, src_y, src_u, src_v, fed);
+            fr->i_frame = h->frames.i_input++; fr->i_type = X264_TYPE_AUTO; fr->i_qpplus1 = 0;
+            fed++;
+            x264_frame_push(h->frames.next, fr);
+            x264_frame_init_lowres(h, fr);
+            if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, fr);
+            if (h->frames.i_input <= h->frames.i_delay) continue;                /* encoder.c:1425: the B buffer is filling */
+        }
+        if (h->frames.current[0] == NULL) {
+            int bframes = 0;
+            if (h->frames.next[0] == NULL) break;
+            x264_slicetype_decide(h);
+            while (IS_X264_TYPE_B(h->frames.next[bframes]->i_type)) bframes++;
+            x264_frame_push(h->frames.current, x264_frame_shift(&h->frames.next[bframes]));
+            while (bframes--) x264_frame_push(h->frames.current, x264_frame_shift(h->frames.next));
+        }
+        h->fenc = x264_frame_shift(h->frames.current);
+        if (h->fenc->i_type == X264_TYPE_IDR) {
+            h->frames.i_last_idr = h->fenc->i_frame;
+            while (h->frames.reference[0]) x264_frame_push_unused(h, x264_frame_pop(h->frames.reference));   /* x264_reference_reset */
+        }
+        const int is_b = IS_X264_TYPE_B(h->fenc->i_type);
+        h->fdec->i_poc = h->fenc->i_poc = 2 * (h->fenc->i_frame - h->frames.i_last_idr);
+        h->fdec->i_type = h->fenc->i_type; h->fdec->i_frame = h->fenc->i_frame;
+        h->fenc->b_kept_as_ref = h->fdec->b_kept_as_ref = !is_b && h->param.i_keyint_max > 1;
+        /* x264_reference_build_list, encoder.c:911-981 */
+        h->i_ref0 = h->i_ref1 = 0;
+        for (i = 0; h->frames.reference[i]; i++) {
+            if (h->frames.reference[i]->i_poc < h->fdec->i_poc) h->fref0[h->i_ref0++] = h->frames.reference[i];
+            else if (h->frames.reference[i]->i_poc > h->fdec->i_poc) h->fref1[h->i_ref1++] = h->frames.reference[i];
+        }
+        for (i = 0; i < h->i_ref0; i++)
+            for (int k = i + 1; k < h->i_ref0; k++)
+                if (h->fref0[k]->i_poc > h->fref0[i]->i_poc) XCHG(x264_frame_t *, h->fref0[i], h->fref0[k]);
+        for (i = 0; i < h->i_ref1; i++)
+            for (int k = i + 1; k < h->i_ref1; k++)
+                if (h->fref1[k]->i_poc < h->fref1[i]->i_poc) XCHG(x264_frame_t *, h->fref1[i], h->fref1[k]);
+        h->i_ref1 = X264_MIN(h->i_ref1, h->frames.i_max_ref1);
+        h->i_ref0 = X264_MIN(h->i_ref0, h->frames.i_max_ref0);
+        h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = h->i_ref1;
+        /* x264_rc_analyse_slice reads frames.current behind the P frame; code_frame calls x264_ratecontrol_start */
+        if ((rc_ = code_frame(c, p, e, o, o2, coded, h->fenc->i_frame)) != 0) return rc_;
+        if (o2->look_cost) {
+            int32_t *lc = o2->look_cost + 8 * (size_t)coded;
+            int d0 = h->i_ref0 && !IS_X264_TYPE_I(h->fenc->i_type) ? h->fenc->i_frame - h->fref0[0]->i_frame : 0;
+            int d1 = is_b ? h->fref1[0]->i_frame - h->fenc->i_frame : 0;
+            lc[0] = is_b ? 0 : h->fenc->i_cost_est[d0][d1]; lc[1] = is_b ? 0 : h->fenc->i_cost_est_aq[d0][d1];
+            lc[2] = is_b ? 0 : h->fenc->i_intra_mbs[d0]; lc[3] = h->fenc->i_cost_est[0][0]; lc[4] = d0; lc[5] = d1; lc[6] = h->fenc->i_type; lc[7] = 0;
+        }
+        coded++;
+    }
+    /* the frames are left to the process: the harness is one call per chain in a test, and x264_frame_delete of a frame whose lowres planes were
+     * exchanged is the encoder's own business at x264_encoder_close */
+    x264_ratecontrol_delete(h);
+    x264_macroblock_cache_end(h);
+    x264_cqm_delete(h);
+    free(c->bsbuf);
+    free(h);
+    return coded == p->n_frames ? 0 : -7;
+}
+
+int refslice_encode_stream(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u,
+                           const uint8_t *src_v, refslice_out *o, refslice_out2 *o2)
+{
+    return run_stream(p, e, src_y, src_u, src_v, o, o2);
 }

@@ -65,17 +65,21 @@ class Ext(C.Structure):
     """refslice_ext (oracle/ref_slice.c): what refslice_encode_chain2 takes on top of Params."""
     _fields_ = [("trellis", C.c_int), ("psy_rd", C.c_float), ("psy_trellis", C.c_float), ("aq_mode", C.c_int),
                 ("aq_strength", C.c_float), ("write", C.c_int), ("payload_cap", C.c_int), ("cabac_init_idc", C.c_int),
-                ("bframes", C.c_int), ("weightb", C.c_int), ("direct_pred", C.c_int), ("lowres_mv", C.c_void_p)]
+                ("bframes", C.c_int), ("weightb", C.c_int), ("direct_pred", C.c_int), ("lowres_mv", C.c_void_p),
+                ("b_adapt", C.c_int), ("pre_scenecut", C.c_int), ("scenecut_threshold", C.c_int), ("keyint_min", C.c_int),
+                ("crf", C.c_float), ("bframe_bias", C.c_int)]
 
 
 DIRECT_SPATIAL, DIRECT_TEMPORAL = 1, 2       # R/x264.h:93-96
 
 
 def make_ext(trellis=0, psy_rd=0.0, psy_trellis=0.0, aq_mode=0, aq_strength=1.0, write=1, payload_cap=0, cabac_init_idc=0,
-             bframes=0, weightb=0, direct_pred=DIRECT_SPATIAL, lowres_mv=None, lowres_seed=None):
+             bframes=0, weightb=0, direct_pred=DIRECT_SPATIAL, lowres_mv=None, lowres_seed=None,
+             b_adapt=0, pre_scenecut=0, scenecut_threshold=-1, keyint_min=0, crf=-1.0, bframe_bias=0):
     """lowres_mv: int16 [frames in coding order][2 lists][n_mb][2], the lookahead's vectors (0x7fff in a frame / list's first component:
     none); the array must outlive the call.  lowres_seed: run2 makes that array itself with lowres_vectors(seed, ...)."""
-    e = Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc, bframes, weightb, direct_pred, None)
+    e = Ext(trellis, psy_rd, psy_trellis, aq_mode, aq_strength, write, payload_cap, cabac_init_idc, bframes, weightb, direct_pred, None,
+            b_adapt, pre_scenecut, scenecut_threshold, keyint_min, crf, bframe_bias)
     if lowres_mv is not None:
         assert lowres_mv.dtype == np.int16 and lowres_mv.flags["C_CONTIGUOUS"]
         e.lowres_mv = lowres_mv.ctypes.data
@@ -102,7 +106,11 @@ OUT2_FIELDS = [("payload", np.uint8, lambda F, n, cap: (F, cap)),
                ("qp_offset", np.float32, lambda F, n, cap: (F, n)),
                ("mv1", np.int16, lambda F, n, cap: (F, n, 16, 2)),
                ("ref1", np.int8, lambda F, n, cap: (F, n, 4)),
-               ("frame_info2", np.int32, lambda F, n, cap: (F, 4))]
+               ("frame_info2", np.int32, lambda F, n, cap: (F, 4)),
+               # the stream entry only (the real lookahead and rate control in front of the loop)
+               ("rc_info", np.float32, lambda F, n, cap: (F, 4)),
+               ("look_mv", np.int16, lambda F, n, cap: (F, 2, n, 2)),
+               ("look_cost", np.int32, lambda F, n, cap: (F, 8))]
 
 
 class Out2(C.Structure):
@@ -170,3 +178,8 @@ def run_reference(p, y, u, v):
 
 def run_reference2(p, e, y, u, v):
     return run2(reference_lib(), "refslice_encode_chain2", p, e, y, u, v)
+
+
+def run_reference_stream(p, e, y, u, v):
+    """x264_encoder_encode's queue: slice types from x264_slicetype_decide, QPs from x264_ratecontrol_start (e.crf >= 0: CRF)."""
+    return run2(reference_lib(), "refslice_encode_stream", p, e, y, u, v)

@@ -462,6 +462,65 @@ typedef struct {
 } x264hip_deblock_params;
 int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x264hip_deblock_params *p);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Lookahead and rate control of ONE GOP chain: the host half.  x264_encoder_encode's frame queue (R/encoder/encoder.c:1390-1470:
+ * frames.next / frames.current, the B-frame delay, x264_reference_update's last_nonb and DPB), x264_slicetype_decide with
+ * x264_slicetype_analyse (b-adapt 1 and 2, the pre-encode scene cut; R/encoder/slicetype.c:359-636), x264_rc_analyse_slice (:638-680)
+ * and the rate control of constant QP and CRF (x264_ratecontrol_new / _start / _mb / _end, rate_estimate_qscale, get_qscale,
+ * accum_p_qp_update; R/encoder/ratecontrol.c:268-420, 776-870, 1077-1160, 1168-1195, 1396-1615), in the library's host C with the
+ * reference's float / double types expression by expression.  No device involved: the per-frame costs the decisions read
+ * (x264_slicetype_frame_cost) are REQUESTED -- x264hip_lookahead_get returns X264HIP_LOOK_NEED with the tasks whose results it
+ * lacks; the caller computes them (x264hip_lookahead_cost_frames on the GPU for all its chains at once), hands the results back with
+ * x264hip_lookahead_set_cost and calls get again.  A cost is a pure function of (b, p0, p1) and the pictures, so the order in which
+ * they are computed does not change any of them; get restarts its decision from the unchanged queue every time.
+ * Not here: 2-pass, ABR, VBV, zones, B-pyramid, the scene cut that re-encodes (param.b_pre_scenecut = 0 with a threshold >= 0). */
+typedef struct x264hip_lookahead x264hip_lookahead;
+typedef struct {
+    int mb_w, mb_h;
+    int bframes, b_adapt, bframe_bias;           /* param.i_bframe, i_bframe_adaptive (0 none, 1 fast, 2 trellis), i_bframe_bias */
+    int keyint_max, keyint_min;                  /* as x264_validate_parameters leaves them (min: clip(min ? min : max / 10 ..., 1, max / 2 + 1)) */
+    int scenecut_threshold, pre_scenecut;        /* param.i_scenecut_threshold (< 0: off), b_pre_scenecut */
+    int rc_method;                               /* 0: X264_RC_CQP, 1: X264_RC_CRF */
+    int qp_constant;                             /* param.rc.i_qp_constant */
+    float rf_constant, ip_factor, pb_factor, qcompress;   /* param.rc.f_rf_constant, f_ip_factor (1.4), f_pb_factor (1.3), f_qcompress (0.6) */
+    int qp_min, qp_max, qp_step;                 /* param.rc.i_qp_min (10), i_qp_max (51), i_qp_step (4) */
+} x264hip_lookahead_params;
+/* one x264_slicetype_frame_cost to compute: frame numbers in input order (p0 == p1 == b: the intra cost of b alone) */
+typedef struct {
+    int b, p0, p1;
+    int do_search[2];        /* frames[b]->lowres_mvs[l][dist - 1] carries the "not searched" marker: search list l and keep the vectors */
+    int speculative;         /* 1: not asked for yet, but independent of everything else in this batch and likely to be (b-adapt 1's next costs) */
+} x264hip_look_need;
+/* the frame x264_encoder_encode would code now */
+typedef struct {
+    int frame;               /* input number (fenc->i_frame) */
+    int type;                /* X264_TYPE_IDR 1, I 2, P 3, B 5 (R/x264.h:116-121) */
+    int poc, kept_as_ref;
+    int qp;                  /* rc->qp = h->sh.i_qp */
+    float f_qpm;             /* rc->f_qpm: the QP before rounding, what x264_adaptive_quant adds its offset to */
+    int ref0_frame, ref1_frame;          /* fref0[0]->i_frame, fref1[0]->i_frame or -1 */
+    int lowres_l0, lowres_l1;            /* 1: fenc->lowres_mvs[0][frame - ref0_frame - 1] / [1][ref1_frame - frame - 1] was searched -- the vectors
+                                          * x264_mb_predict_mv_ref16x16 offers the 16x16 search (R/common/macroblock.c:393-398) */
+    int i_satd;              /* fdec->i_satd (x264_rc_analyse_slice) or 0 */
+} x264hip_look_frame;
+enum { X264HIP_LOOK_NONE = 0, X264HIP_LOOK_FRAME = 1, X264HIP_LOOK_NEED = 2, X264HIP_LOOK_END = 3 };
+x264hip_lookahead *x264hip_lookahead_new(const x264hip_lookahead_params *p);
+void x264hip_lookahead_delete(x264hip_lookahead *la);
+/* a picture enters frames.next (encoder.c:1404-1421); returns its input number.  Its lowres planes and intra costs are the caller's
+ * (x264hip_lowres_init_frame, x264hip_lookahead_intra_frame). */
+int x264hip_lookahead_put(x264hip_lookahead *la);
+/* the rest of x264_encoder_encode up to the slice: NONE = the B buffer is still filling (call put again); FRAME = *out is to be coded
+ * now; NEED = n_need tasks in need[] first (at most max_need, >= 1); END = flushing and nothing left.  flushing: no more input. */
+int x264hip_lookahead_get(x264hip_lookahead *la, int flushing, x264hip_look_frame *out, x264hip_look_need *need, int max_need, int *n_need);
+/* a computed task: frame->i_cost_est[b - p0][p1 - b] = score, i_intra_mbs[b - p0], i_cost_est[0][0] (the latter two when b == p1).
+ * speculative (as the need said): kept aside until the decision asks for it -- a cost the reference never computes must not make its
+ * vectors visible to the main encode (lowres_l0 / lowres_l1 of x264hip_look_frame). */
+void x264hip_lookahead_set_cost(x264hip_lookahead *la, int b, int p0, int p1, int score, int intra_mbs, int cost00, int speculative);
+/* x264_ratecontrol_end + the next call's x264_reference_update for the frame get returned */
+void x264hip_lookahead_end(x264hip_lookahead *la);
+/* frames the caller may drop now: every input number < the returned one is neither queued, nor last_nonb, nor a reference */
+int x264hip_lookahead_oldest_live(const x264hip_lookahead *la);
+
 #ifdef __cplusplus
 }
 #endif

@@ -917,5 +917,6 @@ void x264o_frame_deblock(u8 *py, u8 *pu, u8 *pv, int mb_w, int mb_h, int sy, int
 }
 
 #ifndef X264O_USE_REF
+#include "look_oracle.c"      /* the lookahead's per-frame cost (x264_slicetype_frame_cost) */
 #include "slice_oracle.c"     /* the per-macroblock sweep twin; shares the helpers above */
 #endif

@@ -539,6 +539,12 @@ static int run_stream(const refslice_params *p, const refslice_ext *e, const uin
             fr->i_frame = h->frames.i_input++; fr->i_type = X264_TYPE_AUTO; fr->i_qpplus1 = 0;
             fed++;
             x264_frame_push(h->frames.next, fr);
+            /* Two places x264_frame_init_lowres reads but nobody writes: the luma sample below-right of the picture (it copies the last row
+             * without its duplicated last column, R/common/mc.c:316-317) and, when the lowres width is not a multiple of 16, the columns
+             * between it and stride - 64, which x264_frame_expand_border_lowres takes for picture content (R/common/frame.c:297-302).  In
+             * the encoder they hold what malloc / an earlier reconstruction left; fresh pages give 0, and so does this harness, every time. */
+            memset(fr->buffer_lowres[0], 0, 4 * (size_t)fr->i_stride_lowres * (fr->i_lines[0] / 2 + 2 * PADV));
+            fr->plane[0][fr->i_stride[0] * fr->i_lines[0] + fr->i_width[0]] = 0;
             x264_frame_init_lowres(h, fr);
             if (h->param.rc.i_aq_mode) x264_adaptive_quant_frame(h, fr);
             if (h->frames.i_input <= h->frames.i_delay) continue;                /* encoder.c:1425: the B buffer is filling */

@@ -521,6 +521,38 @@ void x264hip_lookahead_end(x264hip_lookahead *la);
 /* frames the caller may drop now: every input number < the returned one is neither queued, nor last_nonb, nor a reference */
 int x264hip_lookahead_oldest_live(const x264hip_lookahead *la);
 
+/* The device half: x264_slicetype_frame_cost (with x264_slicetype_mb_cost, R/encoder/slicetype.c:43-345) for many chains at once, one
+ * task per wavefront.  A slot is one input frame of every chain of the context's batch: its picture (lowres planes from
+ * x264hip_lowres_init_frame), its intra costs (x264hip_lookahead_intra_frame) and its vectors and their costs for every (list, distance)
+ * -- fenc->lowres_mvs / lowres_mv_costs.  mv: int16 [batch][2][bframes + 1][n_mb][2], mv_cost: int32 [batch][2][bframes + 1][n_mb]; zeroed
+ * once by the caller (the frame's edge macroblocks are never searched and are read as zero vectors).  A task names its three frames by
+ * slot, its chain, the distances d0 = b - p0 and d1 = p1 - b (both 0: intra only) and which lists to search (x264hip_look_need);
+ * out_dev[task] = {i_cost_est, i_intra_mbs, i_cost_est[0][0], 0}.  Two tasks of one call must not search the same (chain, frame, list,
+ * distance), and a bidirectional task needs frames[p1]'s list-0 vectors over d0 + d1 from an EARLIER call (x264hip_lookahead_get asks
+ * in that order).  Asynchronous on the context's stream; staging_host (pinned) and tasks_dev hold n_tasks * x264hip_lookahead_task_bytes()
+ * and must not be reused before the stream has passed the call.  Refused: frames of <= 2 macroblock rows / columns, subme < 2, lossless. */
+typedef struct {
+    const x264hip_picture *pic;
+    const int32_t *intra_cost;   /* device [batch][n_mb] */
+    int16_t *mv;                 /* device */
+    int32_t *mv_cost;            /* device */
+} x264hip_look_slot;
+typedef struct {
+    int chain, slot_b, slot_p0, slot_p1, d0, d1;
+    int do_search[2];
+} x264hip_look_task;
+typedef struct {
+    int me_method, me_range;     /* param.analyse.i_me_method (the lookahead uses min(HEX, it)), i_me_range */
+    int weighted_bipred;         /* param.analyse.b_weighted_bipred */
+    int bframes, bframe_bias;    /* param.i_bframe (the arrays' second dimension is bframes + 1), i_bframe_bias */
+    int subme_param, lossless;   /* param.analyse.i_subpel_refine and qp == 0: what mbcmp is (encoder.c:608-618) */
+    const int16_t *cost_mv;      /* device: p_cost_mv of lambda 1 (x264_lambda_tab[12], slicetype.c:35), centre at cost_mv[cost_mv_range] */
+    int cost_mv_range;
+} x264hip_look_params;
+int x264hip_lookahead_cost_frames(x264hip_frame_ctx *c, const x264hip_look_slot *slots, int n_slots, const x264hip_look_task *tasks,
+                                  int n_tasks, const x264hip_look_params *p, void *staging_host, void *tasks_dev, int32_t *out_dev);
+size_t x264hip_lookahead_task_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

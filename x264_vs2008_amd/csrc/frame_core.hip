@@ -15,6 +15,7 @@
 #include <cstring>
 #include "device_prims.h"
 #include "frame_internal.h"
+#include "x264hip_lookahead.h"
 
 using namespace x264hip;
 
@@ -196,6 +197,10 @@ __global__ void k_dup_row(u8 *p, size_t bs, int stride, int width, int height)
     p += bs * blockIdx.z;
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x < width) p[(ptrdiff_t)height * stride + x] = p[(ptrdiff_t)(height - 1) * stride + x];
+    // The sample below-right of the picture feeds the last pixel of the HV lowres plane, and the reference never writes it (it copies
+    // `width` samples of the last row, not width + 1): there it holds what malloc or an earlier reconstruction's border left.  0 here,
+    // the value of a fresh page -- what oracle/ref_slice.c pins the reference to.
+    if (x == 0) p[(ptrdiff_t)height * stride + width] = 0;
 }
 
 // AQ energy per macroblock: var16x16(Y) + var8x8(U) + var8x8(V)
@@ -331,6 +336,15 @@ extern "C" int x264hip_picture_alloc_source(x264hip_frame_ctx *c, x264hip_pictur
     for (int i = 1; i < 3; i++)
         if (alloc_plane(&pic->plane[i], d.stride_c, d.lines_c, PADH / 2, PADV / 2, c->batch, c->bs_c, c->stream)) return -1;
     pic->filtered[0] = pic->plane[0];
+    return 0;
+}
+// A lookahead slot's picture: the source planes and the half-resolution planes (include/x264hip_lookahead.h)
+extern "C" int x264hip_picture_alloc_lookahead(x264hip_frame_ctx *c, x264hip_picture *pic)
+{
+    if (x264hip_picture_alloc_source(c, pic)) return -1;
+    pic->width_lowres = c->width_l; pic->lines_lowres = c->lines_l; pic->stride_lowres = c->stride_l;
+    for (int i = 0; i < 4; i++)
+        if (alloc_plane(&pic->lowres[i], c->stride_l, c->lines_l, PADH, PADV, c->batch, c->bs_l, c->stream)) return -1;
     return 0;
 }
 // batch element src_b of `src` -> element dst_b of `dst` (Y, U, V with their padding), on the context's stream

@@ -108,3 +108,191 @@ class Lookahead:
 
     def oldest_live(self):
         return self.lib.x264hip_lookahead_oldest_live(self.h)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The device half: every chain's lookahead data in HBM and the batched cost kernel (x264hip_lookahead_cost_frames).
+
+class LookSlot(C.Structure):
+    """x264hip_look_slot"""
+    _fields_ = [("pic", C.c_void_p), ("intra_cost", C.c_void_p), ("mv", C.c_void_p), ("mv_cost", C.c_void_p)]
+
+
+class LookTask(C.Structure):
+    """x264hip_look_task"""
+    _fields_ = [("chain", C.c_int), ("slot_b", C.c_int), ("slot_p0", C.c_int), ("slot_p1", C.c_int), ("d0", C.c_int), ("d1", C.c_int),
+                ("do_search", C.c_int * 2)]
+
+
+class LookParams(C.Structure):
+    """x264hip_look_params"""
+    _fields_ = [("me_method", C.c_int), ("me_range", C.c_int), ("weighted_bipred", C.c_int), ("bframes", C.c_int), ("bframe_bias", C.c_int),
+                ("subme_param", C.c_int), ("lossless", C.c_int), ("cost_mv", C.c_void_p), ("cost_mv_range", C.c_int)]
+
+
+COST_SPAN = 2 * 4 * 2048      # p_cost_mv reaches +-2*4*2048 quarter-pels (R/encoder/analyse.c:191-198)
+
+
+class LookaheadDevice:
+    """The lookahead's per-frame data of every chain of a FrameCtx (batch = chains): a ring of slots, input frame f in slot f % n_slots --
+    the picture (source planes + the four half-resolution planes), its intra costs, and fenc->lowres_mvs / lowres_mv_costs for both lists
+    and every distance.  Chains take pictures in lock step (one per encoder call), so one ring serves them all; how long a frame stays
+    alive differs per chain and is bounded by n_slots (x264hip_lookahead_oldest_live)."""
+
+    def __init__(self, ctx, n_slots, bframes, me_method=1, me_range=16, weightb=0, bframe_bias=0, subme=5, lossless=0, max_tasks=None):
+        from .frame import DeviceArray, Picture
+        import numpy as np
+        self.np, self.ctx, self.lib, self.n_slots, self.bframes = np, ctx, ctx.lib, n_slots, bframes
+        lib = self.lib
+        d = ctx.dims
+        self.n = d.mb_w * d.mb_h
+        self.nd = bframes + 1
+        self.pics, self.intra, self.mv, self.mv_cost = [], [], [], []
+        self.frame_of_slot = [-1] * n_slots
+        for _ in range(n_slots):
+            pic = Picture()
+            ctx.check(lib.x264hip_picture_alloc_lookahead(ctx.h, C.byref(pic)), "picture_alloc_lookahead")
+            ctx.pictures.append(pic)
+            self.pics.append(pic)
+            self.intra.append(DeviceArray(lib, (ctx.batch, self.n), np.int32))
+            self.mv.append(DeviceArray(lib, (ctx.batch, 2, self.nd, self.n, 2), np.int16))
+            self.mv_cost.append(DeviceArray(lib, (ctx.batch, 2, self.nd, self.n), np.int32))
+            # x264hip_malloc zero-fills: edge macroblocks are never searched and read as zero vectors (frame.c:93: memset at allocation)
+        self.slots = (LookSlot * n_slots)()
+        for i in range(n_slots):
+            self.slots[i] = LookSlot(C.addressof(self.pics[i]), self.intra[i].ptr, self.mv[i].ptr, self.mv_cost[i].ptr)
+        tab = np.zeros(2 * COST_SPAN + 1, np.int16)
+        lib.x264hip_cost_mv_table(C.c_int(1), C.c_int(COST_SPAN), tab.ctypes.data_as(C.c_void_p))      # a->i_lambda = x264_lambda_tab[12] = 1
+        self.cost_mv = DeviceArray(lib, tab.shape, np.int16, tab)
+        self.params = LookParams(me_method, me_range, weightb, bframes, bframe_bias, subme, lossless, self.cost_mv.ptr, COST_SPAN)
+        self.max_tasks = max_tasks or 8 * ctx.batch
+        lib.x264hip_lookahead_task_bytes.restype = C.c_size_t
+        tb = lib.x264hip_lookahead_task_bytes()
+        lib.x264hip_host_alloc.restype = C.c_void_p
+        self.staging = lib.x264hip_host_alloc(C.c_size_t(tb * self.max_tasks))
+        self.tasks_dev = DeviceArray(lib, (tb * self.max_tasks,), np.uint8)
+        self.out_dev = DeviceArray(lib, (self.max_tasks, 4), np.int32)
+        self.out_host = lib.x264hip_host_alloc(C.c_size_t(16 * self.max_tasks))
+        if not self.staging or not self.out_host:
+            raise MemoryError("x264hip_host_alloc")
+        self.n_launches = self.n_tasks_run = 0
+
+    def slot(self, frame):
+        return frame % self.n_slots
+
+    def picture(self, frame):
+        s = self.slot(frame)
+        assert self.frame_of_slot[s] == frame, "input frame %d is no longer in its lookahead slot" % frame
+        return self.pics[s]
+
+    def begin_frame(self, frame):
+        """Claim the slot of input frame `frame`; the caller fills the returned picture's Y, U, V (upload / synth) and calls prepare()."""
+        s = self.slot(frame)
+        self.frame_of_slot[s] = frame
+        return self.pics[s]
+
+    def prepare(self, frame):
+        """x264_frame_init_lowres + the intra half of the cost for every chain's copy of `frame` (encoder.c:1415-1418, slicetype.c:186-245)."""
+        s, ctx, lib = self.slot(frame), self.ctx, self.lib
+        ctx.check(lib.x264hip_lowres_init_frame(ctx.h, C.byref(self.pics[s])), "lowres_init_frame")
+        ctx.check(lib.x264hip_lookahead_intra_frame(ctx.h, C.byref(self.pics[s]), self.intra[s].p), "lookahead_intra_frame")
+
+    def run(self, tasks):
+        """tasks: [(chain, b, p0, p1, do_search0, do_search1)] with input frame numbers.  Returns int32 [n][3]: score, intra_mbs, cost00."""
+        np, ctx, lib = self.np, self.ctx, self.lib
+        out = np.zeros((len(tasks), 3), np.int32)
+        for base in range(0, len(tasks), self.max_tasks):
+            part = tasks[base:base + self.max_tasks]
+            arr = (LookTask * len(part))()
+            for i, (chain, b, p0, p1, ds0, ds1) in enumerate(part):
+                for f in (b, p0, p1):
+                    assert self.frame_of_slot[self.slot(f)] == f, "input frame %d is no longer in its lookahead slot" % f
+                arr[i] = LookTask(chain, self.slot(b), self.slot(p0), self.slot(p1), b - p0, p1 - b, (C.c_int * 2)(ds0, ds1))
+            ctx.check(lib.x264hip_lookahead_cost_frames(ctx.h, self.slots, self.n_slots, arr, len(part), C.byref(self.params), C.c_void_p(self.staging),
+                                                        self.tasks_dev.p, self.out_dev.p), "lookahead_cost_frames")
+            ctx.check(lib.x264hip_memcpy_d2h_async(C.c_void_p(self.out_host), self.out_dev.p, C.c_size_t(16 * len(part)), C.c_void_p(ctx.stream)), "memcpy_d2h_async")
+            ctx.sync()
+            res = np.ctypeslib.as_array(C.cast(self.out_host, C.POINTER(C.c_int32)), (len(part), 4))
+            out[base:base + len(part)] = res[:, :3]
+            self.n_launches += 1
+            self.n_tasks_run += len(part)
+        return out
+
+    def mv_ptr(self, chain, frame, lst, dist):
+        """Device address of frames[frame]->lowres_mvs[lst][dist - 1] of one chain ([n_mb][2] int16)."""
+        s = self.slot(frame)
+        return self.mv[s].ptr + 4 * self.n * ((chain * 2 + lst) * self.nd + dist - 1)
+
+    def mv_host(self, chain, frame, lst, dist):
+        a = self.mv[self.slot(frame)].get()
+        return a[chain, lst, dist - 1]
+
+    def close(self):
+        for a in self.intra + self.mv + self.mv_cost + [self.cost_mv, self.tasks_dev, self.out_dev]:
+            a.free()
+        for p in (self.staging, self.out_host):
+            if p:
+                self.lib.x264hip_host_free(C.c_void_p(p))
+        self.staging = self.out_host = None
+
+
+class LookaheadBatch:
+    """The encoder's frame queue for every chain of a FrameCtx: one host state machine per chain, their cost requests computed together.
+
+        lb.put(fill)          # one picture per chain enters; fill(picture, frame) writes its Y, U, V for every chain
+        frames = lb.get(flushing)   # per chain: x264hip_look_frame (what to code now) or None (buffer filling / flushed)
+        ...encode...
+        lb.end(chains)        # those chains' frames are done
+    """
+
+    def __init__(self, ctx, params, device, speculative=True):
+        self.ctx, self.dev, self.speculative = ctx, device, speculative
+        self.chains = [Lookahead(ctx.lib, params) for _ in range(ctx.batch)]
+        self.pending = [None] * ctx.batch
+        self.rounds = 0
+
+    def put(self, fill):
+        frame = None
+        for la in self.chains:
+            f = la.put()
+            assert frame is None or f == frame
+            frame = f
+        fill(self.dev.begin_frame(frame), frame)
+        self.dev.prepare(frame)
+        return frame
+
+    def get(self, flushing=False):
+        n = len(self.chains)
+        out, waiting = [None] * n, list(range(n))
+        while waiting:
+            tasks, owners, still = [], [], []
+            for ci in waiting:
+                kind, fr, needs = self.chains[ci].get(flushing, self.speculative)
+                if kind == NEED:
+                    for (b, p0, p1, ds0, ds1, spec) in needs:
+                        tasks.append((ci, b, p0, p1, ds0, ds1))
+                        owners.append(spec)
+                    still.append(ci)
+                elif kind == FRAME:
+                    out[ci] = fr
+                    self.pending[ci] = fr
+            if tasks:
+                res = self.dev.run(tasks)
+                self.rounds += 1
+                for (ci, b, p0, p1, ds0, ds1), spec, r in zip(tasks, owners, res):
+                    self.chains[ci].set_cost(b, p0, p1, int(r[0]), int(r[1]), int(r[2]), spec)
+            waiting = still
+        return out
+
+    def end(self, chains=None):
+        for ci in (range(len(self.chains)) if chains is None else chains):
+            if self.pending[ci] is not None:
+                self.chains[ci].end()
+                self.pending[ci] = None
+
+    def oldest_live(self):
+        return min(la.oldest_live() for la in self.chains)
+
+    def close(self):
+        for la in self.chains:
+            la.close()

@@ -12,6 +12,37 @@ extern "C" {
  * x264_frame_new with b_have_lowres, R/common/frame.c:80-96).  Freed with x264hip_picture_free. */
 int x264hip_picture_alloc_lookahead(x264hip_frame_ctx *c, x264hip_picture *pic);
 
+
+/* The macroblock sweep for chains that no longer move in lock step.  x264hip_slice_sweep_frame codes the same kind of frame in every
+ * batch element; once x264_slicetype_decide places B frames per chain and the rate control prices every frame on its own, chain A
+ * codes a P frame from references {9, 8} at QP 24 while chain B codes a B frame between 8 and 12 at QP 27.  Here every entry is ONE
+ * chain's sweep, described exactly like a call of x264hip_slice_sweep_frame -- its own source picture, references, reconstruction,
+ * states and slice parameters (QP, POCs, lowres vectors, list 1) -- and the chain (batch element) it applies to: the pictures and states
+ * are the batch-wide ones, the entry touches element `chain` of each.  One launch per kernel kind (I / P, I / P with the subme 8-9
+ * refinement, B), each block taking its arguments from its entry (csrc/slice_kernel.h, template argument CH).  The raster variant with
+ * the entropy coder in the loop only (params->rd with write = 1).  Every entry's `out` state gets the frame-level scalars later frames
+ * read (poc, ref_poc ...): give each chain its own COPY of the x264hip_mb_state structure (same device arrays, its own scalars).  The
+ * abort flag of every distinct state written must be cleared before the call (x264hip_mb_state_clear_progress).  staging_host (pinned)
+ * and table_dev: n * x264hip_chain_sweep_bytes() each, left alone until the stream has passed the call. */
+typedef struct {
+    int chain;
+    const x264hip_picture *fenc;
+    const x264hip_picture *const *refs;
+    int n_refs;
+    x264hip_picture *recon;
+    const x264hip_slice_params *params;
+    const x264hip_mb_state *l0;
+    x264hip_mb_state *out;
+} x264hip_chain_sweep;
+int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *entries, int n, void *staging_host, void *table_dev);
+size_t x264hip_chain_sweep_bytes(void);
+int x264hip_mb_state_clear_progress(x264hip_frame_ctx *c, x264hip_mb_state *st);
+/* The batch elements the end-of-frame calls of this context touch from now on -- x264hip_deblock_frame, x264hip_expand_border,
+ * x264hip_hpel_filter_frame: a device list of n element indices, or NULL = all.  With chains out of lock step a pool picture holds,
+ * per element, either the frame that chain has just coded into it (to be filtered and kept as a reference) or an older reference of
+ * another chain that must stay as it is. */
+int x264hip_frame_ctx_elements(x264hip_frame_ctx *c, const int *elems_dev, int n);
+
 #ifdef __cplusplus
 }
 #endif

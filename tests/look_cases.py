@@ -43,11 +43,11 @@ def config(seed):
 def reference_records(c):
     """What the reference's encoder does with the clip: per coded frame (input number, type, QP, lowres vectors l0 / l1 or None, i_satd),
     and the whole harness output (payloads ...) for the tests that go on to encode."""
-    p = rs.make_params(c["w"], c["h"], c["frames"], qp=c["qp"], me_method=c["me"], subme=c["subme"], n_refs=2, inter=0x33, intra=0x3,
-                       transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"])
+    p = rs.make_params(c["w"], c["h"], c["frames"], qp=c["qp"], me_method=c["me"], subme=c["subme"], n_refs=c.get("n_refs", 2), inter=c.get("inter", 0x33),
+                       intra=0x3, transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"], mixed_refs=c.get("mixed_refs", 0), chroma_me=c.get("chroma_me", 1))
     e = rs.make_ext(bframes=c["bframes"], b_adapt=c["b_adapt"], pre_scenecut=c["pre_scenecut"], scenecut_threshold=c["scenecut_threshold"],
                     keyint_min=c["keyint_min"], crf=-1.0 if c["crf"] is None else c["crf"], bframe_bias=c["bframe_bias"], weightb=c["weightb"],
-                    aq_mode=c["aq"], aq_strength=1.0)
+                    aq_mode=c["aq"], aq_strength=1.0, trellis=c.get("trellis", 0), psy_rd=c.get("psy_rd", 0.0), direct_pred=c.get("direct_pred", 1))
     y, u, v = clip(c["w"], c["h"], c["frames"], c["cut"], c["t0"], c["slow"])
     a = rs.run_reference_stream(p, e, y, u, v)
     return a

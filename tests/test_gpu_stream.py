@@ -1,0 +1,105 @@
+"""End to end: a batch of chains through the StreamEncoder -- the lookahead's cost kernel, the library's slice-type decision and rate
+control, the chain-table sweep with every chain coding its own kind of frame at its own QP -- against the REFERENCE's encoder run on the
+same clips (oracle/ref_slice.c refslice_encode_stream: x264_encoder_encode's queue around x264_slicetype_decide, x264_ratecontrol_start
+and the slice loop).  Compared: the order frames are coded in, their types, QPs and the slice_data() bytes of every one.
+
+  * golden: tests/golden/stream_*.npz made by oracle/gen_golden_stream.py from the reference;
+  * live: the same configurations with other clips where oracle/_ref/libx264ref.so is built."""
+import os
+
+import numpy as np
+import pytest
+
+import look_cases as K
+from oracle import refslice as rs
+from x264_vs2008_amd import lookahead as LA
+from x264_vs2008_amd.frame import cqm_init
+from x264_vs2008_amd.stream import StreamEncoder
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
+
+
+def encoder_for(hip_lib, c, batch):
+    return StreamEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), batch=batch, crf=c["crf"], b_adapt=c["b_adapt"], bframe_bias=c["bframe_bias"],
+                         keyint_min=c["keyint_min"], scenecut_threshold=c["scenecut_threshold"], pre_scenecut=c["pre_scenecut"],
+                         qp=c["qp"], me_method=c["me"], me_range=16, subme=c["subme"], n_refs=c.get("n_refs", 2), inter=c.get("inter", 0x33), intra=0x3,
+                         transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"], mixed_refs=c.get("mixed_refs", 0), chroma_me=c.get("chroma_me", 1),
+                         trellis=c.get("trellis", 0), psy_rd=c.get("psy_rd", 0.0), aq_mode=c["aq"], aq_strength=1.0, bframes=c["bframes"],
+                         weightb=c["weightb"], direct_pred=c.get("direct_pred", 1), qp_min=0)
+
+
+def run_stream(hip_lib, cs):
+    """cs: the chains' configurations (one encoder configuration, different clips).  Returns per chain [(frame, slice type, qp, payload)]."""
+    c0, frames = cs[0], cs[0]["frames"]
+    clips = [K.clip(c["w"], c["h"], frames, c["cut"], c["t0"], c["slow"]) for c in cs]
+    enc = encoder_for(hip_lib, c0, len(cs))
+    got = [[] for _ in cs]
+
+    def fill(pic, f):
+        for b, (y, u, v) in enumerate(clips):
+            enc.ctx.upload(pic, y[f], u[f], v[f], b=b)
+
+    fed = 0
+    for _ in range(4 * frames + 8):
+        coded = enc.step(fill if fed < frames else None)
+        fed += fed < frames
+        if not coded and fed >= frames and enc.flushing:
+            break
+        if coded:
+            enc.sync()
+            enc.status()
+            pl = enc.payloads()
+            for cd in coded:
+                got[cd.chain].append((cd.frame, cd.slice_type, cd.qp, pl[cd.chain]))
+    enc.close()
+    return got
+
+
+def check(got, a, c, what):
+    frames = c["frames"]
+    assert len(got) == frames, "%s: %d frames coded, the reference codes %d" % (what, len(got), frames)
+    for f, (frame, st, qp, payload) in enumerate(got):
+        ref = (int(a["frame_info2"][f][0]), int(a["frame_info"][f][0]), int(a["frame_info"][f][1]))
+        assert (frame, st, qp) == ref, "%s coded frame %d: (input, slice, qp) %s, the reference %s" % (what, f, (frame, st, qp), ref)
+        want = bytes(a["payload"][f, :a["payload_len"][f]])
+        assert payload == want, "%s coded frame %d (input %d, slice %d, qp %d): payload differs (%d vs %d bytes)" % (what, f, frame, st, qp, len(payload), len(want))
+
+
+CONFIGS = {
+    "badapt1_crf_aq": dict(w=128, h=96, frames=14, bframes=3, b_adapt=1, crf=23.0, subme=5, me=1, weightb=1, aq=1, n_refs=2),
+    "badapt2_crf_rd": dict(w=112, h=96, frames=13, bframes=2, b_adapt=2, crf=28.0, subme=7, me=2, weightb=0, aq=0, n_refs=3, mixed_refs=1, trellis=1, inter=0x13),
+    "scenecut_cqp": dict(w=96, h=80, frames=12, bframes=0, b_adapt=0, crf=None, subme=6, me=1, weightb=0, aq=1, keyint=8, inter=0x13),
+    "temporal_crf": dict(w=128, h=80, frames=12, bframes=1, b_adapt=1, crf=20.0, subme=4, me=0, weightb=1, aq=0, direct_pred=2),
+}
+SEEDS = {"badapt1_crf_aq": [0, 3, 9], "badapt2_crf_rd": [4, 7], "scenecut_cqp": [5, 11, 12], "temporal_crf": [1, 6]}
+
+
+def chains(name, seeds):
+    cs = []
+    for s in seeds:
+        c = K.config(s)
+        c.update(pre_scenecut=1, scenecut_threshold=40, keyint=250, keyint_min=0, bframe_bias=0, qp=26)
+        c.update(CONFIGS[name])
+        cs.append(c)
+    return cs
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_stream_equals_reference_fixture(hip_lib, name):
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "stream_%s.npz" % name))
+    cs = chains(name, SEEDS[name])
+    got = run_stream(hip_lib, cs)
+    for i, c in enumerate(cs):
+        a = {k: gold["c%d_%s" % (i, k)] for k in ("frame_info", "frame_info2", "payload", "payload_len")}
+        check(got[i], a, c, "%s chain %d" % (name, i))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_stream_equals_reference_live(hip_lib, name):
+    cs = chains(name, [s + 40 for s in SEEDS[name]])
+    got = run_stream(hip_lib, cs)
+    for i, c in enumerate(cs):
+        check(got[i], K.reference_records(c), c, "%s chain %d" % (name, i))

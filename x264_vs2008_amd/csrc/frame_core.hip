@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void k_synth_plane(u8 *pix, size_t bs, int str
 // every padding byte takes the nearest interior pixel (left/right bands first,
 // then whole rows copied up/down, which is the same thing).
 // Grid: y over [-padv, height+padv), x in dwords over [-padh, width+padh).
-__global__ void k_expand_border(u8 *pix, size_t bs, int stride, int width, int height, int padh, int padv)
+__global__ void k_expand_border(u8 *pix, size_t bs, int stride, int width, int height, int padh, int padv, const int *elems)
 {
-    pix += bs * blockIdx.z;
+    pix += bs * (elems ? elems[blockIdx.z] : blockIdx.z);
     int xq = blockIdx.x * blockDim.x + threadIdx.x;      // dword index from -padh
     int y = (int)blockIdx.y - padv;
     int x = xq * 4 - padh;
@@ -98,9 +98,9 @@ __global__ void k_expand_border(u8 *pix, size_t bs, int stride, int width, int h
 #define HP_TW 64
 #define HP_TH 16
 __global__ __launch_bounds__(256) void k_hpel(const u8 *__restrict__ src, u8 *__restrict__ dh, u8 *__restrict__ dv,
-                                              u8 *__restrict__ dc, size_t bs, int stride, int x_lo, int y_lo, int nx, int ny)
+                                              u8 *__restrict__ dc, size_t bs, int stride, int x_lo, int y_lo, int nx, int ny, const int *elems)
 {
-    src += bs * blockIdx.z; dh += bs * blockIdx.z; dv += bs * blockIdx.z; dc += bs * blockIdx.z;
+    { const size_t be = elems ? elems[blockIdx.z] : blockIdx.z; src += bs * be; dh += bs * be; dv += bs * be; dc += bs * be; }
     __shared__ u32 s_src[21 * 18];          // 21 rows x 72 bytes, column 0 = x0 - 4
     __shared__ i16 s_v[HP_TH * 72];         // raw vertical 6-tap, column 0 = x0 - 4
     const int tid = threadIdx.x;
@@ -305,6 +305,12 @@ extern "C" void x264hip_frame_ctx_delete(x264hip_frame_ctx *c)
 }
 extern "C" void *x264hip_frame_ctx_stream(x264hip_frame_ctx *c) { return (void *)c->stream; }
 extern "C" int x264hip_sync(x264hip_frame_ctx *c) { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int x264hip_frame_ctx_elements(x264hip_frame_ctx *c, const int *elems_dev, int n)
+{
+    if (elems_dev && (n <= 0 || n > c->batch)) { set_error("frame_ctx_elements: %d elements of a batch of %d", n, c->batch); return -1; }
+    c->elems = elems_dev; c->n_elems = elems_dev ? n : 0;
+    return 0;
+}
 extern "C" int x264hip_frame_ctx_select(x264hip_frame_ctx *c, int batch_index)
 {
     if (batch_index < 0 || batch_index >= c->batch) { set_error("batch index %d out of range", batch_index); return -1; }
@@ -453,7 +459,7 @@ extern "C" int x264hip_picture_download(x264hip_frame_ctx *c, const x264hip_pict
 static void launch_expand(const x264hip_frame_ctx *c, u8 *pix, size_t bs, int stride, int width, int height, int padh, int padv)
 {
     int nq = (width + 2 * padh + 3) / 4;
-    hipLaunchKernelGGL(k_expand_border, dim3((nq + 255) / 256, height + 2 * padv, c->batch), dim3(256), 0, c->stream, pix, bs, stride, width, height, padh, padv);
+    hipLaunchKernelGGL(k_expand_border, dim3((nq + 255) / 256, height + 2 * padv, c->elems ? c->n_elems : c->batch), dim3(256), 0, c->stream, pix, bs, stride, width, height, padh, padv, c->elems);
 }
 
 extern "C" int x264hip_expand_border(x264hip_frame_ctx *c, x264hip_picture *pic, int which)
@@ -478,9 +484,9 @@ extern "C" int x264hip_hpel_filter_frame(x264hip_frame_ctx *c, x264hip_picture *
     const x264hip_frame_dims &d = c->d;
     // region kept by the reference after border expansion: x in [-4, w+4), y in [-8, h+8)
     int nx = c->width16 + 8, ny = c->lines16 + 16;
-    dim3 grid((nx + HP_TW - 1) / HP_TW, (ny + HP_TH - 1) / HP_TH, c->batch);
+    dim3 grid((nx + HP_TW - 1) / HP_TW, (ny + HP_TH - 1) / HP_TH, c->elems ? c->n_elems : c->batch);
     hipLaunchKernelGGL(k_hpel, grid, dim3(256), 0, c->stream, pic->plane[0], pic->filtered[1], pic->filtered[2], pic->filtered[3],
-                       c->bs_y, d.stride_y, -4, -8, nx, ny);
+                       c->bs_y, d.stride_y, -4, -8, nx, ny, c->elems);
     HIPCHK(hipGetLastError());
     return x264hip_expand_border(c, pic, 1);
 }

@@ -105,14 +105,14 @@ struct DbLds {
 __global__ __launch_bounds__(64 * DB_WAVES) void k_deblock_diag(u8 *__restrict__ py, u8 *__restrict__ pu, u8 *__restrict__ pv, DbGeom g,
                                                                 const u8 *__restrict__ mb_type, const u8 *__restrict__ qp,
                                                                 const u8 *__restrict__ nnz, const u8 *__restrict__ t8x8,
-                                                                const i16 *__restrict__ mv, const signed char *__restrict__ ref)
+                                                                const i16 *__restrict__ mv, const signed char *__restrict__ ref, const int *__restrict__ elems)
 {
     __shared__ DbLds s_all[DB_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * DB_WAVES + wave;
     if (k >= g.count) return;
     {   // batch element
-        const size_t bz = blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
+        const size_t bz = elems ? elems[blockIdx.y] : blockIdx.y, nmb = (size_t)g.mb_w * g.mb_h;
         py += g.bs_y * bz; pu += g.bs_c * bz; pv += g.bs_c * bz;
         mb_type += nmb * bz; qp += nmb * bz; nnz += (size_t)(g.layout ? 27 : 26) * nmb * bz; t8x8 += nmb * bz; mv += 32 * nmb * bz; ref += 4 * nmb * bz;
     }
@@ -246,9 +246,9 @@ extern "C" int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *reco
         int y_max = t / 2 < g.mb_h - 1 ? t / 2 : g.mb_h - 1;
         if (y_max < y_min) continue;
         g.diag = t; g.y_min = y_min; g.count = y_max - y_min + 1;
-        hipLaunchKernelGGL(k_deblock_diag, dim3((g.count + DB_WAVES - 1) / DB_WAVES, c->batch), dim3(64 * DB_WAVES), 0, c->stream,
+        hipLaunchKernelGGL(k_deblock_diag, dim3((g.count + DB_WAVES - 1) / DB_WAVES, c->elems ? c->n_elems : c->batch), dim3(64 * DB_WAVES), 0, c->stream,
                            recon->plane[0], recon->plane[1], recon->plane[2], g, p->mb_type, p->qp, p->nnz, p->transform8x8,
-                           p->mv, (const signed char *)p->ref);
+                           p->mv, (const signed char *)p->ref, c->elems);
     }
     HIPCHK(hipGetLastError());
     return 0;

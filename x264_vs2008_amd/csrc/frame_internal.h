@@ -19,6 +19,9 @@ struct x264hip_frame_ctx {
     size_t bs_y, bs_c, bs_l;       // bytes between batch elements: luma-sized, chroma-sized, lowres planes
     int stride_l, width_l, lines_l;
     unsigned long long *ssd_dev;   // [batch][3] accumulators for x264hip_ssd_frame
+    // x264hip_frame_ctx_elements: the batch elements the end-of-frame calls (deblock, border expansion, half-pel filter) touch;
+    // NULL = all.  Chains that code different kinds of frames keep some of a picture's elements as they are (device list).
+    const int *elems; int n_elems;
 };
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }

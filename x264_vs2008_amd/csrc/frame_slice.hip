@@ -1,12 +1,17 @@
 // frame_slice.hip -- host side of the macroblock sweep (x264hip_slice_sweep_frame ...) and the wavefront-schedule kernel variants.
 // The kernel itself lives in slice_kernel.h; its raster-order variant is instantiated in frame_slice_rd.hip (a translation unit of
 // its own so that the two compile side by side).
+#include <vector>
 #include "slice_kernel.h"
+#include "x264hip_lookahead.h"
 
 void x264hip_launch_slice_rd(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_b(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_bt(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
 void x264hip_launch_slice_rf(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream);
+void x264hip_launch_slice_rd_ch(const SwDesc *tab, int n, hipStream_t stream);
+void x264hip_launch_slice_bt_ch(const SwDesc *tab, int n, hipStream_t stream);
+void x264hip_launch_slice_rf_ch(const SwDesc *tab, int n, hipStream_t stream);
 
 // b_fast_intra's raster-order term, settled once the frame is complete: macroblocks whose analysis went on without
 // knowing it (it could not change their type) recorded the statistics term for the other answer in cost_alt.
@@ -120,9 +125,12 @@ extern "C" int x264hip_noise_reduction_update(x264hip_frame_ctx *c, const x264hi
     return 0;
 }
 
-extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs, int n_refs,
-                                         x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
-                                         x264hip_mb_state *out)
+// The three argument structures of one sweep launch from the ABI's description of it, and which kernel codes it
+enum { SW_KIND_PLAIN = 0, SW_KIND_RD, SW_KIND_RF, SW_KIND_B, SW_KIND_BT };
+static void sweep_note_frame(const x264hip_slice_params *p, int n_refs, x264hip_mb_state *out);
+static int sweep_build(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs, int n_refs,
+                       x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
+                       x264hip_mb_state *out, SwArgs &a, SwRefs &t, SwRd &r, int &kind)
 {
     const bool is_b = p->slice_type == 1, is_p = p->slice_type == 0 || is_b;     // is_p: "has list 0" in what follows
     if (p->slice_type != 0 && p->slice_type != 1 && p->slice_type != 2) { set_error("slice_sweep: slice type %d (0 P, 1 B, 2 I)", p->slice_type); return -1; }
@@ -161,9 +169,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     if (p->transform8x8 && (!p->quant8_mf || !p->quant8_bias || !p->dequant8_mf)) { set_error("slice_sweep: 8x8 quantiser tables missing"); return -1; }
     if (is_p && !p->cost_mv) { set_error("slice_sweep: cost_mv missing"); return -1; }
     if (c->d.mb_w > 0xffff) { set_error("slice_sweep: frame too wide"); return -1; }
-    SwArgs a;
-    SwRefs t;
-    memset(&a, 0, sizeof(a));
+    memset(&a, 0, sizeof(a)); memset(&t, 0, sizeof(t));
     a.mb_w = c->d.mb_w; a.mb_h = c->d.mb_h; a.sy = c->d.stride_y; a.sc = c->d.stride_c; a.batch = c->batch; a.batch_pad = (c->batch + 7) & ~7;
     a.bs_y = c->bs_y; a.bs_c = c->bs_c;
     a.slice_type = p->slice_type; a.qp = p->qp;
@@ -244,15 +250,8 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
         t.u1 = t.u[0]; t.v1 = t.v[0];
         for (int i = 0; i < SW_MAX_REFS; i++) { t.biw[i] = 32; t.dsf[i] = 256; t.map_col[i] = -2; }
     }
-    HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
-    static int wpe = 0;
-    if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..3
-        const char *e = getenv("X264HIP_SWEEP_WPE");
-        wpe = e ? atoi(e) : 3;                                       // 3 waves/SIMD (168 VGPRs, 12 waves per CU with 13 KB of LDS each): measured best
-        if (wpe < 1 || wpe > 3) wpe = 3;
-    }
-    SwRd r;
     memset(&r, 0, sizeof(r));
+    kind = SW_KIND_PLAIN;
     if (prd) {
         r.on = 1; r.mbrd = mbrd; r.trellis = p->cabac ? prd->trellis : 0; r.psy_rd = mbrd ? prd->psy_rd : 0;
         r.write = prd->write; r.cabac_init_idc = prd->cabac_init_idc; r.i_frame = prd->i_frame; r.i_frame_stride = prd->i_frame_stride;
@@ -267,31 +266,102 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
             r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
             // the extended B kernel (temporal direct prediction, the lookahead's candidates) only where it is needed: the plain one is 6-8 % faster
-            if (r.direct_temporal || a.lowres0 || a.lowres1) x264hip_launch_slice_bt(a, t, r, c->stream); else x264hip_launch_slice_b(a, t, r, c->stream);
-        } else if (mbrd >= 2)
-            x264hip_launch_slice_rf(a, t, r, c->stream);          // subme 8-9: the I / P kernel with the RD refinement (slice_refine.h)
-        else
-        x264hip_launch_slice_rd(a, t, r, c->stream);
-    } else {
-    const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
-    switch (a.lossless ? 0 : wpe) {
-    case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t, r); break;
-    case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t, r); break;
-    case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t, r); break;
-    default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t, r); break;
+            kind = r.direct_temporal || a.lowres0 || a.lowres1 ? SW_KIND_BT : SW_KIND_B;
+        } else
+            kind = mbrd >= 2 ? SW_KIND_RF : SW_KIND_RD;     // subme 8-9: the I / P kernel with the RD refinement (slice_refine.h)
     }
-    }
-    if (!prd && is_p && a.flags_intra)
-        hipLaunchKernelGGL(k_resolve_fast_intra, dim3(c->batch), dim3(64), 0, c->stream, (const signed char *)out->mb_type, out->cost_intra,
-                           (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
-    HIPCHK(hipGetLastError());
-    // the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
+    return 0;
+}
+
+// the frame-level scalars later frames read from this one (x264_macroblock_slice_init, R/common/macroblock.c:771-808)
+static void sweep_note_frame(const x264hip_slice_params *p, int n_refs, x264hip_mb_state *out)
+{
+    const bool is_p = p->slice_type == 0 || p->slice_type == 1;
     out->poc = p->poc; out->n_ref0 = is_p ? n_refs : 0;
     for (int i = 0; i < 8; i++) out->ref_poc[i] = i < n_refs ? p->ref_poc[i] : 0;     /* (a B frame's state is never read by later frames) */
     for (int i = 0; i < SW_MAX_REFS; i++) {
         int delta = i < n_refs && is_p ? p->poc - p->ref_poc[i] : 0;
         out->inv_ref_poc[i] = delta ? (256 + delta / 2) / delta : 0;
     }
+}
+
+extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_picture *fenc, const x264hip_picture *const *refs, int n_refs,
+                                         x264hip_picture *recon, const x264hip_slice_params *p, const x264hip_mb_state *l0,
+                                         x264hip_mb_state *out)
+{
+    SwArgs a; SwRefs t; SwRd r;
+    int kind;
+    if (sweep_build(c, fenc, refs, n_refs, recon, p, l0, out, a, t, r, kind)) return -1;
+    const bool is_p = p->slice_type == 0;
+    HIPCHK(hipMemsetAsync(out->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
+    static int wpe = 0;
+    if (!wpe) {                                                      // developer knob: X264HIP_SWEEP_WPE = 1..3
+        const char *e = getenv("X264HIP_SWEEP_WPE");
+        wpe = e ? atoi(e) : 3;                                       // 3 waves/SIMD (168 VGPRs, 12 waves per CU with 13 KB of LDS each): measured best
+        if (wpe < 1 || wpe > 3) wpe = 3;
+    }
+    switch (kind) {
+    case SW_KIND_BT: x264hip_launch_slice_bt(a, t, r, c->stream); break;
+    case SW_KIND_B: x264hip_launch_slice_b(a, t, r, c->stream); break;
+    case SW_KIND_RF: x264hip_launch_slice_rf(a, t, r, c->stream); break;
+    case SW_KIND_RD: x264hip_launch_slice_rd(a, t, r, c->stream); break;
+    default: {
+        const dim3 grid((unsigned)(a.batch_pad * a.mb_h)), block(64);
+        switch (a.lossless ? 0 : wpe) {
+        case 0: hipLaunchKernelGGL((k_slice_sweep<2, true>), grid, block, 0, c->stream, a, t, r, nullptr); break;
+        case 1: hipLaunchKernelGGL(k_slice_sweep<1>, grid, block, 0, c->stream, a, t, r, nullptr); break;
+        case 3: hipLaunchKernelGGL(k_slice_sweep<3>, grid, block, 0, c->stream, a, t, r, nullptr); break;
+        default: hipLaunchKernelGGL(k_slice_sweep<2>, grid, block, 0, c->stream, a, t, r, nullptr); break;
+        }
+    }
+    }
+    if (kind == SW_KIND_PLAIN && is_p && a.flags_intra)
+        hipLaunchKernelGGL(k_resolve_fast_intra, dim3(c->batch), dim3(64), 0, c->stream, (const signed char *)out->mb_type, out->cost_intra,
+                           (const int *)out->cost_intra_alt, c->d.mb_w * c->d.mb_h);
+    HIPCHK(hipGetLastError());
+    sweep_note_frame(p, n_refs, out);
+    return 0;
+}
+
+// The chain-table launch: every entry is a sweep of ONE chain (batch element) with its own pictures, states and slice parameters.
+extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev)
+{
+    if (n <= 0) return 0;
+    if (!staging_host || !table_dev) { set_error("slice_sweep_chains: staging / table buffers missing"); return -1; }
+    SwDesc *st = (SwDesc *)staging_host;
+    // entries sorted by kernel: [RD | RF | BT]; a first pass builds, a second places
+    int cnt[5] = {0, 0, 0, 0, 0};
+    static thread_local std::vector<SwDesc> tmp;
+    static thread_local std::vector<int> kinds;
+    tmp.resize((size_t)n); kinds.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        x264hip_chain_sweep &s = e[i];
+        if (s.chain < 0 || s.chain >= c->batch) { set_error("slice_sweep_chains: entry %d: chain %d", i, s.chain); return -1; }
+        if (!s.params || !s.params->rd || !s.params->rd->write) { set_error("slice_sweep_chains: entry %d: the chain table belongs to the raster variant with the entropy coder in the loop (params.rd, write = 1)", i); return -1; }
+        int kind;
+        if (sweep_build(c, s.fenc, s.refs, s.n_refs, s.recon, s.params, s.l0, s.out, tmp[i].a, tmp[i].t, tmp[i].r, kind)) return -1;
+        if (kind == SW_KIND_B) kind = SW_KIND_BT;                       // one B kernel in the table launches
+        tmp[i].a.chain = s.chain;
+        kinds[i] = kind; cnt[kind]++;
+        sweep_note_frame(s.params, s.n_refs, s.out);
+    }
+    int base[5], at[5];
+    base[SW_KIND_RD] = 0; base[SW_KIND_RF] = cnt[SW_KIND_RD]; base[SW_KIND_BT] = base[SW_KIND_RF] + cnt[SW_KIND_RF];
+    for (int k = 0; k < 5; k++) at[k] = base[k];
+    for (int i = 0; i < n; i++) st[at[kinds[i]]++] = tmp[i];
+    HIPCHK(hipMemcpyAsync(table_dev, st, sizeof(SwDesc) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    const SwDesc *tab = (const SwDesc *)table_dev;
+    if (cnt[SW_KIND_RD]) x264hip_launch_slice_rd_ch(tab + base[SW_KIND_RD], cnt[SW_KIND_RD], c->stream);
+    if (cnt[SW_KIND_RF]) x264hip_launch_slice_rf_ch(tab + base[SW_KIND_RF], cnt[SW_KIND_RF], c->stream);
+    if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], c->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" size_t x264hip_chain_sweep_bytes(void) { return sizeof(SwDesc); }
+// the abort flag of a state (what x264hip_slice_sweep_frame clears before each launch; a chain-table caller clears it once per state it writes)
+extern "C" int x264hip_mb_state_clear_progress(x264hip_frame_ctx *c, x264hip_mb_state *st)
+{
+    HIPCHK(hipMemsetAsync(st->progress, 0, sizeof(int) * ((size_t)c->d.mb_h * c->batch + 1), c->stream));
     return 0;
 }
 

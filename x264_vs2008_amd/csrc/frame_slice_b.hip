@@ -5,5 +5,5 @@
 
 void x264hip_launch_slice_b(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_slice_sweep<2, false, true, true>), dim3((unsigned)a.batch), dim3(64), 0, stream, a, t, r);
+    hipLaunchKernelGGL((k_slice_sweep<2, false, true, true>), dim3((unsigned)a.batch), dim3(64), 0, stream, a, t, r, nullptr);
 }

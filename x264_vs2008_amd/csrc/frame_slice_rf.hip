@@ -6,5 +6,5 @@
 
 void x264hip_launch_slice_rf(const SwArgs &a, const SwRefs &t, const SwRd &r, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_slice_sweep<2, false, true, false, false, true>), dim3((unsigned)a.batch), dim3(64), 0, stream, a, t, r);
+    hipLaunchKernelGGL((k_slice_sweep<2, false, true, false, false, true>), dim3((unsigned)a.batch), dim3(64), 0, stream, a, t, r, nullptr);
 }

@@ -70,6 +70,7 @@ struct SwRefs {
 };
 struct SwArgs {
     int mb_w, mb_h, sy, sc, batch, batch_pad;
+    int chain;                  // the chain-table launch (template argument CH): the batch element this table entry codes
     size_t bs_y, bs_c;
     int slice_type, qp, qpc, lambda, chroma_skip_thresh, n_refs;
     int l0_n_ref0;
@@ -1294,9 +1295,29 @@ static __device__ const u8 d_chroma_qp[52] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 
                                               29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
 
 // RF: the I / P kernel with the RD refinement of subme 8-9 (x264_me_refine_qpel_rd, x264_intra_rd_refine: slice_refine.h)
-template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false, bool RF = false>       // TD: the extended B kernel (temporal direct prediction, lookahead candidates)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs, SwRd rd)
+// CH: the chain-table launch.  Chains that no longer move in lock step (adaptive B placement, per-chain QPs) each code their own
+// frame type from their own pictures: block i takes ALL three argument structures from tab[i], built by the host exactly as for a
+// launch of its own (x264hip_slice_sweep_chains), and codes batch element tab[i].a.chain.  The table is read through the constant
+// address space, like the kernel-argument segment it replaces, so the same loads can be re-issued instead of kept in registers.
+struct SwDesc { SwArgs a; SwRefs t; SwRd r; };
+template <int WPE, bool LL = false, bool RD = false, bool BS = false, bool TD = false, bool RF = false, bool CH = false>       // TD: the extended B kernel (temporal direct prediction, lookahead candidates)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_slice_sweep(SwArgs a, SwRefs refs_k, SwRd rd_k, const SwDesc *tab)
 {
+    static_assert(!CH || RD, "the chain table belongs to the raster variant");
+    SwRd rd_l;
+    if constexpr (CH) {
+        typedef const __attribute__((address_space(4))) SwDesc *desc_p;
+        const desc_p d = (desc_p)(uintptr_t)tab + blockIdx.x;
+        typedef const __attribute__((address_space(4))) u32 *word_p;
+        static_assert(sizeof(SwArgs) % 4 == 0 && sizeof(SwRd) % 4 == 0 && alignof(SwDesc) >= 4, "copied by dwords");
+        const word_p wa = (word_p)&d->a, wr = (word_p)&d->r;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(SwArgs) / 4; i++) ((u32 *)&a)[i] = wa[i];
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(SwRd) / 4; i++) ((u32 *)&rd_l)[i] = wr[i];
+    }
+    const SwRd &rd = CH ? rd_l : rd_k;
+    const SwRefs &refs = CH ? tab[blockIdx.x].t : refs_k;
     static_assert(!BS || RD, "B slices run in the raster variant");
     static_assert(!TD || BS, "temporal direct prediction is a B-slice matter");
     static_assert(!RF || (RD && !BS), "the RD refinement is built for the raster variant's I / P kernel");
@@ -1311,7 +1332,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     SwLdsRf &sf = *(SwLdsRf *)((char *)&sr_ + sizeof(SwLdsRd));  // only touched when RF (then sr_ is an SwLdsRdF)
     (void)sf;
     const int lane_id = threadIdx.x, lane = lane_id;
-    const int bz = RD ? (int)blockIdx.x : (int)(blockIdx.x % a.batch_pad), mby0 = RD ? 0 : (int)(blockIdx.x / a.batch_pad);
+    const int bz = CH ? a.chain : RD ? (int)blockIdx.x : (int)(blockIdx.x % a.batch_pad), mby0 = RD ? 0 : (int)(blockIdx.x / a.batch_pad);
     if (bz >= a.batch) return;
     const size_t nmb = (size_t)a.mb_w * a.mb_h, cb = nmb * bz, by_ = a.bs_y * bz, bc_ = a.bs_c * bz;
     // batch element

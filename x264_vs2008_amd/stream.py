@@ -1,0 +1,216 @@
+"""x264_encoder_encode for a batch of GOP chains with the real lookahead and rate control in front of the macroblock sweep
+(R/encoder/encoder.c:1340-1600): x264_slicetype_decide places every chain's B frames (b-adapt 1 / 2, the pre-encode scene cut),
+x264_ratecontrol_start prices every frame (CQP or CRF), and the lookahead's half-resolution vectors are the first candidates of the
+16x16 searches -- so the chains stop moving in lock step: at one step chain A codes a P frame from references {9, 8} at QP 24 while
+chain B codes a B frame between 8 and 12 at QP 27.
+
+    enc = StreamEncoder(lib, w, h, cqm, batch=B, crf=23.0, bframes=3, b_adapt=1, ...)      # ChainEncoder's options + the lookahead's
+    frames = enc.step(fill)                # one picture per chain in (fill(picture, input number)), at most one coded frame per chain out
+    frames = enc.step(None)                # flushing: no more input; [] when every chain is done
+    enc.payloads()                         # slice_data() of the frames just coded, per chain (None where the chain coded nothing)
+
+Host side: x264_vs2008_amd.lookahead (the library's host C state machine per chain + the batched cost kernel).  Device side: one
+chain-table launch per kernel kind (x264hip_slice_sweep_chains), each chain's entry naming its own source picture (the lookahead's slot),
+references, reconstruction and QP; the end-of-frame filters run on the elements that coded a kept frame (x264hip_frame_ctx_elements).
+The arithmetic lives in the HIP library; this file orders launches and owns device buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import lookahead as LA
+from .frame import DeblockParams, DeviceArray
+from .slice import (COST_SPAN, ChainEncoder, MbState, SLICE_B, SLICE_I, SLICE_P, SliceB, SliceParams, SliceRd)
+
+
+class ChainSweep(C.Structure):
+    """x264hip_chain_sweep"""
+    _fields_ = [("chain", C.c_int), ("fenc", C.c_void_p), ("refs", C.c_void_p), ("n_refs", C.c_int), ("recon", C.c_void_p),
+                ("params", C.c_void_p), ("l0", C.c_void_p), ("out", C.c_void_p)]
+
+
+class Coded:
+    """What one chain coded in a step."""
+    __slots__ = ("chain", "frame", "type", "slice_type", "qp", "f_qpm", "poc", "n_ref0", "n_ref1", "i_satd")
+
+    def __repr__(self):
+        return "Coded(chain=%d frame=%d type=%d qp=%d poc=%d)" % (self.chain, self.frame, self.type, self.qp, self.poc)
+
+
+class StreamEncoder(ChainEncoder):
+    def __init__(self, lib, width, height, cqm, batch=1, crf=None, b_adapt=1, bframe_bias=0, keyint_min=0, scenecut_threshold=40, pre_scenecut=1,
+                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, **kw):
+        kw.setdefault("write", 1)
+        kw.setdefault("levels", False)
+        if kw.get("lanes"):
+            raise ValueError("StreamEncoder: the chains of a step already run side by side; lanes belong to the lock-step encoder")
+        super().__init__(lib, width, height, cqm, batch=batch, **kw)
+        if not self.raster or not self.rd_opt["write"]:
+            raise ValueError("StreamEncoder: the chain-table sweep is the raster variant with the entropy coder in the loop")
+        o, d = self.opt, self.ctx.dims
+        keyint = o["keyint"] if o["keyint"] > 0 else 1 << 30
+        self.la_params = LA.make_params(d.mb_w, d.mb_h, bframes=self.bopt["bframes"], b_adapt=b_adapt if self.bopt["bframes"] else 0, bframe_bias=bframe_bias,
+                                        keyint_max=keyint, keyint_min=keyint_min, scenecut_threshold=scenecut_threshold, pre_scenecut=pre_scenecut,
+                                        crf=crf, qp=o["qp"], ip_factor=ip_factor, pb_factor=pb_factor, qcompress=qcompress,
+                                        qp_min=self.rd_opt["qp_min"], qp_max=self.rd_opt["qp_max"], qp_step=qp_step)
+        bf = self.bopt["bframes"]
+        delay = (max(bf, 3) * 4 if b_adapt == 2 and bf else bf)
+        self.n_slots = n_slots or (delay + 2 * bf + 4)
+        self.look = LA.LookaheadDevice(self.ctx, self.n_slots, bf, me_method=o["me_method"], me_range=o["me_range"], weightb=self.bopt["weightb"],
+                                       bframe_bias=bframe_bias, subme=o["subme"], lossless=self.lossless)
+        self.lb = LA.LookaheadBatch(self.ctx, self.la_params, self.look, speculative=speculative)
+        B, n = batch, d.mb_w * d.mb_h
+        # fenc->f_qp_offset of every slot (x264_adaptive_quant_frame runs when the picture comes in, encoder.c:1420-1421)
+        self.aq_slots = None
+        if self.rd_opt["aq_mode"]:
+            self.aq_slots = [(DeviceArray(lib, (B, n), np.int32), DeviceArray(lib, (B, n), np.float32)) for _ in range(self.n_slots)]
+        # per chain: [(pool index, poc, MbState copy with this chain's frame-level scalars)], newest first; the IDR's input number; frames coded
+        self.crefs = [[] for _ in range(B)]
+        self.c_last_idr = [0] * B
+        self.c_coded = [0] * B
+        lib.x264hip_chain_sweep_bytes.restype = C.c_size_t
+        lib.x264hip_host_alloc.restype = C.c_void_p
+        tb = lib.x264hip_chain_sweep_bytes()
+        self.tab_host = lib.x264hip_host_alloc(C.c_size_t(tb * B))
+        self.tab_dev = DeviceArray(lib, (tb * B,), np.uint8)
+        self.elems_dev = [DeviceArray(lib, (B,), np.int32) for _ in range(len(self.pool))]
+        self.flushing = False
+        self.coded_now = [None] * B
+        self.n_sweeps = 0
+
+    # ---- one call of x264_encoder_encode for every chain --------------------------------------------------------------------------
+    def step(self, fill):
+        """fill(picture, frame): write input picture `frame` of every chain into `picture` (ctx.upload / ctx.synth); None: flush.
+        Returns the list of Coded for the chains that coded a frame (empty while the B buffer fills; empty for good once flushed)."""
+        L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
+        c.sync()                                        # the previous step's launches have read their tables / element lists
+        if fill is None:
+            self.flushing = True
+        else:
+            frame = self.lb.put(lambda pic, f: self._fill(fill, pic, f))
+        frames = self.lb.get(self.flushing)
+        B = c.batch
+        self.coded_now = [None] * B
+        todo = [(ci, fr) for ci, fr in enumerate(frames) if fr is not None]
+        if not todo:
+            return []
+        keep = []                                       # everything the C call reads must outlive it
+        entries = (ChainSweep * len(todo))()
+        b = self.cqm.bufs
+        rb = self.rd_bufs
+        written, filt = set(), {}
+        out = []
+        for k, (ci, fr) in enumerate(todo):
+            idr = fr.type == LA.TYPE_IDR
+            stype = SLICE_I if fr.type in (LA.TYPE_IDR, LA.TYPE_I) else SLICE_B if fr.type == LA.TYPE_B else SLICE_P
+            if idr:
+                self.crefs[ci], self.c_last_idr[ci] = [], fr.frame
+            refs_all = self.crefs[ci]
+            poc = fr.poc
+            used = {r[0] for r in refs_all}
+            pic_i = next(i for i in range(len(self.pool)) if i not in used)
+            recon, state = self.pool[pic_i], self.states[pic_i]
+            refs = sorted([r for r in refs_all if r[1] < poc], key=lambda r: -r[1])[:o["n_refs"]] if stype != SLICE_I else []
+            refs1 = sorted([r for r in refs_all if r[1] > poc], key=lambda r: r[1])[:1] if stype == SLICE_B else []
+            qp = fr.qp
+            slot = self.look.slot(fr.frame)
+            assert self.look.frame_of_slot[slot] == fr.frame, "input frame %d left its lookahead slot before it was coded (n_slots too small)" % fr.frame
+            lw0 = lw1 = None
+            n = self.look.n
+            if stype != SLICE_I and fr.lowres_l0:     # the kernel adds the chain's offset in an [batch][n_mb][2] array to the pointer it is given
+                lw0 = self.look.mv_ptr(ci, fr.frame, 0, fr.frame - fr.ref0_frame) - 4 * n * ci
+            if stype == SLICE_B and fr.lowres_l1:
+                lw1 = self.look.mv_ptr(ci, fr.frame, 1, fr.ref1_frame - fr.frame) - 4 * n * ci
+            p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
+                            subme=o["subme"], chroma_me=o["chroma_me"], mv_range=o["mv_range"] or 512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
+                            cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
+                            quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
+                            quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
+                            cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
+                            noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless,
+                            lowres_mv=lw0)
+            rd = SliceRd(trellis=ro["trellis"], psy_rd=self.psy_rd_fix, write=1, cabac_init_idc=ro["cabac_init_idc"], i_frame=self.c_coded[ci],
+                         qp_min=ro["qp_min"], qp_max=ro["qp_max"], f_qpm=fr.f_qpm, aq_offset=self.aq_slots[slot][1].ptr if self.aq_slots else None,
+                         cost_mv_all=rb["cost_mv_all"].ptr, unquant4_mf=rb["unquant4_mf"].ptr, unquant8_mf=rb["unquant8_mf"].ptr,
+                         payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
+                         stale=rb["stale"].ptr, i_frame_stride=0)
+            p.rd = C.addressof(rd)
+            keep += [p, rd]
+            if stype == SLICE_B:
+                sb = SliceB(fref1=C.addressof(self.pool[refs1[0][0]]), l1_state=C.addressof(refs1[0][2]), ref1_poc=refs1[0][1],
+                            weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"], lowres_mv1=lw1)
+                p.b = C.addressof(sb)
+                keep.append(sb)
+            for i, r in enumerate(refs):
+                p.ref_poc[i] = r[1]
+            arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(self.pool[r[0]]) for r in refs]) if refs else None
+            mine = MbState.from_buffer_copy(state.st)        # this chain's view of the state: the device arrays + its own frame-level scalars
+            keep += [arr, mine]
+            entries[k] = ChainSweep(ci, C.addressof(self.look.pics[slot]), C.cast(arr, C.c_void_p) if arr else None, len(refs), C.addressof(recon),
+                                    C.addressof(p), C.addressof(refs[0][2]) if refs else None, C.addressof(mine))
+            if pic_i not in written:
+                written.add(pic_i)
+                c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(state.st)), "mb_state_clear_progress")
+            cd = Coded()
+            cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
+            cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
+            out.append(cd)
+            self.coded_now[ci] = cd
+            if stype != SLICE_B:                           # kept: filtered below, then this chain's newest reference
+                filt.setdefault(pic_i, []).append(ci)
+                self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
+            self.c_coded[ci] += 1
+        c.check(L.x264hip_slice_sweep_chains(c.h, entries, len(todo), C.c_void_p(self.tab_host), self.tab_dev.p), "slice_sweep_chains")
+        self.n_sweeps += 1
+        if self.nr:                                        # x264_noise_reduction_update at the end of every frame (encoder.c:1755)
+            c.check(L.x264hip_noise_reduction_update(c.h, C.byref(self.nr), o["noise_reduction"]), "noise_reduction_update")
+        # x264_fdec_filter_row for the kept frames: loop filter, borders, half-pel planes, on the elements that were just written
+        for pic_i, chains in filt.items():
+            recon, s = self.pool[pic_i], self.states[pic_i].st
+            el = self.elems_dev[pic_i]
+            lst = np.zeros(c.batch, np.int32)
+            lst[:len(chains)] = chains
+            el.set(lst)
+            c.check(L.x264hip_frame_ctx_elements(c.h, el.p, len(chains)), "frame_ctx_elements")
+            if o["deblock"]:
+                dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
+                                   alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1,
+                                   sub8x8=1 if o["inter"] & 0x20 else 0)
+                c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
+            c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
+            c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
+        c.check(L.x264hip_frame_ctx_elements(c.h, None, 0), "frame_ctx_elements")
+        self._keep = keep
+        self.lb.end([ci for ci, _ in todo])
+        self.last_bufs, self.last_ctx = rb, c
+        return out
+
+    def _fill(self, fill, pic, frame):
+        fill(pic, frame)
+        if self.aq_slots:
+            c, L, ro = self.ctx, self.lib, self.rd_opt
+            en, off = self.aq_slots[self.look.slot(frame)]
+            L.x264hip_adaptive_quant_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+            c.check(L.x264hip_adaptive_quant_frame(c.h, C.byref(pic), C.c_float(ro["aq_strength"]), en.p, off.p), "adaptive_quant_frame")
+
+    def payloads(self):
+        """slice_data() of the frame each chain coded in the last step (None where it coded nothing); valid after sync()."""
+        all_ = super().payloads()
+        return [p if self.coded_now[i] is not None else None for i, p in enumerate(all_)]
+
+    def status(self):
+        c = self.ctx
+        for s in self.states:
+            c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(s.st)), "slice_sweep_status")
+
+    def close(self):
+        self.lb.close()
+        self.look.close()
+        for pair in self.aq_slots or []:
+            for a in pair:
+                a.free()
+        for a in [self.tab_dev] + self.elems_dev:
+            a.free()
+        if self.tab_host:
+            self.lib.x264hip_host_free(C.c_void_p(self.tab_host))
+            self.tab_host = None
+        super().close()

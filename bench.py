@@ -98,6 +98,55 @@ def _cpu_chain(job):
     return spent, kind, pays
 
 
+SEG = 4096                 # frames of the one long clip between the starts of two chains' segments (stream mode)
+
+
+def _cpu_stream(job):
+    """One chain through the reference's WHOLE encoder on one core: x264_encoder_encode's frame queue, x264_slicetype_decide, the CRF
+    rate control and the slice loop (oracle/ref_slice.c refslice_encode_stream).  Own process, like _cpu_chain."""
+    import time as _t
+    from oracle import refslice as rs
+    width, height, n_in, kw, ekw, g, want_payload = job
+    fr = [synth.frame(width, height, g * SEG + f) for f in range(n_in)]
+    y, u, v = (np.ascontiguousarray(np.stack([f[i] for f in fr])) for i in range(3))
+    p = rs.make_params(width, height, n_in, **kw)
+    t0 = _t.perf_counter()
+    out = rs.run_reference_stream(p, rs.make_ext(**ekw), y, u, v)
+    spent = _t.perf_counter() - t0
+    recs = None
+    if want_payload:
+        recs = [(int(out["frame_info2"][f][0]), int(out["frame_info"][f][0]), int(out["frame_info"][f][1]), bytes(out["payload"][f, :int(out["payload_len"][f])]))
+                for f in range(n_in)]
+    return spent, "reference", recs
+
+
+def stream_ext(args):
+    o = rd_options(args)
+    o.update(b_adapt=args.b_adapt, pre_scenecut=1, scenecut_threshold=args.scenecut, crf=args.crf, keyint_min=0)
+    return o
+
+
+def cpu_baseline_stream(args):
+    """The stream mode's CPU leg: the reference's whole encoder (lookahead and rate control included) on chain 0's pictures -- its
+    coded frames are the parity check's -- then one such encoder per host core on other chains' pictures."""
+    import multiprocessing as mp
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")):
+        return None, None
+    n_in = args.cpu_frames
+    kw, ekw = analysis_options(args), stream_ext(args)
+    spent1, kind, recs = _cpu_stream((args.width, args.height, n_in, kw, ekw, 0, True))
+    avail = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    cores = max(1, min(avail, args.cpu_procs or avail))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_stream, [(args.width, args.height, n_in, kw, ekw, 1 + i, False) for i in range(cores)], chunksize=1)
+    spent_all = max(r[0] for r in res)
+    return {"value": round(cores * n_in / spent_all, 4), "unit": "frames/s", "cores": cores, "kind": kind, "one_core": round(n_in / spent1, 4),
+            "sample": "the reference's whole encoder -- frame queue, x264_slicetype_decide (b-adapt %d, pre-scenecut), x264_ratecontrol_start (CRF %.1f), the per-macroblock "
+                      "loop with the same options, entropy coding included -- on chains of %d %dx%d frames of the same clip: chain 0 on one core (%.1f s), then %d processes, "
+                      "one chain each, on the %d host cores (%.1f s); C compiled -O3, no asm"
+                      % (args.b_adapt, args.crf, n_in, args.width, args.height, spent1, cores, cores, spent_all)}, recs
+
+
 def cpu_baseline(args, g_total):
     """The same loop on the host cores: the REFERENCE's own x264_macroblock_cache_load / _analyse / _encode / _write_cabac /
     _cache_save + x264_frame_deblock_row + x264_frame_filter, compiled from the reference's sources where they lie
@@ -119,6 +168,152 @@ def cpu_baseline(args, g_total):
             "sample": "the same per-macroblock loop with the same options on chains of %d %dx%d frames of the same clip: chain 0 on one core (%.1f s), "
                       "then %d processes, one chain each, on the %d host cores (%.1f s); C compiled -O3, no asm%s"
                       % (n, args.width, args.height, spent1, cores, cores, spent_all, ", entropy coding included" if raster else ", no entropy coding on either side")}, pays
+
+
+def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_recs, delay):
+    """The default: every chain is a stream of its own through the whole encoder.  A step = one x264_encoder_encode call per chain: a
+    picture comes in (synthesised on the device into the lookahead's slot; lowres planes, intra costs, AQ offsets follow), the
+    lookahead answers what the slice-type decision and the rate control ask (batched x264_slicetype_frame_cost launches), and every
+    chain codes the frame its own queue hands it, at its own QP, in one chain-table launch per kernel kind."""
+    from x264_vs2008_amd.stream import StreamEncoder
+    o = rd_options(args)
+    enc = StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut, pre_scenecut=1,
+                        write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, **analysis_options(args), **o)
+    ctx = enc.ctx
+    d = ctx.dims
+    px = d.mb_w * 16 * d.lines_y
+    n_coded = args.warmup + args.steps
+    check = ref_recs is not None
+    cap_n = min(CAPTURE, args.payload_cap - sl.PAYLOAD_LEAD)
+    hip.x264hip_host_alloc.restype = C.c_void_p
+    pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
+    coded0 = []                                          # chain 0's coded frames: (input number, slice type, qp)
+    fed = [0]
+
+    def fill(pic, f):
+        ctx.synth(pic, g_first * SEG + f, g_step * SEG)
+
+    def one_step():
+        out = enc.step(fill)
+        fed[0] += 1
+        if out and check and rank == 0:
+            c0 = enc.coded_now[0]
+            if c0 is not None and len(coded0) < n_coded:
+                k = len(coded0)
+                enc.payload_async(0, pin + k * (cap_n + 64), pin + k * (cap_n + 64) + 64, cap_n)
+                coded0.append((c0.frame, c0.slice_type, c0.qp))
+        return out
+
+    def sync_all():
+        assert hip.x264hip_device_synchronize() == 0
+
+    for _ in range(delay):                               # the B buffer fills: nothing is coded yet (encoder.c:1423-1430)
+        assert not one_step()
+    for _ in range(args.warmup):
+        assert len(one_step()) == B
+    sync_all()
+    enc.status()
+    if dist is not None:
+        dist.barrier()
+    enc.sweep_events = []
+    rounds0, tasks0 = enc.lb.rounds, enc.look.n_tasks_run
+    t0 = time.perf_counter()
+    kinds = {"P": 0, "B": 0, "I": 0}
+    for _ in range(args.steps):
+        out = one_step()
+        assert len(out) == B
+        for cd in out:
+            kinds["PBI"[cd.slice_type]] += 1
+    sync_all()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    enc.status()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        nb = torch.tensor([B], dtype=torch.int64)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        chains_total = int(nb[0])
+    else:
+        chains_total = B
+
+    checked = 0
+    if check:
+        for k, (frame, st, qp) in enumerate(coded0):
+            base = pin + k * (cap_n + 64)
+            n = C.c_int32.from_address(base).value
+            got = C.string_at(base + 64, min(n, cap_n))
+            rf, rst, rqp, want = ref_recs[k]
+            if (frame, st, qp) != (rf, rst, rqp):
+                raise SystemExit("bench.py: PARITY FAILURE -- chain 0, coded frame %d: the GPU side codes input %d as slice type %d at QP %d, the reference input %d as "
+                                 "type %d at QP %d" % (k, frame, st, qp, rf, rst, rqp))
+            if n != len(want) or got != want[:cap_n]:
+                raise SystemExit("bench.py: PARITY FAILURE -- chain 0, coded frame %d (input %d): the GPU's slice payload (%d bytes) differs from the reference's "
+                                 "(%d bytes)" % (k, frame, n, len(want)))
+            checked += 1
+        hip.x264hip_host_free(C.c_void_p(pin))
+
+    ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, _, _, _ in enc.sweep_events]
+    by_all = [by for _, _, _, by, _ in enc.sweep_events]
+    for a, b, _, _, _ in enc.sweep_events:
+        hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
+    sweep_ms, sweep_bytes = float(np.mean(ms_all)), int(np.mean(by_all))
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    if rank == 0:
+        fps = chains_total * args.steps / dt
+        frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)
+        size = "%dp" % args.height
+        total = sum(kinds.values())
+        metric = ("encoded frames/sec, %s, preset=medium's flag set with the encoder's own lookahead and rate control (--crf %.0f --b-adapt %d --pre-scenecut, %s, subme %d RD, "
+                  "trellis %d, psy-rd, aq-mode %d, CABAC payload on the GPU); 1/2/4/8 MI355X (bit-exact)"
+                  % (size, args.crf, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.aq_mode))
+        what = ("%dx%d streams (one per chain, segments of one synthetic clip) through x264_encoder_encode's path on the GPU: pictures synthesised on the device, "
+                "x264_frame_init_lowres + lookahead costs (x264_slicetype_frame_cost, one wavefront per task) feeding the library's x264_slicetype_decide / x264_ratecontrol_start "
+                "(host C), then the per-macroblock loop in raster order (one wavefront per chain: cache_load, x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, "
+                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct spatial --me %s "
+                "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d --pre-scenecut, chroma ME, fast "
+                "P-skip, dct-decimate, CABAC; payload bytes stay on the device (slice / NAL headers and the download are the host's)"
+                % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
+                   args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut))
+        missing = ["the scene cut that re-encodes (the reference's default at --threads 1): this run is the preset plus --pre-scenecut, the flag the reference forces with "
+                   "--threads > 1 and BASELINE.md prescribes for GOP-sharded runs", "slice / NAL headers around the payload"]
+        line = {
+            "metric": metric,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": what, "matches_baseline": False, "missing": missing,
+                       "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
+                       "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint,
+                       "per_chain_fps": round(fps / chains_total, 4),
+                       "latency_note": "throughput exists only with thousands of streams in flight: one chain advances one frame per step",
+                       "slice_types_in_timed_steps": {k: round(v / max(total, 1), 4) for k, v in kinds.items()},
+                       "lookahead": {"cost_tasks_per_step_and_chain": round((enc.look.n_tasks_run - tasks0) / max(args.steps * B, 1), 3),
+                                     "cost_launch_rounds_per_step": round((enc.lb.rounds - rounds0) / max(args.steps, 1), 3), "slots": enc.n_slots, "delay": delay},
+                       "parallelism": "B streams per GPU; per step one chain-table launch per kernel kind (I / P and B chains side by side), one wavefront per chain walking its frame "
+                                      "in raster order; lookahead cost tasks one wavefront each; chains shard across GPUs with no data-path collective",
+                       "parity_checked_frames": checked,
+                       "parity": ("chain 0 of rank 0, all %d coded frames of this run (%d of them timed): input order, slice types, QPs and payload bytes equal the reference's whole "
+                                  "encoder (frame queue, slicetype decision, CRF, per-macroblock loop) run on the same pictures" % (checked, max(0, checked - args.warmup))) if checked else
+                                 "not checked in this run (no CPU leg: --no-cpu, no oracle/_ref, or more than one rank)"},
+            "roofline": {"bound": "hbm", "kernel": "k_slice_sweep<raster, chain table>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "traffic_note": "no rocprofv3 PMC measurement committed for this configuration",
+                         "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
+                         "note": "one 'launch' = a step's chain-table launches together (the I / P kernel and the B kernel, back to back on the stream; HIP events around the pair); "
+                                 "the sweep is bound by the serial macroblock chain of a slice (%d macroblocks one after the other per frame, %d frames in flight), not by bandwidth; "
+                                 "whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w * d.mb_h, B, frame_bytes, frame_bytes * (fps / world) / 1e9)},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -156,6 +351,12 @@ def main():
     ap.add_argument("--dct8", type=int, default=1, help="param.analyse.b_transform_8x8")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU leg's chains (0: warmup + steps, every GPU frame of chain 0 is then checked)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU leg (and with it the parity check of this run)")
+    ap.add_argument("--stream", type=int, default=-1, help="1: the real lookahead and rate control in front of the sweep (x264_vs2008_amd/stream.py): --crf, --b-adapt, pre-scenecut, "
+                    "lowres motion candidates, every chain placing its own B frames and pricing its own frames (-1: 1 for the raster variant, 0 with --wavefront 1); "
+                    "0: round 2's lock-step chains at constant QP with a fixed B pattern")
+    ap.add_argument("--crf", type=float, default=23.0)
+    ap.add_argument("--b-adapt", type=int, default=1)
+    ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold of the pre-encode scene cut (--pre-scenecut)")
     args = ap.parse_args()
     wf = bool(args.wavefront)
     uhd = args.preset == "uhd"
@@ -164,9 +365,12 @@ def main():
     args.me = args.me if args.me >= 0 else (2 if uhd else 1)
     args.steps = args.steps or (24 if wf else 12)
     args.warmup = args.warmup if args.warmup >= 0 else (3 if wf else 2)
-    args.batch = args.batch or (240 if wf else 512 if uhd else 2048)
+    args.stream = (0 if wf else 1) if args.stream < 0 else args.stream
+    if args.stream and wf:
+        raise SystemExit("bench.py: --stream needs the raster variant")
+    args.batch = args.batch or (240 if wf else (384 if args.stream else 512) if uhd else (1536 if args.stream else 2048))
     args.subme = args.subme or (5 if wf else 7)
-    args.keyint = args.keyint or (24 if wf else 12)
+    args.keyint = args.keyint or (24 if wf else 250 if args.stream else 12)
     args.payload_cap = args.payload_cap or ((4 << 20) if uhd else (1 << 20))
     if wf:
         args.trellis, args.psy_rd, args.aq_mode = 0, 0.0, 0
@@ -175,7 +379,8 @@ def main():
     if args.bframes:
         args.inter |= 0x100                          # X264_ANALYSE_BSUB16x16: the medium preset's b8x8
     n_coded = args.warmup + args.steps
-    args.cpu_frames = args.cpu_frames or n_coded
+    delay = (max(args.bframes, 3) * 4 if args.b_adapt == 2 else args.bframes) if args.stream and args.bframes else 0     # h->frames.i_delay, encoder.c:703-706
+    args.cpu_frames = args.cpu_frames or (n_coded + delay)
 
     # stdout carries ONE line, the JSON: everything else any library prints there (gloo announces its connections on stdout) goes
     # to stderr -- file descriptor 1 points at stderr until the result is written to the saved descriptor
@@ -198,7 +403,7 @@ def main():
     # ---- the CPU leg first: the reference on chain 0's frames (rank 0 of a single-GPU run only), before any HIP call ----
     cpu, ref_pays = None, None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_frames > 0:
-        cpu, ref_pays = cpu_baseline(args, g_total)
+        cpu, ref_pays = cpu_baseline_stream(args) if args.stream else cpu_baseline(args, g_total)
 
     dist = None
     if world > 1:
@@ -217,6 +422,8 @@ def main():
     # the raster variant's product is the payload: no coefficient-level arrays in the states, and a payload buffer sized for the
     # content (the sweep stops with an error, never writes past it, if a chain's slice does not fit)
     ropt = {} if wf else dict(write=1, levels=False, payload_cap=args.payload_cap, **gpu_options(args))
+    if args.stream:
+        return run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_pays, delay)
     enc = sl.ChainEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, **analysis_options(args), **ropt)      # quantiser tables: x264hip_cqm_init (flat matrices)
     ctx = enc.ctx
     d = ctx.dims

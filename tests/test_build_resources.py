@@ -37,8 +37,9 @@ def kernel_metadata(tmp_path):
                 out[name.group(1)] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_count|vgpr_spill_count|group_segment_fixed_size):\s+(\d+)", blk)}
     return out
 
-RASTER = re.compile(r"ILi\dELb[01]ELb1ELb[01]ELb[01]ELb[01]EEv")      # k_slice_sweep<WPE, LL, RD = true, BS, TD, RF>
-REFINE = re.compile(r"ILi\dELb[01]ELb1ELb[01]ELb[01]ELb1EEv")         # ... with the RD refinement of subme 8-9 (RF = true)
+RASTER = re.compile(r"ILi\dELb[01]ELb1ELb[01]ELb[01]ELb[01]ELb[01]EEv")      # k_slice_sweep<WPE, LL, RD = true, BS, TD, RF, CH>
+REFINE = re.compile(r"ILi\dELb[01]ELb1ELb[01]ELb[01]ELb1ELb[01]EEv")         # ... with the RD refinement of subme 8-9 (RF = true)
+TABLE = re.compile(r"ILi\dELb[01]ELb1ELb[01]ELb[01]ELb[01]ELb1EEv")           # ... launched from a chain table (CH = true)
 
 
 def test_sweep_kernels_use_no_scratch_memory(tmp_path):
@@ -59,11 +60,18 @@ def test_raster_sweep_resources_are_bounded(tmp_path):
     had two call sites the compiler kept it as a function and 1.8 KB per lane of shared variables in scratch: rocprofv3 counted 64 KB
     of HBM writes per macroblock, profiles/r02_raster_traffic.json; one call site -> inlined -> registers.)"""
     md = kernel_metadata(tmp_path)
-    rd = [v for k, v in md.items() if "k_slice_sweep" in k and RASTER.search(k) and not REFINE.search(k)]
+    rd = [v for k, v in md.items() if "k_slice_sweep" in k and RASTER.search(k) and not REFINE.search(k) and not TABLE.search(k)]
     assert len(rd) == 3                                  # I / P, B with spatial and B with temporal direct prediction
+    # the chain-table launches (x264hip_slice_sweep_chains: I / P, I / P with the refinement, the extended B kernel) read their arguments
+    # from a table entry through the constant address space; they must stay as free of private memory as the kernels they mirror
+    tb = {k: v for k, v in md.items() if "k_slice_sweep" in k and TABLE.search(k)}
+    assert len(tb) == 3, sorted(tb)
+    for k, v in tb.items():
+        lim = 512 if REFINE.search(k) else 68
+        assert v["private_segment_fixed_size"] <= lim and v["group_segment_fixed_size"] <= 24 * 1024, (k, v)
     # the refinement variant (subme 8-9) is a kernel of its own, so that what it spills (its candidate generator's state on top of the
     # analysis records: a few hundred bytes per lane) costs the default kernels above nothing
-    rf = [v for k, v in md.items() if "k_slice_sweep" in k and REFINE.search(k)]
+    rf = [v for k, v in md.items() if "k_slice_sweep" in k and REFINE.search(k) and not TABLE.search(k)]
     assert len(rf) == 1 and rf[0]["private_segment_fixed_size"] <= 512 and rf[0]["group_segment_fixed_size"] <= 24 * 1024, rf
     for v in rd:
         # (the B instantiation reserves a small frame -- at most a handful of spilled registers, 12 bytes per lane at the time of

@@ -115,9 +115,12 @@ __global__ __launch_bounds__(64) void k_look_cost(const LookTaskDev *__restrict_
                 int mvx[2] = {0, 0}, mvy[2] = {0, 0};
                 for (int l = 0; l < 1 + b_bidir; l++) {
                     int cost, vx, vy;
-                    if (T.do_search[l]) {
+                    // (selects, not T.x[l]: a dynamically indexed member would put the whole task record into private memory)
+                    i16 *const mv_l = l ? T.mv[1] : T.mv[0];
+                    int *const mcost_l = l ? T.mcost[1] : T.mcost[0];
+                    if (l ? T.do_search[1] : T.do_search[0]) {
                         // reverse-order predictors, slicetype.c:151-163: right, below, below-left, below-right (zero where absent)
-                        const u32 *rc = s_row[l][my & 1], *rb = s_row[l][(my + 1) & 1];
+                        const u32 *rc = s_row[l][my & 1], *rb = s_row[l][(my + 1) & 1];     // (LDS: indexing is free)
                         u32 cand[4] = {0, 0, 0, 0};
                         int n_mvc = 0;
                         if (mx < mb_w - 1) cand[n_mvc++] = rc[mx + 1];
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(64) void k_look_cost(const LookTaskDev *__restrict_
                         LK_SYNC();
                         MxCtx c;
                         c.fe = (MX_LDS(u32))s_fe; c.fe_u = (MX_LDS(u8))s_fe; c.fe_v = (MX_LDS(u8))s_fe;
-                        const u8 *const *rp = T.pl[1 + l];
-                        c.pl[0] = (MX_GLB(u8))(rp[0] + off); c.pl[1] = (MX_GLB(u8))(rp[1] + off); c.pl[2] = (MX_GLB(u8))(rp[2] + off); c.pl[3] = (MX_GLB(u8))(rp[3] + off);
+                        c.pl[0] = (MX_GLB(u8))((l ? T.pl[2][0] : T.pl[1][0]) + off); c.pl[1] = (MX_GLB(u8))((l ? T.pl[2][1] : T.pl[1][1]) + off);
+                        c.pl[2] = (MX_GLB(u8))((l ? T.pl[2][2] : T.pl[1][2]) + off); c.pl[3] = (MX_GLB(u8))((l ? T.pl[2][3] : T.pl[1][3]) + off);
                         c.cu = c.pl[0]; c.cv = c.pl[0];
                         c.cost_g = (MX_GLB(i16))cost_g; c.cost_l = (MX_LDS(i16))s_costl; c.has_cost_l = true;
                         c.patch = (MX_LDS(u8))s_fe; c.has_patch = false; c.patch_on = false;
@@ -152,13 +155,13 @@ __global__ __launch_bounds__(64) void k_look_cost(const LookTaskDev *__restrict_
                         LK_SYNC();                            // s_mvc read; the row entry below is this block's own
                         if (lane == 0) {
                             s_row[l][my & 1][mx] = (u32)(u16)vx | ((u32)(u16)vy << 16);
-                            *(u32 *)(T.mv[l] + 2 * xy) = (u32)(u16)vx | ((u32)(u16)vy << 16);
-                            T.mcost[l][xy] = cost;
+                            *(u32 *)(mv_l + 2 * xy) = (u32)(u16)vx | ((u32)(u16)vy << 16);
+                            mcost_l[xy] = cost;
                         }
                     } else {
-                        vx = MX_UNI((int)T.mv[l][2 * xy]); vy = MX_UNI((int)T.mv[l][2 * xy + 1]); cost = MX_UNI(T.mcost[l][xy]);
+                        vx = MX_UNI((int)mv_l[2 * xy]); vy = MX_UNI((int)mv_l[2 * xy + 1]); cost = MX_UNI(mcost_l[xy]);
                     }
-                    mvx[l] = vx; mvy[l] = vy;
+                    if (l) { mvx[1] = vx; mvy[1] = vy; } else { mvx[0] = vx; mvy[0] = vy; }
                     bcost = min(bcost, cost);
                 }
                 if (b_bidir && (mvx[0] | mvy[0] | mvx[1] | mvy[1])) LK_TRY_BIDIR(mvx[0], mvy[0], mvx[1], mvy[1], 5);

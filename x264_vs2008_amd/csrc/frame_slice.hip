@@ -1,6 +1,8 @@
 // frame_slice.hip -- host side of the macroblock sweep (x264hip_slice_sweep_frame ...) and the wavefront-schedule kernel variants.
 // The kernel itself lives in slice_kernel.h; its raster-order variant is instantiated in frame_slice_rd.hip (a translation unit of
 // its own so that the two compile side by side).
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "slice_kernel.h"
 #include "x264hip_lookahead.h"
@@ -323,6 +325,7 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     return 0;
 }
 
+struct ChainAux { hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done = nullptr; };
 // The chain-table launch: every entry is a sweep of ONE chain (batch element) with its own pictures, states and slice parameters.
 extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev)
 {
@@ -351,9 +354,30 @@ extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sw
     for (int i = 0; i < n; i++) st[at[kinds[i]]++] = tmp[i];
     HIPCHK(hipMemcpyAsync(table_dev, st, sizeof(SwDesc) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     const SwDesc *tab = (const SwDesc *)table_dev;
+    // The I / P chains and the B chains of a step are different chains: their kernels run side by side, the B kernel on a stream of its
+    // own between two events (behind the table's upload, ahead of whatever follows on the context's stream).
+    const bool two = cnt[SW_KIND_BT] && (cnt[SW_KIND_RD] || cnt[SW_KIND_RF]);
+    static std::mutex mu;
+    static std::unordered_map<x264hip_frame_ctx *, ChainAux> aux_of;
+    ChainAux *ax = nullptr;
+    if (two) {
+        std::lock_guard<std::mutex> g(mu);
+        ax = &aux_of[c];
+        if (!ax->stream) {
+            HIPCHK(hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ax->ready, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ax->done, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ax->ready, c->stream));
+        HIPCHK(hipStreamWaitEvent(ax->stream, ax->ready, 0));
+    }
+    if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], two ? ax->stream : c->stream);
     if (cnt[SW_KIND_RD]) x264hip_launch_slice_rd_ch(tab + base[SW_KIND_RD], cnt[SW_KIND_RD], c->stream);
     if (cnt[SW_KIND_RF]) x264hip_launch_slice_rf_ch(tab + base[SW_KIND_RF], cnt[SW_KIND_RF], c->stream);
-    if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], c->stream);
+    if (two) {
+        HIPCHK(hipEventRecord(ax->done, ax->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, ax->done, 0));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -257,6 +257,8 @@ class LookaheadBatch:
             f = la.put()
             assert frame is None or f == frame
             frame = f
+        old = self.dev.frame_of_slot[self.dev.slot(frame)]
+        assert old < 0 or old < self.oldest_live(), "lookahead ring of %d slots too small: input frame %d is still alive when %d arrives" % (self.dev.n_slots, old, frame)
         fill(self.dev.begin_frame(frame), frame)
         self.dev.prepare(frame)
         return frame

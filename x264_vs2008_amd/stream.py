@@ -54,7 +54,7 @@ class StreamEncoder(ChainEncoder):
                                         qp_min=self.rd_opt["qp_min"], qp_max=self.rd_opt["qp_max"], qp_step=qp_step)
         bf = self.bopt["bframes"]
         delay = (max(bf, 3) * 4 if b_adapt == 2 and bf else bf)
-        self.n_slots = n_slots or (delay + 2 * bf + 4)
+        self.n_slots = n_slots or (delay + bf + 3)        # oldest live frame .. newest input spans at most delay + bframes + 2 (asserted when a slot is reused)
         self.look = LA.LookaheadDevice(self.ctx, self.n_slots, bf, me_method=o["me_method"], me_range=o["me_range"], weightb=self.bopt["weightb"],
                                        bframe_bias=bframe_bias, subme=o["subme"], lossless=self.lossless)
         self.lb = LA.LookaheadBatch(self.ctx, self.la_params, self.look, speculative=speculative)
@@ -76,6 +76,7 @@ class StreamEncoder(ChainEncoder):
         self.flushing = False
         self.coded_now = [None] * B
         self.n_sweeps = 0
+        self.sweep_events = None       # set to [] to collect (start, stop, chains, algorithmic bytes) HIP events around every step's sweep launches
 
     # ---- one call of x264_encoder_encode for every chain --------------------------------------------------------------------------
     def step(self, fill):
@@ -159,7 +160,17 @@ class StreamEncoder(ChainEncoder):
                 filt.setdefault(pic_i, []).append(ci)
                 self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
             self.c_coded[ci] += 1
+        ev = None
+        if self.sweep_events is not None:
+            ev = (L.x264hip_event_create(), L.x264hip_event_create())
+            L.x264hip_event_record(C.c_void_p(ev[0]), C.c_void_p(c.stream))
         c.check(L.x264hip_slice_sweep_chains(c.h, entries, len(todo), C.c_void_p(self.tab_host), self.tab_dev.p), "slice_sweep_chains")
+        if ev:
+            L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
+            px = self.ctx.dims.mb_w * 16 * self.ctx.dims.lines_y
+            # per frame the source (1.5 B/px), each reference's four luma planes + chroma (4.5 B/px) and the reconstruction (1.5 B/px)
+            self.sweep_events.append((ev[0], ev[1], len(todo), sum(px * (3.0 + 4.5 * (cd.n_ref0 + cd.n_ref1)) for cd in out),
+                                      "".join("PBI"[cd.slice_type] for cd in out[:1]) + ":%d" % len(todo)))
         self.n_sweeps += 1
         if self.nr:                                        # x264_noise_reduction_update at the end of every frame (encoder.c:1755)
             c.check(L.x264hip_noise_reduction_update(c.h, C.byref(self.nr), o["noise_reduction"]), "noise_reduction_update")

@@ -1,30 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/sec of the per-macroblock hot loop on 1..N MI355X.
+"""bench.py -- frames/sec of x264's per-macroblock hot loop, with the encoder's own lookahead and rate control around it, on 1..N MI355X.
 
-The workload is ONE long synthetic 1080p clip (SURVEY.md 8(d)'s integer generator) cut into closed GOPs of `keyint` frames.  Every GPU
-advances B GOP chains in lock step: a "step" codes one frame (in coding order: I P B B B P ...) of each of its B chains.  Chain g
-codes GOPs g, g + G, g + 2G, ... of the clip (G = chains over all GPUs), so no two chains -- and no frame and any of its references
--- ever hold the same picture.  The source of a step is synthesised ON THE DEVICE right before the step's sweep (x264hip_picture_synth,
-three small kernels inside the timed region, < 0.2 % of a step): nothing is uploaded, nothing is re-used.
-Per step and chain the GPU does what x264_slice_write + x264_fdec_filter_row do for one frame (R/encoder/encoder.c:1141-1291,
-983-1056):
+DEFAULT (--stream 1): every GPU runs B independent STREAMS (chains), each a segment of ONE long synthetic 1080p clip (SURVEY.md 8(d)'s
+integer generator; chain g's pictures start g * 4096 frames into it), through what x264_encoder_encode does with BASELINE.md's MED flag
+set plus --pre-scenecut:
 
-  x264hip_adaptive_quant_frame   x264_adaptive_quant_frame: per-macroblock QP offsets from the source's AC energy
-  x264hip_slice_sweep_frame      raster-order variant (x264hip_slice_rd): cache_load -> x264_macroblock_analyse (RD mode decision,
-                                 subme 7) -> x264_macroblock_encode (trellis 1) -> x264_macroblock_write_cabac -> cache_save for all
-                                 8160 macroblocks, one wavefront per chain; the slice's CABAC payload comes out of the same launch
-  x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   an anchor becomes a reference (B frames are disposable)
+  --crf 23 --ref 3 --bframes 3 --b-adapt 1 --me hex --subme 7 --8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --weightb
+  --mixed-refs --direct spatial, psy-rd 1.0, aq-mode 1, keyint 250, scenecut 40 (decided before the encode), CABAC, deblock
 
-Default options = BASELINE.md's MED flag set as far as it is built: --ref 3 --bframes 3 --weightb --direct spatial --me hex --subme 7
---8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --mixed-refs, psy-rd 1.0, aq-mode 1, CABAC, deblock -- at CONSTANT QP (CRF needs
-the lookahead) and with the B frames in a fixed pattern (b-adapt needs it too): config.matches_baseline is false and config.missing
-lists what is left.  PARITY IS CHECKED IN THIS RUN: rank 0's chain 0 is also coded by the reference's own functions on the host (the
-cpu_baseline leg, before the GPU is touched), and the payload bytes of every frame the GPU produced for that chain -- warm-up and timed
-steps alike, copied out asynchronously -- must equal the reference's, or the run fails (config.parity_checked_frames).
+A "step" is one x264_encoder_encode call for every chain (x264_vs2008_amd/stream.py):
+
+  x264hip_picture_synth            the chain's next picture, synthesised ON THE DEVICE into the lookahead's slot (nothing uploaded)
+  x264hip_lowres_init_frame, x264hip_lookahead_intra_frame, x264hip_adaptive_quant_frame     what the encoder does when a picture comes in
+  x264hip_lookahead_* (host C) + x264hip_lookahead_cost_frames     x264_slicetype_decide (b-adapt 1, scene cut), x264_rc_analyse_slice and
+                                   x264_ratecontrol_start (CRF): every chain places its own B frames and prices its own frames; the
+                                   per-frame costs they read (x264_slicetype_frame_cost) are batched GPU launches, one wavefront per task
+  x264hip_slice_sweep_chains       the per-macroblock loop in raster order for the frame each chain's queue hands it -- cache_load ->
+                                   x264_macroblock_analyse (RD mode decision) -> x264_macroblock_encode (trellis) ->
+                                   x264_macroblock_write_cabac -> cache_save for all 8160 macroblocks, one wavefront per chain, the I / P
+                                   chains and the B chains of the step side by side; the slice's CABAC payload comes out of the launch
+  x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   a kept frame becomes a reference (the elements that coded one)
+
+config.matches_baseline is false for ONE flag: the scene cut is the pre-encode one (--pre-scenecut, which the reference itself forces
+with --threads > 1 and BASELINE.md prescribes for sharded runs), not the one that re-encodes.  PARITY IS CHECKED IN THIS RUN: rank 0's
+chain 0 also goes through the REFERENCE's whole encoder on the host (frame queue, slice-type decision, rate control, slice loop; the
+cpu_baseline leg, before the GPU is touched), and for every frame the GPU side coded for that chain -- warm-up and timed steps alike --
+the input number, slice type, QP and payload bytes must equal the reference's, or the run fails (config.parity_checked_frames).
+
+--stream 0: round 2's lock-step chains (closed GOPs of --keyint 12, constant QP, B frames in a fixed pattern, no lookahead);
 --preset uhd: BASELINE config 2 (3840x2160, --me umh); --wavefront 1: round 1's configuration (subme 5, no RD / trellis / AQ / entropy
 coding; one wavefront per macroblock row); --strong 1: the batch is the TOTAL number of chains, spread over the ranks (strong scaling).
 
-Chains shard across ranks with no data-path collective (closed GOPs).
+Chains shard across ranks with no data-path collective (independent streams / closed GOPs).
 One JSON line on stdout (rank 0).  Launch for N > 1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
 """
@@ -174,61 +181,91 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     """The default: every chain is a stream of its own through the whole encoder.  A step = one x264_encoder_encode call per chain: a
     picture comes in (synthesised on the device into the lookahead's slot; lowres planes, intra costs, AQ offsets follow), the
     lookahead answers what the slice-type decision and the rate control ask (batched x264_slicetype_frame_cost launches), and every
-    chain codes the frame its own queue hands it, at its own QP, in one chain-table launch per kernel kind."""
+    chain codes the frame its own queue hands it, at its own QP, in one chain-table launch per kernel kind.
+    --groups G drives the chains of a GPU as G independently stepping groups (own stream and host thread each).  A step's P chains take
+    about twice as long as its B chains and a group waits for its slowest chain, so the idea was that another group's work fills the wave
+    slots the finished B chains leave; measured, it does not pay (the kernels are latency-bound per wavefront and every resident chain
+    is a wavefront: fewer resident chains run faster each, more run slower), so the default is one group."""
+    import threading
     from x264_vs2008_amd.stream import StreamEncoder
     o = rd_options(args)
-    enc = StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut, pre_scenecut=1,
-                        write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, **analysis_options(args), **o)
-    ctx = enc.ctx
-    d = ctx.dims
-    px = d.mb_w * 16 * d.lines_y
+    G = max(1, min(args.groups, B))
+    sizes = [len(range(j, B, G)) for j in range(G)]
+    offs = [sum(sizes[:j]) for j in range(G)]
     n_coded = args.warmup + args.steps
-    check = ref_recs is not None
+    check = ref_recs is not None and rank == 0
     cap_n = min(CAPTURE, args.payload_cap - sl.PAYLOAD_LEAD)
     hip.x264hip_host_alloc.restype = C.c_void_p
     pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
     coded0 = []                                          # chain 0's coded frames: (input number, slice type, qp)
-    fed = [0]
+    encs = [StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=sizes[j], crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut,
+                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, **analysis_options(args), **o) for j in range(G)]
+    d = encs[0].ctx.dims
+    px = d.mb_w * 16 * d.lines_y
+    kinds = [{"P": 0, "B": 0, "I": 0} for _ in range(G)]
+    errors = []
+    gate = threading.Barrier(G + 1)
 
-    def fill(pic, f):
-        ctx.synth(pic, g_first * SEG + f, g_step * SEG)
-
-    def one_step():
-        out = enc.step(fill)
-        fed[0] += 1
-        if out and check and rank == 0:
+    def one_step(j, timed):
+        enc = encs[j]
+        # group j's chain b is chain g_first + (offs[j] + b) * g_step of the job: its pictures start SEG frames after the previous chain's
+        out = enc.step(lambda pic, f: enc.ctx.synth(pic, (g_first + offs[j] * g_step) * SEG + f, g_step * SEG))
+        if out and check and j == 0:
             c0 = enc.coded_now[0]
             if c0 is not None and len(coded0) < n_coded:
                 k = len(coded0)
                 enc.payload_async(0, pin + k * (cap_n + 64), pin + k * (cap_n + 64) + 64, cap_n)
                 coded0.append((c0.frame, c0.slice_type, c0.qp))
+        if timed:
+            for cd in out:
+                kinds[j]["PBI"[cd.slice_type]] += 1
         return out
 
-    def sync_all():
-        assert hip.x264hip_device_synchronize() == 0
+    def worker(j):
+        try:
+            enc = encs[j]
+            for _ in range(delay):                       # the B buffer fills: nothing is coded yet (encoder.c:1423-1430)
+                assert not one_step(j, False)
+            for _ in range(args.warmup):
+                assert len(one_step(j, False)) == sizes[j]
+            enc.sync()
+            enc.status()
+            gate.wait()                                  # everyone warmed up
+            gate.wait()                                  # the clock runs
+            enc.sweep_events = []
+            for _ in range(args.steps):
+                assert len(one_step(j, True)) == sizes[j]
+            enc.sync()
+        except BaseException as ex:                      # noqa: B036 -- reported by the main thread
+            errors.append(ex)
+            gate.abort()
+            return
+        gate.wait()
 
-    for _ in range(delay):                               # the B buffer fills: nothing is coded yet (encoder.c:1423-1430)
-        assert not one_step()
-    for _ in range(args.warmup):
-        assert len(one_step()) == B
-    sync_all()
-    enc.status()
-    if dist is not None:
-        dist.barrier()
-    enc.sweep_events = []
-    rounds0, tasks0 = enc.lb.rounds, enc.look.n_tasks_run
-    t0 = time.perf_counter()
-    kinds = {"P": 0, "B": 0, "I": 0}
-    for _ in range(args.steps):
-        out = one_step()
-        assert len(out) == B
-        for cd in out:
-            kinds["PBI"[cd.slice_type]] += 1
-    sync_all()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    enc.status()
+    threads = [threading.Thread(target=worker, args=(j,)) for j in range(G)]
+    for t in threads:
+        t.start()
+    try:
+        gate.wait()
+        assert hip.x264hip_device_synchronize() == 0
+        if dist is not None:
+            dist.barrier()
+        rounds0, tasks0 = sum(e.lb.rounds for e in encs), sum(e.look.n_tasks_run for e in encs)
+        t0 = time.perf_counter()
+        gate.wait()
+        gate.wait()                                      # every group's timed steps are done and synchronised
+        assert hip.x264hip_device_synchronize() == 0
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        pass
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for e in encs:
+        e.status()
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -256,9 +293,11 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
             checked += 1
         hip.x264hip_host_free(C.c_void_p(pin))
 
-    ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, _, _, _ in enc.sweep_events]
-    by_all = [by for _, _, _, by, _ in enc.sweep_events]
-    for a, b, _, _, _ in enc.sweep_events:
+    # the dominant kernels, timed live with HIP events on their launch stream: per step and group the chain-table launches together
+    evs = [ev for e in encs for ev in e.sweep_events]
+    ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, _, _, _ in evs]
+    by_all = [by for _, _, _, by, _ in evs]
+    for a, b, _, _, _ in evs:
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
     sweep_ms, sweep_bytes = float(np.mean(ms_all)), int(np.mean(by_all))
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
@@ -266,7 +305,10 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         fps = chains_total * args.steps / dt
         frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)
         size = "%dp" % args.height
-        total = sum(kinds.values())
+        ksum = {k: sum(kk[k] for kk in kinds) for k in "PBI"}
+        total = sum(ksum.values())
+        tasks = sum(e.look.n_tasks_run for e in encs) - tasks0
+        rounds = sum(e.lb.rounds for e in encs) - rounds0
         metric = ("encoded frames/sec, %s, preset=medium's flag set with the encoder's own lookahead and rate control (--crf %.0f --b-adapt %d --pre-scenecut, %s, subme %d RD, "
                   "trellis %d, psy-rd, aq-mode %d, CABAC payload on the GPU); 1/2/4/8 MI355X (bit-exact)"
                   % (size, args.crf, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.aq_mode))
@@ -287,14 +329,15 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": what, "matches_baseline": False, "missing": missing,
                        "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
-                       "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint,
+                       "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint, "groups_per_gpu": G,
                        "per_chain_fps": round(fps / chains_total, 4),
                        "latency_note": "throughput exists only with thousands of streams in flight: one chain advances one frame per step",
-                       "slice_types_in_timed_steps": {k: round(v / max(total, 1), 4) for k, v in kinds.items()},
-                       "lookahead": {"cost_tasks_per_step_and_chain": round((enc.look.n_tasks_run - tasks0) / max(args.steps * B, 1), 3),
-                                     "cost_launch_rounds_per_step": round((enc.lb.rounds - rounds0) / max(args.steps, 1), 3), "slots": enc.n_slots, "delay": delay},
-                       "parallelism": "B streams per GPU; per step one chain-table launch per kernel kind (I / P and B chains side by side), one wavefront per chain walking its frame "
-                                      "in raster order; lookahead cost tasks one wavefront each; chains shard across GPUs with no data-path collective",
+                       "slice_types_in_timed_steps": {k: round(v / max(total, 1), 4) for k, v in ksum.items()},
+                       "lookahead": {"cost_tasks_per_step_and_chain": round(tasks / max(args.steps * B, 1), 3),
+                                     "cost_launch_rounds_per_step_and_group": round(rounds / max(args.steps * G, 1), 3), "slots": encs[0].n_slots, "delay": delay},
+                       "parallelism": "B streams per GPU in %d independently stepping groups (own stream and host thread each); per group and step one chain-table launch per kernel kind "
+                                      "(I / P and B chains side by side), one wavefront per chain walking its frame in raster order; lookahead cost tasks one wavefront each; chains "
+                                      "shard across GPUs with no data-path collective" % G,
                        "parity_checked_frames": checked,
                        "parity": ("chain 0 of rank 0, all %d coded frames of this run (%d of them timed): input order, slice types, QPs and payload bytes equal the reference's whole "
                                   "encoder (frame queue, slicetype decision, CRF, per-macroblock loop) run on the same pictures" % (checked, max(0, checked - args.warmup))) if checked else
@@ -303,15 +346,17 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "traffic_note": "no rocprofv3 PMC measurement committed for this configuration",
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
-                         "note": "one 'launch' = a step's chain-table launches together (the I / P kernel and the B kernel, back to back on the stream; HIP events around the pair); "
-                                 "the sweep is bound by the serial macroblock chain of a slice (%d macroblocks one after the other per frame, %d frames in flight), not by bandwidth; "
-                                 "whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (d.mb_w * d.mb_h, B, frame_bytes, frame_bytes * (fps / world) / 1e9)},
+                         "note": "one 'launch' = one group's chain-table launches of a step together (the I / P kernel and the B kernel, side by side on two streams; HIP events around "
+                                 "the pair), %d chains; %d groups overlap, so the launches' durations add up to more than the wall clock; the sweep is bound by the serial macroblock "
+                                 "chain of a slice (%d macroblocks one after the other per frame, %d frames in flight), not by bandwidth; whole-frame algorithmic bytes = %d -> %.1f GB/s at "
+                                 "this fps" % (sizes[0], G, d.mb_w * d.mb_h, B, frame_bytes, frame_bytes * (fps / world) / 1e9)},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    enc.close()
+    for e in encs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -355,6 +400,9 @@ def main():
                     "lowres motion candidates, every chain placing its own B frames and pricing its own frames (-1: 1 for the raster variant, 0 with --wavefront 1); "
                     "0: round 2's lock-step chains at constant QP with a fixed B pattern")
     ap.add_argument("--crf", type=float, default=23.0)
+    ap.add_argument("--groups", type=int, default=1, help="stream mode: independently stepping groups of chains per GPU (own stream and host thread each); measured: 1 is best -- "
+                    "the kernels are bound by each wavefront's own latency, so groups out of phase only slow one another (2048 chains: 428 frames/s in one group, 256 / 185 / 130 "
+                    "with 1536 chains in 2 / 3 / 4)")
     ap.add_argument("--b-adapt", type=int, default=1)
     ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold of the pre-encode scene cut (--pre-scenecut)")
     args = ap.parse_args()
@@ -368,7 +416,7 @@ def main():
     args.stream = (0 if wf else 1) if args.stream < 0 else args.stream
     if args.stream and wf:
         raise SystemExit("bench.py: --stream needs the raster variant")
-    args.batch = args.batch or (240 if wf else (384 if args.stream else 512) if uhd else (1536 if args.stream else 2048))
+    args.batch = args.batch or (240 if wf else 512 if uhd else 2048)
     args.subme = args.subme or (5 if wf else 7)
     args.keyint = args.keyint or (24 if wf else 250 if args.stream else 12)
     args.payload_cap = args.payload_cap or ((4 << 20) if uhd else (1 << 20))

@@ -199,7 +199,8 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
     coded0 = []                                          # chain 0's coded frames: (input number, slice type, qp)
     encs = [StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=sizes[j], crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut,
-                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, **analysis_options(args), **o) for j in range(G)]
+                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, n_frames=(delay + n_coded) if args.pipeline else None,
+                          **analysis_options(args), **o) for j in range(G)]
     d = encs[0].ctx.dims
     px = d.mb_w * 16 * d.lines_y
     kinds = [{"P": 0, "B": 0, "I": 0} for _ in range(G)]
@@ -209,7 +210,7 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     def one_step(j, timed):
         enc = encs[j]
         # group j's chain b is chain g_first + (offs[j] + b) * g_step of the job: its pictures start SEG frames after the previous chain's
-        out = enc.step(lambda pic, f: enc.ctx.synth(pic, (g_first + offs[j] * g_step) * SEG + f, g_step * SEG))
+        out = enc.step(lambda pic, f: enc.src_ctx.synth(pic, (g_first + offs[j] * g_step) * SEG + f, g_step * SEG))
         if out and check and j == 0:
             c0 = enc.coded_now[0]
             if c0 is not None and len(coded0) < n_coded:
@@ -369,7 +370,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="independent GOP chains advanced per step on each GPU; 0: 2048 (8 wavefronts on each of the 256 CUs) for the raster "
                     "variant (one wavefront per chain, all resident: what its LDS and registers allow), 512 with --preset uhd, 240 with --wavefront 1")
     ap.add_argument("--strong", type=int, default=0, help="1: --batch is the total number of chains of the job, spread round-robin over the ranks (strong scaling: total work fixed)")
-    ap.add_argument("--preset", default="hd", choices=["hd", "uhd"], help="hd: BASELINE config 1 (1920x1080, hex); uhd: config 2 (3840x2160, --me umh)")
+    ap.add_argument("--preset", default="hd", choices=["hd", "uhd", "slow"], help="hd: BASELINE config 1 (1920x1080, hex); uhd: config 2 (3840x2160, --me umh); slow: config 4's flag set on "
+                    "one GPU (1920x1080, --ref 5 --b-adapt 2 --me umh --subme 8, --direct spatial --pre-scenecut as BASELINE.md prescribes for sharded runs)")
     ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
     ap.add_argument("--trellis", type=int, default=1)
     ap.add_argument("--bframes", type=int, default=-1, help="disposable B frames between anchors, fixed pattern (-1: 3 for the raster variant = the medium "
@@ -400,6 +402,8 @@ def main():
                     "lowres motion candidates, every chain placing its own B frames and pricing its own frames (-1: 1 for the raster variant, 0 with --wavefront 1); "
                     "0: round 2's lock-step chains at constant QP with a fixed B pattern")
     ap.add_argument("--crf", type=float, default=23.0)
+    ap.add_argument("--pipeline", type=int, default=1, help="stream mode: 1: every step prepares the next step's lookahead (picture in, costs, decisions) beside its own sweep, on a stream "
+                    "of its own -- the lookahead's kernels and the host's work fill the time the step's P chains run on after its B chains; 0: one after the other")
     ap.add_argument("--groups", type=int, default=1, help="stream mode: independently stepping groups of chains per GPU (own stream and host thread each); measured: 1 is best -- "
                     "the kernels are bound by each wavefront's own latency, so groups out of phase only slow one another (2048 chains: 428 frames/s in one group, 256 / 185 / 130 "
                     "with 1536 chains in 2 / 3 / 4)")
@@ -407,16 +411,20 @@ def main():
     ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold of the pre-encode scene cut (--pre-scenecut)")
     args = ap.parse_args()
     wf = bool(args.wavefront)
-    uhd = args.preset == "uhd"
+    uhd, slow = args.preset == "uhd", args.preset == "slow"
+    if slow:
+        args.refs = 5 if args.refs == 3 else args.refs
+        args.b_adapt = 2 if args.b_adapt == 1 else args.b_adapt
+        args.subme = args.subme or 8
     args.width = args.width or (3840 if uhd else 1920)
     args.height = args.height or (2160 if uhd else 1080)
-    args.me = args.me if args.me >= 0 else (2 if uhd else 1)
+    args.me = args.me if args.me >= 0 else (2 if uhd or slow else 1)
     args.steps = args.steps or (24 if wf else 12)
     args.warmup = args.warmup if args.warmup >= 0 else (3 if wf else 2)
     args.stream = (0 if wf else 1) if args.stream < 0 else args.stream
     if args.stream and wf:
         raise SystemExit("bench.py: --stream needs the raster variant")
-    args.batch = args.batch or (240 if wf else 512 if uhd else 2048)
+    args.batch = args.batch or (240 if wf else 512 if uhd else 1024 if slow else 2048)
     args.subme = args.subme or (5 if wf else 7)
     args.keyint = args.keyint or (24 if wf else 250 if args.stream else 12)
     args.payload_cap = args.payload_cap or ((4 << 20) if uhd else (1 << 20))

@@ -12,7 +12,37 @@ def sweeps(db, what):
     return list(c.execute(what))
 
 
-if sys.argv[1] == "trace":
+if sys.argv[1] == "stream":
+    # the stream mode: per step the I / P table kernel and the B table kernel side by side on two streams, and the lookahead's cost kernels
+    db, bench, stats, out = sys.argv[2:6]
+    c = sqlite3.connect(db)
+    with open(stats, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for r in c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            w.writerow([r[0], r[1], int(r[2] * 1000) if r[2] < 1e9 else int(r[2]), round(r[3] * 1000, 1), round(r[4], 4)])
+    rows = list(c.execute("select start, end, name, grid_x from kernels where name like '%k_slice_sweep%' order by start"))
+    steps = []
+    for s_, e_, name, gx in rows:
+        kind = "B" if "ELb1ELb1ELb1ELb0ELb1EEv" in name else "IP"
+        if steps and s_ < steps[-1]["end"]:
+            steps[-1]["end"] = max(steps[-1]["end"], e_)
+        else:
+            steps.append({"start": s_, "end": e_, "kernels": []})
+        steps[-1]["kernels"].append({"kind": kind, "chains": gx // 64, "ms": round((e_ - s_) / 1e6, 3)})
+    b = json.loads(open(bench).read().strip().splitlines()[-1])
+    span = [round((s_["end"] - s_["start"]) / 1e6, 3) for s_ in steps]
+    timed = span[b["warmup"]:b["warmup"] + b["steps"]]
+    look = [round((e_ - s_) / 1e6, 3) for s_, e_ in c.execute("select start, end from kernels where name like '%k_look_cost%' order by start")]
+    json.dump({"what": "k_slice_sweep<raster, chain table> launches of `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu` (default options, stream mode) in step order: "
+                       "per step the I / P kernel and the B kernel run side by side on two streams; span_ms = first start to last end, which is what bench.py's HIP events "
+                       "bracket (plus the table's upload).  Warm-up steps first, then the timed ones.",
+               "steps": [{"span_ms": sp, "kernels": s_["kernels"]} for sp, s_ in zip(span, steps)],
+               "mean_timed_span_ms": round(sum(timed) / max(len(timed), 1), 3), "bench_json_avg_launch_ms": b["roofline"]["avg_launch_ms"], "bench_json_value": b["value"],
+               "k_look_cost_launches": len(look), "k_look_cost_total_ms": round(sum(look), 1), "k_look_cost_mean_ms": round(sum(look) / max(len(look), 1), 3)},
+              open(out, "w"), indent=1)
+    print("steps", len(steps), "mean timed span", sum(timed) / max(len(timed), 1), "bench", b["roofline"]["avg_launch_ms"], b["value"], "look", len(look), sum(look))
+elif sys.argv[1] == "trace":
     db, bench, stats, out = sys.argv[2:6]
     c = sqlite3.connect(db)
     with open(stats, "w", newline="") as f:

@@ -6,8 +6,12 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 acc = collections.defaultdict(dict)
-for did, cn, val, dur in c.execute("select dispatch_id, counter_name, sum(value), max(duration) from counters_collection "
-                                   "where kernel_name like '%k_slice_sweep%' group by dispatch_id, counter_name"):
+pat = sys.argv[2] if len(sys.argv) > 2 else "%k_slice_sweep%"
+for did, cn, val, dur, name, gx in c.execute("select dispatch_id, counter_name, sum(value), max(duration), max(kernel_name), max(grid_size_x) from counters_collection "
+                                             "where kernel_name like ? group by dispatch_id, counter_name", (pat,)):
     acc[did][cn] = val
     acc[did]["duration_ms"] = dur / 1e6
+    # which instantiation: ...ELb<BS>ELb<TD>ELb<RF>ELb<CH>EEv -- B kernels have BS = 1
+    acc[did]["kernel"] = "k_look_cost" if "look_cost" in name else ("B" if "ELb1ELb1ELb1ELb0ELb1EEv" in name or "ELb1ELb1ELb0ELb0" in name else "IP") + (" table" if name.endswith("ELb1EEv6SwArgs6SwRefs4SwRdPK6SwDesc") else "")
+    acc[did]["waves"] = gx // 64 if gx else None
 print(json.dumps([dict(dispatch=d, **acc[d]) for d in sorted(acc)], indent=1))

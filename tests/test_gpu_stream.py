@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
 
 
-def encoder_for(hip_lib, c, batch):
-    return StreamEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), batch=batch, crf=c["crf"], b_adapt=c["b_adapt"], bframe_bias=c["bframe_bias"],
+def encoder_for(hip_lib, c, batch, pipeline=False):
+    return StreamEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), batch=batch, n_frames=c["frames"] if pipeline else None, crf=c["crf"], b_adapt=c["b_adapt"], bframe_bias=c["bframe_bias"],
                          keyint_min=c["keyint_min"], scenecut_threshold=c["scenecut_threshold"], pre_scenecut=c["pre_scenecut"],
                          qp=c["qp"], me_method=c["me"], me_range=16, subme=c["subme"], n_refs=c.get("n_refs", 2), inter=c.get("inter", 0x33), intra=0x3,
                          transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"], mixed_refs=c.get("mixed_refs", 0), chroma_me=c.get("chroma_me", 1),
@@ -30,16 +30,17 @@ def encoder_for(hip_lib, c, batch):
                          weightb=c["weightb"], direct_pred=c.get("direct_pred", 1), qp_min=0)
 
 
-def run_stream(hip_lib, cs):
-    """cs: the chains' configurations (one encoder configuration, different clips).  Returns per chain [(frame, slice type, qp, payload)]."""
+def run_stream(hip_lib, cs, pipeline=False):
+    """cs: the chains' configurations (one encoder configuration, different clips).  Returns per chain [(frame, slice type, qp, payload)].
+    pipeline: the encoder is told how many pictures there are and prepares every next call's lookahead beside the sweep in flight."""
     c0, frames = cs[0], cs[0]["frames"]
     clips = [K.clip(c["w"], c["h"], frames, c["cut"], c["t0"], c["slow"]) for c in cs]
-    enc = encoder_for(hip_lib, c0, len(cs))
+    enc = encoder_for(hip_lib, c0, len(cs), pipeline)
     got = [[] for _ in cs]
 
     def fill(pic, f):
         for b, (y, u, v) in enumerate(clips):
-            enc.ctx.upload(pic, y[f], u[f], v[f], b=b)
+            enc.src_ctx.upload(pic, y[f], u[f], v[f], b=b)
 
     fed = 0
     for _ in range(4 * frames + 8):
@@ -86,11 +87,12 @@ def chains(name, seeds):
     return cs
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_stream_equals_reference_fixture(hip_lib, name):
+def test_stream_equals_reference_fixture(hip_lib, name, pipeline):
     gold = np.load(os.path.join(ROOT, "tests", "golden", "stream_%s.npz" % name))
     cs = chains(name, SEEDS[name])
-    got = run_stream(hip_lib, cs)
+    got = run_stream(hip_lib, cs, pipeline)
     for i, c in enumerate(cs):
         a = {k: gold["c%d_%s" % (i, k)] for k in ("frame_info", "frame_info2", "payload", "payload_len")}
         check(got[i], a, c, "%s chain %d" % (name, i))

@@ -371,9 +371,10 @@ extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sw
         HIPCHK(hipEventRecord(ax->ready, c->stream));
         HIPCHK(hipStreamWaitEvent(ax->stream, ax->ready, 0));
     }
-    if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], two ? ax->stream : c->stream);
+    // the I / P kernel first: its wavefronts -- the step's long ones -- are dealt evenly over the SIMDs before the B kernel's fill the rest
     if (cnt[SW_KIND_RD]) x264hip_launch_slice_rd_ch(tab + base[SW_KIND_RD], cnt[SW_KIND_RD], c->stream);
     if (cnt[SW_KIND_RF]) x264hip_launch_slice_rf_ch(tab + base[SW_KIND_RF], cnt[SW_KIND_RF], c->stream);
+    if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], two ? ax->stream : c->stream);
     if (two) {
         HIPCHK(hipEventRecord(ax->done, ax->stream));
         HIPCHK(hipStreamWaitEvent(c->stream, ax->done, 0));

@@ -1318,6 +1318,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
     const SwRd &rd = CH ? rd_l : rd_k;
     const SwRefs &refs = CH ? tab[blockIdx.x].t : refs_k;
+    // A step's I / P chains and B chains run side by side, and an I / P chain is the longer of the two (more references, more candidates):
+    // where a SIMD holds one of each, the I / P wavefront issues first, so that both kernels end at about the same time instead of
+    // the B chains' wave slots idling while the step waits for its P chains.
+    if constexpr (CH && !BS) __builtin_amdgcn_s_setprio(3);
     static_assert(!BS || RD, "B slices run in the raster variant");
     static_assert(!TD || BS, "temporal direct prediction is a B-slice matter");
     static_assert(!RF || (RD && !BS), "the RD refinement is built for the raster variant's I / P kernel");

@@ -245,18 +245,22 @@ class LookaheadBatch:
         lb.end(chains)        # those chains' frames are done
     """
 
-    def __init__(self, ctx, params, device, speculative=True):
+    def __init__(self, ctx, params, device, speculative=True, limits=None):
+        """limits: pictures per chain (None: unbounded) -- a chain whose stream is shorter stops taking pictures and flushes on its own."""
         self.ctx, self.dev, self.speculative = ctx, device, speculative
         self.chains = [Lookahead(ctx.lib, params) for _ in range(ctx.batch)]
         self.pending = [None] * ctx.batch
         self.rounds = 0
+        self.limits = list(limits) if limits is not None else None
+        self.fed = 0
 
     def put(self, fill):
-        frame = None
-        for la in self.chains:
-            f = la.put()
-            assert frame is None or f == frame
-            frame = f
+        frame = self.fed
+        for ci, la in enumerate(self.chains):
+            if self.limits is None or frame < self.limits[ci]:
+                f = la.put()
+                assert f == frame
+        self.fed += 1
         old = self.dev.frame_of_slot[self.dev.slot(frame)]
         assert old < 0 or old < self.oldest_live(), "lookahead ring of %d slots too small: input frame %d is still alive when %d arrives" % (self.dev.n_slots, old, frame)
         fill(self.dev.begin_frame(frame), frame)
@@ -269,7 +273,7 @@ class LookaheadBatch:
         while waiting:
             tasks, owners, still = [], [], []
             for ci in waiting:
-                kind, fr, needs = self.chains[ci].get(flushing, self.speculative)
+                kind, fr, needs = self.chains[ci].get(flushing or (self.limits is not None and self.fed >= self.limits[ci]), self.speculative)
                 if kind == NEED:
                     for (b, p0, p1, ds0, ds1, spec) in needs:
                         tasks.append((ci, b, p0, p1, ds0, ds1))

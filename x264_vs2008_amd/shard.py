@@ -78,6 +78,51 @@ def encode_clip(hip, cqm, frames, keyint, rank=0, world=1, **options):
     return out
 
 
+def encode_clip_stream(hip, cqm, frames, keyint, rank=0, world=1, **options):
+    """The same sharding with the whole encoder per GOP: `frames` is cut at every multiple of `keyint` and each piece is a stream of its
+    own through x264_vs2008_amd.stream.StreamEncoder -- its own lookahead (b-adapt, pre-encode scene cut), rate control (CRF or constant
+    QP) and B frames -- so every piece starts with an IDR and references nothing outside itself; this rank codes the pieces
+    gops_for_rank gives it, all of them in every launch.  Returns {gop_index: [(input number within the piece, slice type, qp, payload)]}
+    in coding order.  A piece's result is what the reference's encoder produces for that piece ALONE (tests/test_gpu_shard.py): the
+    lookahead and the rate control of a single long stream see across the cut, so the concatenation is a valid stream of closed GOPs
+    but not the single-process stream of the whole clip -- the price of coding GOPs side by side, the same in the reference when it is
+    run once per segment."""
+    from .stream import StreamEncoder
+    n = len(frames)
+    gops = gop_bounds(n, keyint)
+    mine = [i for i in range(len(gops)) if i % world == rank]
+    out = {g: [] for g in mine}
+    if not mine:
+        return out
+    h, w = frames[0][0].shape
+    lens = [gops[g][1] - gops[g][0] for g in mine]
+    options = dict(options)
+    options.setdefault("keyint", keyint)
+    enc = StreamEncoder(hip, w, h, cqm, batch=len(mine), limits=lens, **options)
+    try:
+        def fill(pic, f):
+            for b, g in enumerate(mine):            # a piece cut short by the end of the clip repeats its last picture; nobody reads it
+                y, u, v = frames[min(gops[g][0] + f, gops[g][1] - 1)]
+                enc.src_ctx.upload(pic, y, u, v, b=b)
+
+        fed, idle = 0, 0
+        while idle < 2:
+            coded = enc.step(fill if fed < max(lens) else None)
+            fed += fed < max(lens)
+            if coded:
+                idle = 0
+                enc.sync()
+                enc.status()
+                pay = enc.payloads()
+                for cd in coded:
+                    out[mine[cd.chain]].append((cd.frame, cd.slice_type, cd.qp, pay[cd.chain]))
+            elif fed >= max(lens):
+                idle += 1
+    finally:
+        enc.close()
+    return out
+
+
 def payload_digests(per_gop):
     """{gop_index: sha256 over the GOP's slice payloads (each preceded by its length)} -- what the ranks gather."""
     import hashlib
@@ -85,6 +130,9 @@ def payload_digests(per_gop):
     for g, pays in per_gop.items():
         hsh = hashlib.sha256()
         for p in pays:
+            if isinstance(p, tuple):                 # encode_clip_stream's records: the order and the decisions belong to the result
+                hsh.update(repr(p[:3]).encode())
+                p = p[3]
             hsh.update(len(p).to_bytes(4, "little"))
             hsh.update(p)
         d[g] = hsh.hexdigest()

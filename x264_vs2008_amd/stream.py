@@ -38,7 +38,7 @@ class Coded:
 
 class StreamEncoder(ChainEncoder):
     def __init__(self, lib, width, height, cqm, batch=1, crf=None, b_adapt=1, bframe_bias=0, keyint_min=0, scenecut_threshold=40, pre_scenecut=1,
-                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, **kw):
+                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, limits=None, n_frames=None, **kw):
         kw.setdefault("write", 1)
         kw.setdefault("levels", False)
         if kw.get("lanes"):
@@ -55,9 +55,17 @@ class StreamEncoder(ChainEncoder):
         bf = self.bopt["bframes"]
         delay = (max(bf, 3) * 4 if b_adapt == 2 and bf else bf)
         self.n_slots = n_slots or (delay + bf + 3)        # oldest live frame .. newest input spans at most delay + bframes + 2 (asserted when a slot is reused)
-        self.look = LA.LookaheadDevice(self.ctx, self.n_slots, bf, me_method=o["me_method"], me_range=o["me_range"], weightb=self.bopt["weightb"],
+        # The lookahead works on a stream of its own (same geometry, so its pictures are the sweep's sources): with n_frames given (how many
+        # pictures every chain will take) step() prepares the NEXT call's decisions right after launching this one's sweep, and the
+        # lookahead's kernels fill the wave slots the step's B chains leave when they finish ahead of its P chains.
+        from .frame import FrameCtx
+        self.src_ctx = FrameCtx(lib, width, height, batch=batch)
+        self.n_frames = n_frames
+        self._prep = None
+        self._coding = set()
+        self.look = LA.LookaheadDevice(self.src_ctx, self.n_slots, bf, me_method=o["me_method"], me_range=o["me_range"], weightb=self.bopt["weightb"],
                                        bframe_bias=bframe_bias, subme=o["subme"], lossless=self.lossless)
-        self.lb = LA.LookaheadBatch(self.ctx, self.la_params, self.look, speculative=speculative)
+        self.lb = LA.LookaheadBatch(self.src_ctx, self.la_params, self.look, speculative=speculative, limits=limits)
         B, n = batch, d.mb_w * d.mb_h
         # fenc->f_qp_offset of every slot (x264_adaptive_quant_frame runs when the picture comes in, encoder.c:1420-1421)
         self.aq_slots = None
@@ -79,20 +87,36 @@ class StreamEncoder(ChainEncoder):
         self.sweep_events = None       # set to [] to collect (start, stop, chains, algorithmic bytes) HIP events around every step's sweep launches
 
     # ---- one call of x264_encoder_encode for every chain --------------------------------------------------------------------------
-    def step(self, fill):
-        """fill(picture, frame): write input picture `frame` of every chain into `picture` (ctx.upload / ctx.synth); None: flush.
-        Returns the list of Coded for the chains that coded a frame (empty while the B buffer fills; empty for good once flushed)."""
-        L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
-        c.sync()                                        # the previous step's launches have read their tables / element lists
-        if fill is None:
+    def _prepare(self, fill):
+        """The lookahead's part of one x264_encoder_encode call for every chain: a picture comes in (or the flush begins), the queues decide.
+        Runs on the lookahead's stream; everything it launched has finished when it returns."""
+        more = fill is not None and (self.n_frames is None or self.lb.fed < self.n_frames)
+        if not more:
             self.flushing = True
         else:
-            frame = self.lb.put(lambda pic, f: self._fill(fill, pic, f))
+            # the slot the new picture takes must not be one a sweep still in flight reads (possible only when the ring is at its bound)
+            if self.look.frame_of_slot[self.look.slot(self.lb.fed)] in self._coding:
+                self.ctx.sync()
+            self.lb.put(lambda pic, f: self._fill(fill, pic, f))
         frames = self.lb.get(self.flushing)
+        self.src_ctx.sync()
+        return frames
+
+    def step(self, fill):
+        """fill(picture, frame): write input picture `frame` of every chain into `picture` (enc.src_ctx.upload / .synth); None: flush.
+        Returns the list of Coded for the chains that coded a frame (empty while the B buffer fills; empty for good once flushed).
+        With n_frames given to the constructor the next call's lookahead is prepared before this one returns (fill is then also asked
+        for the following picture) and the flush starts by itself after n_frames pictures."""
+        L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
+        frames = self._prep if self._prep is not None else self._prepare(fill)
+        self._prep = None
         B = c.batch
         self.coded_now = [None] * B
         todo = [(ci, fr) for ci, fr in enumerate(frames) if fr is not None]
         if not todo:
+            self._coding = set()
+            if self.n_frames is not None and not self.flushing:
+                self._prep = self._prepare(fill)
             return []
         keep = []                                       # everything the C call reads must outlive it
         entries = (ChainSweep * len(todo))()
@@ -148,9 +172,7 @@ class StreamEncoder(ChainEncoder):
             keep += [arr, mine]
             entries[k] = ChainSweep(ci, C.addressof(self.look.pics[slot]), C.cast(arr, C.c_void_p) if arr else None, len(refs), C.addressof(recon),
                                     C.addressof(p), C.addressof(refs[0][2]) if refs else None, C.addressof(mine))
-            if pic_i not in written:
-                written.add(pic_i)
-                c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(state.st)), "mb_state_clear_progress")
+            written.add(pic_i)
             cd = Coded()
             cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
             cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
@@ -160,6 +182,9 @@ class StreamEncoder(ChainEncoder):
                 filt.setdefault(pic_i, []).append(ci)
                 self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
             self.c_coded[ci] += 1
+        c.sync()                                        # the previous step's sweep and filters are done: their tables, element lists and pictures are free
+        for pic_i in written:
+            c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
         ev = None
         if self.sweep_events is not None:
             ev = (L.x264hip_event_create(), L.x264hip_event_create())
@@ -193,12 +218,15 @@ class StreamEncoder(ChainEncoder):
         self._keep = keep
         self.lb.end([ci for ci, _ in todo])
         self.last_bufs, self.last_ctx = rb, c
+        self._coding = {cd.frame for cd in out}
+        if self.n_frames is not None and not self.flushing:
+            self._prep = self._prepare(fill)            # beside the sweep just launched
         return out
 
     def _fill(self, fill, pic, frame):
         fill(pic, frame)
         if self.aq_slots:
-            c, L, ro = self.ctx, self.lib, self.rd_opt
+            c, L, ro = self.src_ctx, self.lib, self.rd_opt
             en, off = self.aq_slots[self.look.slot(frame)]
             L.x264hip_adaptive_quant_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
             c.check(L.x264hip_adaptive_quant_frame(c.h, C.byref(pic), C.c_float(ro["aq_strength"]), en.p, off.p), "adaptive_quant_frame")
@@ -214,6 +242,8 @@ class StreamEncoder(ChainEncoder):
             c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(s.st)), "slice_sweep_status")
 
     def close(self):
+        self.sync()
+        self.src_ctx.sync()
         self.lb.close()
         self.look.close()
         for pair in self.aq_slots or []:
@@ -225,3 +255,4 @@ class StreamEncoder(ChainEncoder):
             self.lib.x264hip_host_free(C.c_void_p(self.tab_host))
             self.tab_host = None
         super().close()
+        self.src_ctx.close()

@@ -68,6 +68,44 @@ def check(got, a, c, what):
         assert payload == want, "%s coded frame %d (input %d, slice %d, qp %d): payload differs (%d vs %d bytes)" % (what, f, frame, st, qp, len(payload), len(want))
 
 
+def run_async(hip_lib, cs, launches=3, drift=2):
+    """The same through the AsyncStreamEncoder: every chain's frames as its own kernels finish.  Returns per chain [(frame, slice type, qp, payload)]."""
+    import ctypes as C
+    from x264_vs2008_amd.stream import AsyncStreamEncoder
+    c0, frames = cs[0], cs[0]["frames"]
+    clips = [K.clip(c["w"], c["h"], frames, c["cut"], c["t0"], c["slow"]) for c in cs]
+    c = c0
+    enc = AsyncStreamEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), batch=len(cs), n_frames=frames, launches=launches, drift=drift, crf=c["crf"],
+                             b_adapt=c["b_adapt"], bframe_bias=c["bframe_bias"], keyint_min=c["keyint_min"], scenecut_threshold=c["scenecut_threshold"],
+                             pre_scenecut=c["pre_scenecut"], qp=c["qp"], me_method=c["me"], me_range=16, subme=c["subme"], n_refs=c.get("n_refs", 2),
+                             inter=c.get("inter", 0x33), intra=0x3, transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"], mixed_refs=c.get("mixed_refs", 0),
+                             chroma_me=c.get("chroma_me", 1), trellis=c.get("trellis", 0), psy_rd=c.get("psy_rd", 0.0), aq_mode=c["aq"], aq_strength=1.0,
+                             bframes=c["bframes"], weightb=c["weightb"], direct_pred=c.get("direct_pred", 1), qp_min=0)
+    cap = min(1 << 16, enc.payload_cap - 64)          # (PAYLOAD_LEAD bytes of every chain's slot precede the payload)
+    hip_lib.x264hip_host_alloc.restype = C.c_void_p
+    pin = hip_lib.x264hip_host_alloc(C.c_size_t(len(cs) * frames * (cap + 64)))
+    recs = [[] for _ in cs]
+
+    def fill(pic, f):
+        for b, (y, u, v) in enumerate(clips):
+            enc.src_ctx.upload(pic, y[f], u[f], v[f], b=b)
+
+    def on_launch(coded, ctx, ev_b):
+        for cd in coded:
+            k = len(recs[cd.chain])
+            base = pin + (cd.chain * frames + k) * (cap + 64)
+            enc.payload_async_of(cd, k, ctx, ev_b, base, base + 64, cap)
+            recs[cd.chain].append((cd.frame, cd.slice_type, cd.qp, base))
+
+    enc.run(fill, on_launch)
+    enc.status()
+    got = [[(f, st, qp, C.string_at(base + 64, C.c_int32.from_address(base).value)) for f, st, qp, base in r] for r in recs]
+    sizes = list(enc.launch_sizes)
+    enc.close()
+    hip_lib.x264hip_host_free(C.c_void_p(pin))
+    return got, sizes
+
+
 CONFIGS = {
     "badapt1_crf_aq": dict(w=128, h=96, frames=14, bframes=3, b_adapt=1, crf=23.0, subme=5, me=1, weightb=1, aq=1, n_refs=2),
     "badapt2_crf_rd": dict(w=112, h=96, frames=13, bframes=2, b_adapt=2, crf=28.0, subme=7, me=2, weightb=0, aq=0, n_refs=3, mixed_refs=1, trellis=1, inter=0x13),
@@ -96,6 +134,18 @@ def test_stream_equals_reference_fixture(hip_lib, name, pipeline):
     for i, c in enumerate(cs):
         a = {k: gold["c%d_%s" % (i, k)] for k in ("frame_info", "frame_info2", "payload", "payload_len")}
         check(got[i], a, c, "%s chain %d" % (name, i))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_async_stream_equals_reference_fixture(hip_lib, name):
+    """Chains stepping on their own (AsyncStreamEncoder): each chain's frames, in its coding order, are the lock-step encoder's and the reference's."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "stream_%s.npz" % name))
+    cs = chains(name, SEEDS[name])
+    got, sizes = run_async(hip_lib, cs)
+    for i, c in enumerate(cs):
+        a = {k: gold["c%d_%s" % (i, k)] for k in ("frame_info", "frame_info2", "payload", "payload_len")}
+        check(got[i], a, c, "%s chain %d (async)" % (name, i))
+    assert sum(sizes) == len(cs) * cs[0]["frames"]
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")

@@ -385,11 +385,15 @@ extern "C" int x264hip_picture_upload(x264hip_frame_ctx *c, x264hip_picture *pic
         int w = d.width >> !!i, h = d.height >> !!i, st = i ? d.stride_c : d.stride_y;
         u8 *dst = pic->plane[i] + (i ? c->bs_c : c->bs_y) * c->sel;
         HIPCHK(hipMemcpy2DAsync(dst, st, src[i], ss[i], w, h, hipMemcpyHostToDevice, c->stream));
+        // (a copy from pageable memory may leave hipErrorInvalidValue as the thread's "last error" although it returns success -- the
+        // runtime's own look-up of the host pointer; seen on ROCm 7.2 -- so the launch check below must not read what the copy left)
+        (void)hipGetLastError();
         int w16 = c->width16 >> !!i, h16 = c->lines16 >> !!i;
-        if (w16 != w || h16 != h)
+        if (w16 != w || h16 != h) {
             hipLaunchKernelGGL(k_pad_mod16, dim3((w16 + 255) / 256, h16), dim3(256), 0, c->stream, dst, st, w, h, w16, h16);
+            HIPCHK(hipGetLastError());
+        }
     }
-    HIPCHK(hipGetLastError());
     // the caller owns y/u/v and may release them on return (they are usually
     // pageable): do not leave a DMA reading them in flight
     HIPCHK(hipStreamSynchronize(c->stream));

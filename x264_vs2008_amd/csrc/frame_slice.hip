@@ -327,7 +327,21 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
 
 struct ChainAux { hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done = nullptr; };
 // The chain-table launch: every entry is a sweep of ONE chain (batch element) with its own pictures, states and slice parameters.
+static int sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev, void *ev_ip, void *ev_b, bool join);
 extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev)
+{
+    return sweep_chains(c, e, n, staging_host, table_dev, nullptr, nullptr, true);
+}
+// The same with the two kinds' completion visible to the caller: ev_ip is recorded behind the I / P kernels on the context's stream, ev_b
+// behind the B kernel on its own stream, and the context's stream does NOT wait for the B kernel (a disposable B frame has no end-of-frame
+// work: what follows on the context's stream -- the filters of the kept frames -- concerns other chains).  For a scheduler that hands
+// every chain its next frame as soon as its own kernel is done.
+extern "C" int x264hip_slice_sweep_chains_events(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev, void *ev_ip, void *ev_b)
+{
+    if (!ev_ip || !ev_b) { set_error("slice_sweep_chains_events: events missing"); return -1; }
+    return sweep_chains(c, e, n, staging_host, table_dev, ev_ip, ev_b, false);
+}
+static int sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev, void *ev_ip, void *ev_b, bool join)
 {
     if (n <= 0) return 0;
     if (!staging_host || !table_dev) { set_error("slice_sweep_chains: staging / table buffers missing"); return -1; }
@@ -356,7 +370,7 @@ extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sw
     const SwDesc *tab = (const SwDesc *)table_dev;
     // The I / P chains and the B chains of a step are different chains: their kernels run side by side, the B kernel on a stream of its
     // own between two events (behind the table's upload, ahead of whatever follows on the context's stream).
-    const bool two = cnt[SW_KIND_BT] && (cnt[SW_KIND_RD] || cnt[SW_KIND_RF]);
+    const bool two = cnt[SW_KIND_BT] && (cnt[SW_KIND_RD] || cnt[SW_KIND_RF] || !join);
     static std::mutex mu;
     static std::unordered_map<x264hip_frame_ctx *, ChainAux> aux_of;
     ChainAux *ax = nullptr;
@@ -375,10 +389,12 @@ extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sw
     if (cnt[SW_KIND_RD]) x264hip_launch_slice_rd_ch(tab + base[SW_KIND_RD], cnt[SW_KIND_RD], c->stream);
     if (cnt[SW_KIND_RF]) x264hip_launch_slice_rf_ch(tab + base[SW_KIND_RF], cnt[SW_KIND_RF], c->stream);
     if (cnt[SW_KIND_BT]) x264hip_launch_slice_bt_ch(tab + base[SW_KIND_BT], cnt[SW_KIND_BT], two ? ax->stream : c->stream);
-    if (two) {
+    if (two && join) {
         HIPCHK(hipEventRecord(ax->done, ax->stream));
         HIPCHK(hipStreamWaitEvent(c->stream, ax->done, 0));
     }
+    if (ev_ip) HIPCHK(hipEventRecord((hipEvent_t)ev_ip, c->stream));
+    if (ev_b) HIPCHK(hipEventRecord((hipEvent_t)ev_b, two ? ax->stream : c->stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

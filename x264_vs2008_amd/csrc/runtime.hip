@@ -256,6 +256,15 @@ extern "C" int x264hip_memcpy_h2d_async(void *dst_dev, const void *src_host, siz
     HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     return 0;
 }
+// 1: everything the event recorded has finished, 0: not yet, < 0: error (include/x264hip_lookahead.h)
+extern "C" int x264hip_event_query(void *ev)
+{
+    hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }      // "not ready" must not stay behind as the thread's last error
+    set_error("hipEventQuery: %s", hipGetErrorString(e));
+    return -1;
+}
 extern "C" int x264hip_mem_info(size_t *free_bytes, size_t *total_bytes)
 {
     HIPCHK(hipMemGetInfo(free_bytes, total_bytes));

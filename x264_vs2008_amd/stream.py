@@ -125,63 +125,11 @@ class StreamEncoder(ChainEncoder):
         written, filt = set(), {}
         out = []
         for k, (ci, fr) in enumerate(todo):
-            idr = fr.type == LA.TYPE_IDR
-            stype = SLICE_I if fr.type in (LA.TYPE_IDR, LA.TYPE_I) else SLICE_B if fr.type == LA.TYPE_B else SLICE_P
-            if idr:
-                self.crefs[ci], self.c_last_idr[ci] = [], fr.frame
-            refs_all = self.crefs[ci]
-            poc = fr.poc
-            used = {r[0] for r in refs_all}
-            pic_i = next(i for i in range(len(self.pool)) if i not in used)
-            recon, state = self.pool[pic_i], self.states[pic_i]
-            refs = sorted([r for r in refs_all if r[1] < poc], key=lambda r: -r[1])[:o["n_refs"]] if stype != SLICE_I else []
-            refs1 = sorted([r for r in refs_all if r[1] > poc], key=lambda r: r[1])[:1] if stype == SLICE_B else []
-            qp = fr.qp
-            slot = self.look.slot(fr.frame)
-            assert self.look.frame_of_slot[slot] == fr.frame, "input frame %d left its lookahead slot before it was coded (n_slots too small)" % fr.frame
-            lw0 = lw1 = None
-            n = self.look.n
-            if stype != SLICE_I and fr.lowres_l0:     # the kernel adds the chain's offset in an [batch][n_mb][2] array to the pointer it is given
-                lw0 = self.look.mv_ptr(ci, fr.frame, 0, fr.frame - fr.ref0_frame) - 4 * n * ci
-            if stype == SLICE_B and fr.lowres_l1:
-                lw1 = self.look.mv_ptr(ci, fr.frame, 1, fr.ref1_frame - fr.frame) - 4 * n * ci
-            p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
-                            subme=o["subme"], chroma_me=o["chroma_me"], mv_range=o["mv_range"] or 512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
-                            cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
-                            quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
-                            quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
-                            cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
-                            noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless,
-                            lowres_mv=lw0)
-            rd = SliceRd(trellis=ro["trellis"], psy_rd=self.psy_rd_fix, write=1, cabac_init_idc=ro["cabac_init_idc"], i_frame=self.c_coded[ci],
-                         qp_min=ro["qp_min"], qp_max=ro["qp_max"], f_qpm=fr.f_qpm, aq_offset=self.aq_slots[slot][1].ptr if self.aq_slots else None,
-                         cost_mv_all=rb["cost_mv_all"].ptr, unquant4_mf=rb["unquant4_mf"].ptr, unquant8_mf=rb["unquant8_mf"].ptr,
-                         payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
-                         stale=rb["stale"].ptr, i_frame_stride=0)
-            p.rd = C.addressof(rd)
-            keep += [p, rd]
-            if stype == SLICE_B:
-                sb = SliceB(fref1=C.addressof(self.pool[refs1[0][0]]), l1_state=C.addressof(refs1[0][2]), ref1_poc=refs1[0][1],
-                            weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"], lowres_mv1=lw1)
-                p.b = C.addressof(sb)
-                keep.append(sb)
-            for i, r in enumerate(refs):
-                p.ref_poc[i] = r[1]
-            arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(self.pool[r[0]]) for r in refs]) if refs else None
-            mine = MbState.from_buffer_copy(state.st)        # this chain's view of the state: the device arrays + its own frame-level scalars
-            keep += [arr, mine]
-            entries[k] = ChainSweep(ci, C.addressof(self.look.pics[slot]), C.cast(arr, C.c_void_p) if arr else None, len(refs), C.addressof(recon),
-                                    C.addressof(p), C.addressof(refs[0][2]) if refs else None, C.addressof(mine))
+            entries[k], cd, pic_i = self._entry(ci, fr, keep)
             written.add(pic_i)
-            cd = Coded()
-            cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
-            cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
             out.append(cd)
-            self.coded_now[ci] = cd
-            if stype != SLICE_B:                           # kept: filtered below, then this chain's newest reference
+            if cd.slice_type != SLICE_B:                   # kept: filtered below
                 filt.setdefault(pic_i, []).append(ci)
-                self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
-            self.c_coded[ci] += 1
         c.sync()                                        # the previous step's sweep and filters are done: their tables, element lists and pictures are free
         for pic_i in written:
             c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
@@ -223,6 +171,70 @@ class StreamEncoder(ChainEncoder):
             self._prep = self._prepare(fill)            # beside the sweep just launched
         return out
 
+    def _entry(self, ci, fr, keep):
+        """One chain's sweep for the frame its queue handed it: the x264hip_chain_sweep record (whatever it points at goes into `keep`), the
+        chain's DPB bookkeeping (x264_reference_build_list before, x264_reference_update after), the Coded record, the pool picture written."""
+        o, ro, b, rb = self.opt, self.rd_opt, self.cqm.bufs, self._bufs_of(ci)
+        idr = fr.type == LA.TYPE_IDR
+        stype = SLICE_I if fr.type in (LA.TYPE_IDR, LA.TYPE_I) else SLICE_B if fr.type == LA.TYPE_B else SLICE_P
+        if idr:
+            self.crefs[ci], self.c_last_idr[ci] = [], fr.frame
+        refs_all = self.crefs[ci]
+        poc = fr.poc
+        used = {r[0] for r in refs_all}
+        pic_i = next(i for i in range(len(self.pool)) if i not in used)
+        recon, state = self.pool[pic_i], self.states[pic_i]
+        refs = sorted([r for r in refs_all if r[1] < poc], key=lambda r: -r[1])[:o["n_refs"]] if stype != SLICE_I else []
+        refs1 = sorted([r for r in refs_all if r[1] > poc], key=lambda r: r[1])[:1] if stype == SLICE_B else []
+        qp = fr.qp
+        slot = self.look.slot(fr.frame)
+        assert self.look.frame_of_slot[slot] == fr.frame, "input frame %d left its lookahead slot before it was coded (n_slots too small)" % fr.frame
+        lw0 = lw1 = None
+        n = self.look.n
+        if stype != SLICE_I and fr.lowres_l0:     # the kernel adds the chain's offset in an [batch][n_mb][2] array to the pointer it is given
+            lw0 = self.look.mv_ptr(ci, fr.frame, 0, fr.frame - fr.ref0_frame) - 4 * n * ci
+        if stype == SLICE_B and fr.lowres_l1:
+            lw1 = self.look.mv_ptr(ci, fr.frame, 1, fr.ref1_frame - fr.frame) - 4 * n * ci
+        p = SliceParams(slice_type=stype, qp=qp, chroma_qp_offset=o["chroma_qp_offset"], me_method=o["me_method"], me_range=o["me_range"],
+                        subme=o["subme"], chroma_me=o["chroma_me"], mv_range=o["mv_range"] or 512, fast_pskip=o["fast_pskip"], dct_decimate=o["dct_decimate"],
+                        cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
+                        quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
+                        quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
+                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
+                        noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless,
+                        lowres_mv=lw0)
+        rd = SliceRd(trellis=ro["trellis"], psy_rd=self.psy_rd_fix, write=1, cabac_init_idc=ro["cabac_init_idc"], i_frame=self.c_coded[ci],
+                     qp_min=ro["qp_min"], qp_max=ro["qp_max"], f_qpm=fr.f_qpm, aq_offset=self.aq_slots[slot][1].ptr if self.aq_slots else None,
+                     cost_mv_all=rb["cost_mv_all"].ptr, unquant4_mf=rb["unquant4_mf"].ptr, unquant8_mf=rb["unquant8_mf"].ptr,
+                     payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
+                     stale=rb["stale"].ptr, i_frame_stride=0)
+        p.rd = C.addressof(rd)
+        keep += [p, rd]
+        if stype == SLICE_B:
+            sb = SliceB(fref1=C.addressof(self.pool[refs1[0][0]]), l1_state=C.addressof(refs1[0][2]), ref1_poc=refs1[0][1],
+                        weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"], lowres_mv1=lw1)
+            p.b = C.addressof(sb)
+            keep.append(sb)
+        for i, r in enumerate(refs):
+            p.ref_poc[i] = r[1]
+        arr = (C.c_void_p * max(len(refs), 1))(*[C.addressof(self.pool[r[0]]) for r in refs]) if refs else None
+        mine = MbState.from_buffer_copy(state.st)        # this chain's view of the state: the device arrays + its own frame-level scalars
+        keep += [arr, mine]
+        entry = ChainSweep(ci, C.addressof(self.look.pics[slot]), C.cast(arr, C.c_void_p) if arr else None, len(refs), C.addressof(recon),
+                                C.addressof(p), C.addressof(refs[0][2]) if refs else None, C.addressof(mine))
+        cd = Coded()
+        cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
+        cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
+        self.coded_now[ci] = cd
+        if stype != SLICE_B:                           # kept: filtered below, then this chain's newest reference
+            self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
+        self.c_coded[ci] += 1
+        return entry, cd, pic_i
+
+    def _bufs_of(self, ci):
+        """The buffers the chain's next frame writes (AsyncStreamEncoder alternates two sets per chain)."""
+        return self.rd_bufs
+
     def _fill(self, fill, pic, frame):
         fill(pic, frame)
         if self.aq_slots:
@@ -256,3 +268,248 @@ class StreamEncoder(ChainEncoder):
             self.tab_host = None
         super().close()
         self.src_ctx.close()
+
+
+class AsyncStreamEncoder(StreamEncoder):
+    """The same streams without the step: every chain gets its next frame as soon as ITS OWN kernel is done.
+
+    In StreamEncoder a step ends when its slowest chain does; a P chain's frame takes about twice as long as a B chain's, so the wave slots
+    of the B chains idle for the rest of every step.  Here a host scheduler polls the completion of the I / P kernel and of the B kernel of
+    every launch in flight (x264hip_slice_sweep_chains_events, x264hip_event_query), asks the freed chains' queues for their next frames
+    (batching the lookahead's cost requests over them) and launches those at once, on one of a small ring of contexts (streams) -- so
+    launches of different "ages" overlap and the device stays full.  Chains therefore drift apart: a picture is prepared for ALL chains
+    (lowres planes, intra costs, AQ) when the first chain needs it, and the slot ring is `drift` pictures longer; a chain that would run
+    further ahead than the ring allows waits.  The results per chain are exactly StreamEncoder's (tests/test_gpu_stream.py).
+
+        enc = AsyncStreamEncoder(lib, w, h, cqm, batch=B, n_frames=N, ...)
+        enc.run(fill, on_launch)      # codes N frames of every chain; on_launch(coded, stream) after every launch (e.g. to enqueue a
+                                      # payload copy behind it: a chain's payload buffer is reused by its next frame)
+    """
+
+    def __init__(self, lib, width, height, cqm, batch=1, n_frames=None, drift=2, launches=8, **kw):
+        if n_frames is None:
+            raise ValueError("AsyncStreamEncoder: n_frames (pictures per chain) is needed")
+        if kw.get("noise_reduction"):
+            raise ValueError("AsyncStreamEncoder: --nr updates its tables once per frame for all chains together: lock-step only")
+        if kw.get("direct_pred", 1) == 2:
+            pass                                         # temporal direct: x264hip_slice_rd.stale is per chain, frames of a chain stay in order
+        bf = kw.get("bframes", 0)
+        b_adapt = kw.get("b_adapt", 1)
+        delay = (max(bf, 3) * 4 if b_adapt == 2 and bf else bf)
+        kw.setdefault("n_slots", delay + bf + 3 + drift)
+        super().__init__(lib, width, height, cqm, batch=batch, n_frames=None, **kw)
+        from .frame import FrameCtx
+        self.total, self.delay, self.drift = n_frames, delay, drift
+        B = batch
+        lib.x264hip_host_alloc.restype = C.c_void_p
+        lib.x264hip_event_create.restype = C.c_void_p
+        tb = lib.x264hip_chain_sweep_bytes()
+        self.lctx = []
+        for _ in range(launches):
+            lc = FrameCtx(lib, width, height, batch=B)
+            # (element lists in pinned host memory, read by the filter kernels in place: with the device kept full, even a tiny upload's copy
+            # kernel would wait for a wave slot)
+            self.lctx.append(dict(ctx=lc, tab_host=lib.x264hip_host_alloc(C.c_size_t(tb * B)), tab_dev=DeviceArray(lib, (tb * B,), np.uint8),
+                                  elems=[lib.x264hip_host_alloc(C.c_size_t(4 * B)) for _ in range(len(self.pool))],
+                                  ev_ip=lib.x264hip_event_create(), ev_b=lib.x264hip_event_create(), busy=False, ip=[], b=[], keep=None))
+        # a chain's next frame may be launched while the copy of its previous payload is still queued: two sets of what a frame writes
+        d = self.ctx.dims
+        alt = self._frame_bufs(B, d.mb_w * d.mb_h, self.payload_cap, 0)
+        self.rd_bufs_alt = dict(self.rd_bufs, **alt)
+        self._alt_only = alt
+        self.las = self.lb.chains                        # one host state machine per chain (the batch object's lock-step driver is not used)
+        self.fed = [0] * B
+        self.ncoded = [0] * B
+        self.inflight_frame = [-1] * B
+        self.prepared = 0                                # pictures prepared on the device (for all chains)
+        self.n_launches = 0
+        self.launch_sizes = []
+
+    def _bufs_of(self, ci):
+        return self.rd_bufs_alt if self.c_coded[ci] & 1 else self.rd_bufs
+
+    def payload_bufs(self, cd_index, ci):
+        """The buffer set chain ci's frame number cd_index (0-based, coding order) was written to."""
+        return self.rd_bufs_alt if cd_index & 1 else self.rd_bufs
+
+    def payload_async_of(self, cd, index, c, ev_b, host_len, host_buf, nbytes):
+        """From on_launch: enqueue, behind the frame `cd` (its chain's frame number `index`) of the launch on context c, the copy of its payload
+        length and first nbytes payload bytes into pinned host memory; valid once c's stream has passed this point (run() returns after that)."""
+        from .slice import PAYLOAD_LEAD
+        rb = self.payload_bufs(index, cd.chain)
+        st = C.c_void_p(c.stream)
+        if cd.slice_type == SLICE_B:                     # the B kernel runs on the library's second stream of this context
+            self.lib.x264hip_stream_wait_event(st, C.c_void_p(ev_b))
+        self.lib.x264hip_memcpy_d2h_async(C.c_void_p(host_len), C.c_void_p(rb["payload_len"].ptr + 4 * cd.chain), C.c_size_t(4), st)
+        self.lib.x264hip_memcpy_d2h_async(C.c_void_p(host_buf), C.c_void_p(rb["payload"].ptr + self.payload_cap * cd.chain + PAYLOAD_LEAD), C.c_size_t(nbytes), st)
+
+    # -- pictures --------------------------------------------------------------------------------------------------------------------
+    def _oldest_needed(self):
+        m = self.prepared
+        for ci, la in enumerate(self.las):
+            if self.ncoded[ci] < self.total:
+                m = min(m, la.oldest_live() if self.fed[ci] else 0)
+                if self.inflight_frame[ci] >= 0:
+                    m = min(m, self.inflight_frame[ci])
+        return m
+
+    def _prepare_picture(self, fill):
+        """Picture number self.prepared for every chain: source, lowres planes, intra costs, AQ offsets.  False: its slot is still in use."""
+        f = self.prepared
+        if f >= self.total or f - self._oldest >= self.n_slots:
+            return False
+        pic = self.look.begin_frame(f)
+        self._fill(fill, pic, f)
+        self.look.prepare(f)
+        self.prepared += 1
+        return True
+
+    # -- the scheduler ---------------------------------------------------------------------------------------------------------------
+    def run(self, fill, on_launch=None, poll_s=0.002):
+        import time
+        L, B = self.lib, self.ctx.batch
+        ready = set(range(B))
+        done = 0
+        self.coded_all = [[] for _ in range(B)]
+        while done < B:
+            # 1. completions: the B kernel and the I / P kernel (+ its filters) of every launch in flight, separately
+            progressed = False
+            for lc in self.lctx:
+                if not lc["busy"]:
+                    continue
+                if lc["b"] and L.x264hip_event_query(C.c_void_p(lc["ev_b"])) == 1:
+                    ready.update(lc["b"]); lc["b"] = []; progressed = True
+                if lc["ip"] and L.x264hip_event_query(C.c_void_p(lc["ev_ip"])) == 1:
+                    ready.update(lc["ip"]); lc["ip"] = []; progressed = True
+                if not lc["b"] and not lc["ip"] and L.x264hip_event_query(C.c_void_p(lc["ev_b"])) == 1 and L.x264hip_event_query(C.c_void_p(lc["ev_ip"])) == 1:
+                    lc["busy"], lc["keep"] = False, None
+            for ci in list(ready):
+                if self.inflight_frame[ci] >= 0:
+                    self.inflight_frame[ci] = -1
+            free = [lc for lc in self.lctx if not lc["busy"]]
+            if not ready or not free:
+                if not progressed:
+                    time.sleep(poll_s)
+                continue
+            # 2. every ready chain takes the pictures x264_encoder_encode would have been given by now (call j = ncoded + delay gets picture j)
+            cand = []
+            self._oldest = self._oldest_needed()
+            for ci in sorted(ready):
+                if self.ncoded[ci] >= self.total:
+                    ready.discard(ci)
+                    continue
+                want = min(self.total, self.ncoded[ci] + self.delay + 1)
+                ok = True
+                while self.fed[ci] < want:
+                    if self.fed[ci] >= self.prepared and not self._prepare_picture(fill):
+                        ok = False                       # the ring is full: this chain is too far ahead of the slowest one, it waits
+                        break
+                    assert self.las[ci].put() == self.fed[ci]
+                    self.fed[ci] += 1
+                if ok:
+                    cand.append(ci)
+            # 3. their queues decide; the costs they ask for are computed together
+            frames, waiting = {}, cand
+            while waiting:
+                tasks, specs, still = [], [], []
+                for ci in waiting:
+                    kind, fr, needs = self.las[ci].get(self.fed[ci] >= self.total, self.lb.speculative)
+                    if kind == LA.NEED:
+                        for (b, p0, p1, ds0, ds1, spec) in needs:
+                            tasks.append((ci, b, p0, p1, ds0, ds1)); specs.append(spec)
+                        still.append(ci)
+                    elif kind == LA.FRAME:
+                        frames[ci] = fr
+                    elif kind == LA.END:
+                        ready.discard(ci)
+                    else:
+                        raise RuntimeError("AsyncStreamEncoder: chain %d has no frame although %d pictures are in" % (ci, self.fed[ci]))
+                if tasks:
+                    res = self.look.run(tasks)
+                    self.lb.rounds += 1
+                    for (ci, b, p0, p1, ds0, ds1), spec, r in zip(tasks, specs, res):
+                        self.las[ci].set_cost(b, p0, p1, int(r[0]), int(r[1]), int(r[2]), spec)
+                waiting = still
+            if not frames:
+                if not progressed:
+                    time.sleep(poll_s)
+                continue
+            self.src_ctx.sync()                          # the pictures and vectors the sweeps read are in place
+            # 4. one launch for all of them
+            lc = free[0]
+            c = lc["ctx"]
+            keep, written, filt, out = [], set(), {}, []
+            entries = (ChainSweep * len(frames))()
+            for k, (ci, fr) in enumerate(sorted(frames.items())):
+                entries[k], cd, pic_i = self._entry(ci, fr, keep)
+                written.add(pic_i)
+                out.append(cd)
+                if cd.slice_type != SLICE_B:
+                    filt.setdefault(pic_i, []).append(ci)
+                self.inflight_frame[ci] = fr.frame
+                self.ncoded[ci] += 1
+                self.coded_all[ci].append(cd)
+                ready.discard(ci)
+                if self.ncoded[ci] >= self.total:
+                    done += 1
+            for pic_i in written:
+                c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
+            for pic_i, chains in filt.items():
+                np.ctypeslib.as_array(C.cast(lc["elems"][pic_i], C.POINTER(C.c_int32)), (B,))[:len(chains)] = chains
+            ev = None
+            if self.sweep_events is not None:
+                ev = (L.x264hip_event_create(), L.x264hip_event_create())
+                L.x264hip_event_record(C.c_void_p(ev[0]), C.c_void_p(c.stream))
+            c.check(L.x264hip_slice_sweep_chains_events(c.h, entries, len(frames), C.c_void_p(lc["tab_host"]), lc["tab_dev"].p, C.c_void_p(lc["ev_ip"]),
+                                                        C.c_void_p(lc["ev_b"])), "slice_sweep_chains_events")
+            if ev:
+                L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
+                px = self.ctx.dims.mb_w * 16 * self.ctx.dims.lines_y
+                self.sweep_events.append((ev[0], ev[1], len(frames), sum(px * (3.0 + 4.5 * (cd.n_ref0 + cd.n_ref1)) for cd in out if cd.slice_type != SLICE_B), "IP"))
+            o = self.opt
+            for pic_i, chains in filt.items():
+                recon, s = self.pool[pic_i], self.states[pic_i].st
+                c.check(L.x264hip_frame_ctx_elements(c.h, C.c_void_p(lc["elems"][pic_i]), len(chains)), "frame_ctx_elements")
+                if o["deblock"]:
+                    dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
+                                       alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1,
+                                       sub8x8=1 if o["inter"] & 0x20 else 0)
+                    c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
+                c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
+                c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
+            c.check(L.x264hip_frame_ctx_elements(c.h, None, 0), "frame_ctx_elements")
+            self.last_ctx = c
+            if on_launch is not None:
+                on_launch(out, c, lc["ev_b"])            # e.g. copies of the payloads just produced (a B chain's: behind ev_b)
+            # the kept frames' chains are free when the filters are done: the event that says so is recorded behind them
+            L.x264hip_event_record(C.c_void_p(lc["ev_ip"]), C.c_void_p(c.stream))
+            lc["busy"], lc["keep"] = True, keep
+            lc["ip"] = [cd.chain for cd in out if cd.slice_type != SLICE_B]
+            lc["b"] = [cd.chain for cd in out if cd.slice_type == SLICE_B]
+            for cd in out:
+                self.las[cd.chain].end()
+            self.n_launches += 1
+            self.launch_sizes.append(len(out))
+        for lc in self.lctx:
+            lc["ctx"].sync()
+        assert self.lib.x264hip_device_synchronize() == 0
+
+    def status(self):
+        super().status()
+        for lc in self.lctx:
+            for s in self.states:
+                lc["ctx"].check(self.lib.x264hip_slice_sweep_status(lc["ctx"].h, C.byref(s.st)), "slice_sweep_status")
+
+    def close(self):
+        assert self.lib.x264hip_device_synchronize() == 0
+        for a in self._alt_only.values():
+            a.free()
+        for lc in self.lctx:
+            lc["tab_dev"].free()
+            for hp in [lc["tab_host"]] + lc["elems"]:
+                self.lib.x264hip_host_free(C.c_void_p(hp))
+            for e in (lc["ev_ip"], lc["ev_b"]):
+                self.lib.x264hip_event_destroy(C.c_void_p(e))
+            lc["ctx"].close()
+        self.lctx = []
+        super().close()

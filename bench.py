@@ -188,6 +188,8 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     is a wavefront: fewer resident chains run faster each, more run slower), so the default is one group."""
     import threading
     from x264_vs2008_amd.stream import StreamEncoder
+    if args.async_:
+        return run_stream_async(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_recs, delay)
     o = rd_options(args)
     G = max(1, min(args.groups, B))
     sizes = [len(range(j, B, G)) for j in range(G)]
@@ -362,6 +364,146 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         dist.destroy_process_group()
 
 
+def run_stream_async(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_recs, delay):
+    """Stream mode without steps (x264_vs2008_amd/stream.py: AsyncStreamEncoder): warm-up = every chain codes `warmup` frames, then the
+    clock runs while every chain codes `steps` more, each at its own pace; the device is drained at both ends of the timed part."""
+    from x264_vs2008_amd.stream import AsyncStreamEncoder
+    o = rd_options(args)
+    n_coded = args.warmup + args.steps
+    enc = AsyncStreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, n_frames=delay + n_coded, drift=args.drift, launches=args.launches, crf=args.crf,
+                             b_adapt=args.b_adapt, scenecut_threshold=args.scenecut, pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0,
+                             **analysis_options(args), **o)
+    d = enc.ctx.dims
+    px = d.mb_w * 16 * d.lines_y
+    check = ref_recs is not None and rank == 0
+    cap_n = min(CAPTURE, args.payload_cap - sl.PAYLOAD_LEAD)
+    hip.x264hip_host_alloc.restype = C.c_void_p
+    pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
+    coded0 = []
+
+    def fill(pic, f):
+        enc.src_ctx.synth(pic, g_first * SEG + f, g_step * SEG)
+
+    def on_launch(coded, ctx, ev_b):
+        if not check:
+            return
+        for cd in coded:
+            if cd.chain == 0 and len(coded0) < n_coded:
+                k = len(coded0)
+                enc.payload_async_of(cd, k, ctx, ev_b, pin + k * (cap_n + 64), pin + k * (cap_n + 64) + 64, cap_n)
+                coded0.append((cd.frame, cd.slice_type, cd.qp))
+
+    enc.run(fill, on_launch, until=args.warmup)
+    enc.status()
+    if dist is not None:
+        dist.barrier()
+    enc.sweep_events = []
+    rounds0, tasks0, launches0 = enc.lb.rounds, enc.look.n_tasks_run, enc.n_launches
+    t0 = time.perf_counter()
+    enc.run(fill, on_launch, until=n_coded)
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    enc.status()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        nb = torch.tensor([B], dtype=torch.int64)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        chains_total = int(nb[0])
+    else:
+        chains_total = B
+    checked = 0
+    if check:
+        for k, (frame, st, qp) in enumerate(coded0):
+            base = pin + k * (cap_n + 64)
+            n = C.c_int32.from_address(base).value
+            got = C.string_at(base + 64, min(n, cap_n))
+            rf, rst, rqp, want = ref_recs[k]
+            if (frame, st, qp) != (rf, rst, rqp):
+                raise SystemExit("bench.py: PARITY FAILURE -- chain 0, coded frame %d: the GPU side codes input %d as slice type %d at QP %d, the reference input %d as "
+                                 "type %d at QP %d" % (k, frame, st, qp, rf, rst, rqp))
+            if n != len(want) or got != want[:cap_n]:
+                raise SystemExit("bench.py: PARITY FAILURE -- chain 0, coded frame %d (input %d): the GPU's slice payload (%d bytes) differs from the reference's "
+                                 "(%d bytes)" % (k, frame, n, len(want)))
+            checked += 1
+        hip.x264hip_host_free(C.c_void_p(pin))
+    evs = enc.sweep_events
+    ms_all = [hip.x264hip_event_elapsed_ms(C.c_void_p(a), C.c_void_p(b)) for a, b, _, _, _ in evs]
+    n_ip = [n for _, _, n, _, _ in evs]
+    by_all = [by for _, _, _, by, _ in evs]
+    for a, b, _, _, _ in evs:
+        hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
+    sweep_ms = float(np.mean(ms_all)) if ms_all else 0.0
+    sweep_bytes = int(np.mean(by_all)) if by_all else 0
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms else 0.0
+    if rank == 0:
+        fps = chains_total * args.steps / dt
+        frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)
+        size = "%dp" % args.height
+        ksum = {"P": 0, "B": 0, "I": 0}
+        for per in enc.coded_all:
+            for cd in per[args.warmup:n_coded]:
+                ksum["PBI"[cd.slice_type]] += 1
+        total = sum(ksum.values())
+        sizes = enc.launch_sizes[launches0:]
+        metric = ("encoded frames/sec, %s, preset=medium's flag set with the encoder's own lookahead and rate control (--crf %.0f --b-adapt %d --pre-scenecut, %s, subme %d RD, "
+                  "trellis %d, psy-rd, aq-mode %d, CABAC payload on the GPU); 1/2/4/8 MI355X (bit-exact)"
+                  % (size, args.crf, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.aq_mode))
+        what = ("%dx%d streams (one per chain, segments of one synthetic clip) through x264_encoder_encode's path on the GPU: pictures synthesised on the device, "
+                "x264_frame_init_lowres + lookahead costs (x264_slicetype_frame_cost, one wavefront per task) feeding the library's x264_slicetype_decide / x264_ratecontrol_start "
+                "(host C), then the per-macroblock loop in raster order (one wavefront per chain: cache_load, x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, "
+                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct spatial --me %s "
+                "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d --pre-scenecut, chroma ME, fast "
+                "P-skip, dct-decimate, CABAC; payload bytes stay on the device (slice / NAL headers and the download are the host's).  No global step: a host scheduler launches "
+                "every chain's next frame as soon as that chain's own kernel has finished; warm-up = %d frames of every chain, timed = the next %d frames of every chain, the "
+                "device drained before and after" % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis,
+                                                      args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, args.warmup, args.steps))
+        missing = ["the scene cut that re-encodes (the reference's default at --threads 1): this run is the preset plus --pre-scenecut, the flag the reference forces with "
+                   "--threads > 1 and BASELINE.md prescribes for GOP-sharded runs", "slice / NAL headers around the payload"]
+        line = {
+            "metric": metric,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": what, "matches_baseline": False, "missing": missing,
+                       "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
+                       "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint,
+                       "per_chain_fps": round(fps / chains_total, 4),
+                       "latency_note": "throughput exists only with thousands of streams in flight: one chain advances one frame per 'step' on average",
+                       "slice_types_in_timed_steps": {k: round(v / max(total, 1), 4) for k, v in ksum.items()},
+                       "scheduler": {"launches_in_timed_part": len(sizes), "mean_chains_per_launch": round(float(np.mean(sizes)), 1) if sizes else 0,
+                                     "streams": args.launches, "drift_pictures": args.drift},
+                       "lookahead": {"cost_tasks_per_frame": round((enc.look.n_tasks_run - tasks0) / max(args.steps * B, 1), 3),
+                                     "cost_launches": enc.lb.rounds - rounds0, "slots": enc.n_slots, "delay": delay},
+                       "parallelism": "B streams per GPU, each a wavefront per frame; a host scheduler polls the I / P and the B kernel of every launch in flight and launches the freed "
+                                      "chains' next frames at once (chain-table launches on a ring of streams), so chains drift apart by up to %d pictures; lookahead cost tasks one "
+                                      "wavefront each; chains shard across GPUs with no data-path collective" % args.drift,
+                       "parity_checked_frames": checked,
+                       "parity": ("chain 0 of rank 0, all %d coded frames of this run (%d of them timed): input order, slice types, QPs and payload bytes equal the reference's whole "
+                                  "encoder (frame queue, slicetype decision, CRF, per-macroblock loop) run on the same pictures" % (checked, max(0, checked - args.warmup))) if checked else
+                                 "not checked in this run (no CPU leg: --no-cpu, no oracle/_ref, or more than one rank)"},
+            "roofline": {"bound": "hbm", "kernel": "k_slice_sweep<raster, chain table>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "traffic_note": "no rocprofv3 PMC measurement committed for this configuration",
+                         "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
+                         "note": "one 'launch' = the I / P chain-table kernel of one scheduler launch (HIP events on its stream; its B chains run in a kernel of their own on a second "
+                                 "stream and are not in this figure), mean %d I / P chains; many launches overlap, so their durations add up to far more than the wall clock; the "
+                                 "sweep is bound by the serial macroblock chain of a slice (%d macroblocks one after the other per frame, %d frames in flight), not by bandwidth; "
+                                 "whole-frame algorithmic bytes = %d -> %.1f GB/s at this fps" % (int(np.mean(n_ip)) if n_ip else 0, d.mb_w * d.mb_h, B, frame_bytes,
+                                                                                               frame_bytes * (fps / world) / 1e9)},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +544,12 @@ def main():
                     "lowres motion candidates, every chain placing its own B frames and pricing its own frames (-1: 1 for the raster variant, 0 with --wavefront 1); "
                     "0: round 2's lock-step chains at constant QP with a fixed B pattern")
     ap.add_argument("--crf", type=float, default=23.0)
+    ap.add_argument("--async", dest="async_", type=int, default=0, help="stream mode: 1: no steps -- a host scheduler hands every chain its next frame as soon as that chain's own kernel is done "
+                    "(AsyncStreamEncoder; the timed part is then steps frames of every chain, not steps launches; set GPU_MAX_HW_QUEUES=24: the launches need hardware queues of their "
+                    "own); 0 (default): one launch set per step, the step as long as its slowest chain.  Measured on the default workload: 404 frames/s against 455 -- the chains of the "
+                    "synthetic clip decide alike for their first frames, so they finish together anyway and the scheduler only adds launches (DESIGN.md 3.3)")
+    ap.add_argument("--drift", type=int, default=2, help="--async 1: pictures a chain may be ahead of the slowest one (each costs a lookahead slot per chain)")
+    ap.add_argument("--launches", type=int, default=12, help="--async 1: launches in flight (streams)")
     ap.add_argument("--pipeline", type=int, default=1, help="stream mode: 1: every step prepares the next step's lookahead (picture in, costs, decisions) beside its own sweep, on a stream "
                     "of its own -- the lookahead's kernels and the host's work fill the time the step's P chains run on after its B chains; 0: one after the other")
     ap.add_argument("--groups", type=int, default=1, help="stream mode: independently stepping groups of chains per GPU (own stream and host thread each); measured: 1 is best -- "

@@ -43,6 +43,9 @@ int x264hip_mb_state_clear_progress(x264hip_frame_ctx *c, x264hip_mb_state *st);
  * frame as soon as its own kernel is done instead of when the step's slowest chain is (x264_vs2008_amd/stream.py: AsyncStreamEncoder). */
 int x264hip_slice_sweep_chains_events(x264hip_frame_ctx *c, x264hip_chain_sweep *entries, int n, void *staging_host, void *table_dev, void *ev_ip, void *ev_b);
 int x264hip_event_query(void *ev);       /* 1 finished, 0 not yet, < 0 error */
+/* a stream of the device's greatest priority (x264hip_stream_destroy frees it): its kernels' wavefronts are dispatched first when a slot
+ * frees -- the lookahead's short kernels beside sweeps that keep the device full */
+void *x264hip_stream_create_high_priority(void);
 /* The batch elements the end-of-frame calls of this context touch from now on -- x264hip_deblock_frame, x264hip_expand_border,
  * x264hip_hpel_filter_frame: a device list of n element indices, or NULL = all.  With chains out of lock step a pool picture holds,
  * per element, either the frame that chain has just coded into it (to be filtered and kept as a reference) or an older reference of

@@ -209,7 +209,9 @@ extern "C" int x264hip_lookahead_cost_frames(x264hip_frame_ctx *c, const x264hip
         d.intra = sl[0]->intra_cost + (size_t)t.chain * n;
         d.d0 = t.d0; d.d1 = t.d1; d.do_search[0] = t.do_search[0]; d.do_search[1] = t.do_search[1];
     }
-    HIPCHK(hipMemcpyAsync(tasks_dev, st, sizeof(LookTaskDev) * (size_t)n_tasks, hipMemcpyHostToDevice, c->stream));
+    // tasks_dev == staging_host: the kernel reads the records in place, from pinned host memory (168 bytes per task, once) -- for callers that
+    // keep the device full, where even a small upload's copy kernel would wait for a wave slot
+    if (tasks_dev != staging_host) HIPCHK(hipMemcpyAsync(tasks_dev, st, sizeof(LookTaskDev) * (size_t)n_tasks, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_look_cost, dim3(n_tasks), dim3(64), 0, c->stream, (const LookTaskDev *)tasks_dev, mb_w, mb_h, slots[0].pic->stride_lowres,
                        p->me_method < 1 ? p->me_method : 1, p->me_range, p->weighted_bipred, p->bframe_bias, p->cost_mv + p->cost_mv_range, out_dev);
     HIPCHK(hipGetLastError());

@@ -256,6 +256,16 @@ extern "C" int x264hip_memcpy_h2d_async(void *dst_dev, const void *src_host, siz
     HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     return 0;
 }
+// A stream whose wavefronts are dispatched ahead of those of ordinary streams when a slot frees (hipStreamCreateWithPriority, the device's
+// greatest priority): for short kernels that must get through while long ones keep the device full (include/x264hip_lookahead.h)
+extern "C" void *x264hip_stream_create_high_priority(void)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+    return (void *)s;
+}
 // 1: everything the event recorded has finished, 0: not yet, < 0: error (include/x264hip_lookahead.h)
 extern "C" int x264hip_event_query(void *ev)
 {

@@ -218,6 +218,41 @@ class LookaheadDevice:
             self.n_tasks_run += len(part)
         return out
 
+    # -- the same without waiting: for a scheduler that keeps the device full (AsyncStreamEncoder) -------------------------------------
+    def run_async(self, tasks):
+        """Enqueue the tasks' launch; returns a handle for poll().  Task records and results live in pinned host memory that the kernel reads
+        and writes in place (no copy kernels, which would queue for a wave slot behind whatever fills the device)."""
+        np, ctx, lib = self.np, self.ctx, self.lib
+        assert 0 < len(tasks) <= self.max_tasks
+        if not hasattr(self, "_ring"):
+            lib.x264hip_event_create.restype = C.c_void_p
+            tb = lib.x264hip_lookahead_task_bytes()
+            self._ring = [dict(staging=lib.x264hip_host_alloc(C.c_size_t(tb * self.max_tasks)), out=lib.x264hip_host_alloc(C.c_size_t(16 * self.max_tasks)),
+                               ev=lib.x264hip_event_create(), busy=False) for _ in range(16)]
+        slot = next((r for r in self._ring if not r["busy"]), None)
+        if slot is None:
+            return None
+        arr = (LookTask * len(tasks))()
+        for i, (chain, b, p0, p1, ds0, ds1) in enumerate(tasks):
+            for f in (b, p0, p1):
+                assert self.frame_of_slot[self.slot(f)] == f, "input frame %d is no longer in its lookahead slot" % f
+            arr[i] = LookTask(chain, self.slot(b), self.slot(p0), self.slot(p1), b - p0, p1 - b, (C.c_int * 2)(ds0, ds1))
+        ctx.check(lib.x264hip_lookahead_cost_frames(ctx.h, self.slots, self.n_slots, arr, len(tasks), C.byref(self.params), C.c_void_p(slot["staging"]),
+                                                    C.c_void_p(slot["staging"]), C.c_void_p(slot["out"])), "lookahead_cost_frames")
+        lib.x264hip_event_record(C.c_void_p(slot["ev"]), C.c_void_p(ctx.stream))
+        slot["busy"], slot["n"] = True, len(tasks)
+        self.n_launches += 1
+        self.n_tasks_run += len(tasks)
+        return slot
+
+    def poll(self, handle):
+        """None while the launch is running, then its results (int32 [n][3])."""
+        if self.lib.x264hip_event_query(C.c_void_p(handle["ev"])) != 1:
+            return None
+        res = self.np.ctypeslib.as_array(C.cast(handle["out"], C.POINTER(C.c_int32)), (handle["n"], 4))[:, :3].copy()
+        handle["busy"] = False
+        return res
+
     def mv_ptr(self, chain, frame, lst, dist):
         """Device address of frames[frame]->lowres_mvs[lst][dist - 1] of one chain ([n_mb][2] int16)."""
         s = self.slot(frame)
@@ -230,6 +265,10 @@ class LookaheadDevice:
     def close(self):
         for a in self.intra + self.mv + self.mv_cost + [self.cost_mv, self.tasks_dev, self.out_dev]:
             a.free()
+        for r in getattr(self, "_ring", []):
+            self.lib.x264hip_host_free(C.c_void_p(r["staging"])); self.lib.x264hip_host_free(C.c_void_p(r["out"]))
+            self.lib.x264hip_event_destroy(C.c_void_p(r["ev"]))
+        self._ring = []
         for p in (self.staging, self.out_host):
             if p:
                 self.lib.x264hip_host_free(C.c_void_p(p))

@@ -14,6 +14,8 @@ chain-table launch per kernel kind (x264hip_slice_sweep_chains), each chain's en
 references, reconstruction and QP; the end-of-frame filters run on the elements that coded a kept frame (x264hip_frame_ctx_elements).
 The arithmetic lives in the HIP library; this file orders launches and owns device buffers."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 
@@ -38,7 +40,7 @@ class Coded:
 
 class StreamEncoder(ChainEncoder):
     def __init__(self, lib, width, height, cqm, batch=1, crf=None, b_adapt=1, bframe_bias=0, keyint_min=0, scenecut_threshold=40, pre_scenecut=1,
-                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, limits=None, n_frames=None, **kw):
+                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, limits=None, n_frames=None, lookahead_priority=False, **kw):
         kw.setdefault("write", 1)
         kw.setdefault("levels", False)
         if kw.get("lanes"):
@@ -59,7 +61,11 @@ class StreamEncoder(ChainEncoder):
         # pictures every chain will take) step() prepares the NEXT call's decisions right after launching this one's sweep, and the
         # lookahead's kernels fill the wave slots the step's B chains leave when they finish ahead of its P chains.
         from .frame import FrameCtx
-        self.src_ctx = FrameCtx(lib, width, height, batch=batch)
+        self._hp_stream = None
+        if lookahead_priority:
+            lib.x264hip_stream_create_high_priority.restype = C.c_void_p
+            self._hp_stream = lib.x264hip_stream_create_high_priority()
+        self.src_ctx = FrameCtx(lib, width, height, stream=self._hp_stream, batch=batch)
         self.n_frames = n_frames
         self._prep = None
         self._coding = set()
@@ -268,6 +274,9 @@ class StreamEncoder(ChainEncoder):
             self.tab_host = None
         super().close()
         self.src_ctx.close()
+        if self._hp_stream:
+            self.lib.x264hip_stream_destroy(C.c_void_p(self._hp_stream))
+            self._hp_stream = None
 
 
 class AsyncStreamEncoder(StreamEncoder):
@@ -297,7 +306,7 @@ class AsyncStreamEncoder(StreamEncoder):
         b_adapt = kw.get("b_adapt", 1)
         delay = (max(bf, 3) * 4 if b_adapt == 2 and bf else bf)
         kw.setdefault("n_slots", delay + bf + 3 + drift)
-        super().__init__(lib, width, height, cqm, batch=batch, n_frames=None, **kw)
+        super().__init__(lib, width, height, cqm, batch=batch, n_frames=None, lookahead_priority=True, **kw)
         from .frame import FrameCtx
         self.total, self.delay, self.drift = n_frames, delay, drift
         B = batch
@@ -347,10 +356,10 @@ class AsyncStreamEncoder(StreamEncoder):
     def _oldest_needed(self):
         m = self.prepared
         for ci, la in enumerate(self.las):
-            if self.ncoded[ci] < self.total:
+            if self.inflight_frame[ci] >= 0:
+                m = min(m, self.inflight_frame[ci])
+            if self.ncoded[ci] + (1 if self.inflight_frame[ci] >= 0 else 0) < self.total:
                 m = min(m, la.oldest_live() if self.fed[ci] else 0)
-                if self.inflight_frame[ci] >= 0:
-                    m = min(m, self.inflight_frame[ci])
         return m
 
     def _prepare_picture(self, fill):
@@ -361,97 +370,140 @@ class AsyncStreamEncoder(StreamEncoder):
         pic = self.look.begin_frame(f)
         self._fill(fill, pic, f)
         self.look.prepare(f)
+        # what says "picture f is in place" to the sweeps that will read it (they run on other streams)
+        if not hasattr(self, "pic_events"):
+            self.pic_events = {}
+        ev = self.pic_events.pop(f - self.n_slots, None) or self.lib.x264hip_event_create()
+        self.lib.x264hip_event_record(C.c_void_p(ev), C.c_void_p(self.src_ctx.stream))
+        self.pic_events[f] = ev
         self.prepared += 1
         return True
 
     # -- the scheduler ---------------------------------------------------------------------------------------------------------------
-    def run(self, fill, on_launch=None, poll_s=0.002):
+    def _decide(self, chains, fill):
+        """The lookahead's part for `chains` (idle, or with a frame in flight -- the decision does not read its result): pictures in, queues
+        asked.  A chain ends up with its next frame in self.next_frame, or pending on a batch of cost tasks launched here (not waited for), or
+        back in self.undecided (no slot free for a picture / no launch buffer free)."""
+        tasks, specs, owners = [], [], []
+        for ci in chains:
+            if self.ncoded[ci] + (1 if self.inflight_frame[ci] >= 0 else 0) >= self.total or ci in self.next_frame:
+                continue
+            want = min(self.total, self.ncoded[ci] + (1 if self.inflight_frame[ci] >= 0 else 0) + self.delay + 1)
+            ok = True
+            while self.fed[ci] < want:
+                if self.fed[ci] >= self.prepared and not self._prepare_picture(fill):
+                    ok = False                           # the ring is full: this chain is too far ahead of the slowest one, it waits
+                    break
+                assert self.las[ci].put() == self.fed[ci]
+                self.fed[ci] += 1
+            if not ok:
+                self.undecided.add(ci)
+                continue
+            kind, fr, needs = self.las[ci].get(self.fed[ci] >= self.total, self.lb.speculative)
+            if kind == LA.FRAME:
+                self.next_frame[ci] = fr
+            elif kind == LA.NEED:
+                if len(tasks) + len(needs) > self.look.max_tasks:
+                    self.undecided.add(ci)
+                    continue
+                for (b, p0, p1, ds0, ds1, spec) in needs:
+                    tasks.append((ci, b, p0, p1, ds0, ds1)); specs.append(spec)
+                owners.append(ci)
+            elif kind != LA.END:
+                raise RuntimeError("AsyncStreamEncoder: chain %d has no frame although %d pictures are in" % (ci, self.fed[ci]))
+        if tasks:
+            h = self.look.run_async(tasks)
+            if h is None:                                # every launch buffer is in flight: ask again later
+                self.undecided.update(owners)
+            else:
+                self.lb.rounds += 1
+                self.cost_batches.append((h, tasks, specs, owners))
+
+    def run(self, fill, on_launch=None, until=None, poll_s=0.001):
+        """Code frames until every chain has coded `until` of them (default: all n_frames), then wait for the device.  May be called again with a
+        larger `until` (a benchmark's warm-up, then its timed part)."""
         import time
         L, B = self.lib, self.ctx.batch
-        ready = set(range(B))
-        done = 0
-        self.coded_all = [[] for _ in range(B)]
+        target = self.total if until is None else min(until, self.total)
+        if not hasattr(self, "coded_all"):
+            self.coded_all = [[] for _ in range(B)]
+            self.next_frame, self.cost_batches, self.undecided = {}, [], set()
+            self.pic_events = {}
+        idle = {ci for ci in range(B) if self.inflight_frame[ci] < 0}           # chains whose previous frame (if any) is done
+        done = sum(1 for ci in range(B) if self.ncoded[ci] >= target)
+        self._oldest = self._oldest_needed()
+        self._decide([ci for ci in sorted(idle) if self.ncoded[ci] < target], fill)
+        stats = os.environ.get("X264HIP_ASYNC_STATS")
+        t_last, acc = time.perf_counter(), [0.0, 0.0, 0.0, 0.0, 0.0]
         while done < B:
-            # 1. completions: the B kernel and the I / P kernel (+ its filters) of every launch in flight, separately
             progressed = False
+            if stats:                                    # time-weighted: idle chains, idle chains without a decision, launches in flight, cost batches in flight
+                now = time.perf_counter(); dt_ = now - t_last; t_last = now
+                n_idle = sum(1 for ci in idle if self.ncoded[ci] < target)
+                acc[0] += dt_; acc[1] += dt_ * n_idle; acc[2] += dt_ * sum(1 for ci in idle if self.ncoded[ci] < target and ci not in self.next_frame)
+                acc[3] += dt_ * sum(1 for lc in self.lctx if lc["busy"]); acc[4] += dt_ * len(self.cost_batches)
+            # 1. sweeps: the B kernel and the I / P kernel (+ its filters) of every launch in flight, separately
             for lc in self.lctx:
                 if not lc["busy"]:
                     continue
-                if lc["b"] and L.x264hip_event_query(C.c_void_p(lc["ev_b"])) == 1:
-                    ready.update(lc["b"]); lc["b"] = []; progressed = True
-                if lc["ip"] and L.x264hip_event_query(C.c_void_p(lc["ev_ip"])) == 1:
-                    ready.update(lc["ip"]); lc["ip"] = []; progressed = True
-                if not lc["b"] and not lc["ip"] and L.x264hip_event_query(C.c_void_p(lc["ev_b"])) == 1 and L.x264hip_event_query(C.c_void_p(lc["ev_ip"])) == 1:
+                for kind in ("b", "ip"):
+                    if lc[kind] and L.x264hip_event_query(C.c_void_p(lc["ev_" + kind])) == 1:
+                        for ci in lc[kind]:
+                            self.inflight_frame[ci] = -1
+                            self.ncoded[ci] += 1
+                            if self.ncoded[ci] == target:
+                                done += 1
+                        idle.update(lc[kind]); lc[kind] = []; progressed = True
+                if not lc["b"] and not lc["ip"]:
                     lc["busy"], lc["keep"] = False, None
-            for ci in list(ready):
-                if self.inflight_frame[ci] >= 0:
-                    self.inflight_frame[ci] = -1
-            free = [lc for lc in self.lctx if not lc["busy"]]
-            if not ready or not free:
-                if not progressed:
-                    time.sleep(poll_s)
-                continue
-            # 2. every ready chain takes the pictures x264_encoder_encode would have been given by now (call j = ncoded + delay gets picture j)
-            cand = []
-            self._oldest = self._oldest_needed()
-            for ci in sorted(ready):
-                if self.ncoded[ci] >= self.total:
-                    ready.discard(ci)
-                    continue
-                want = min(self.total, self.ncoded[ci] + self.delay + 1)
-                ok = True
-                while self.fed[ci] < want:
-                    if self.fed[ci] >= self.prepared and not self._prepare_picture(fill):
-                        ok = False                       # the ring is full: this chain is too far ahead of the slowest one, it waits
-                        break
-                    assert self.las[ci].put() == self.fed[ci]
-                    self.fed[ci] += 1
-                if ok:
-                    cand.append(ci)
-            # 3. their queues decide; the costs they ask for are computed together
-            frames, waiting = {}, cand
-            while waiting:
-                tasks, specs, still = [], [], []
-                for ci in waiting:
-                    kind, fr, needs = self.las[ci].get(self.fed[ci] >= self.total, self.lb.speculative)
-                    if kind == LA.NEED:
-                        for (b, p0, p1, ds0, ds1, spec) in needs:
-                            tasks.append((ci, b, p0, p1, ds0, ds1)); specs.append(spec)
-                        still.append(ci)
-                    elif kind == LA.FRAME:
-                        frames[ci] = fr
-                    elif kind == LA.END:
-                        ready.discard(ci)
-                    else:
-                        raise RuntimeError("AsyncStreamEncoder: chain %d has no frame although %d pictures are in" % (ci, self.fed[ci]))
-                if tasks:
-                    res = self.look.run(tasks)
-                    self.lb.rounds += 1
+            # 2. cost batches: results in, the chains that asked go on deciding
+            if self.cost_batches:
+                keep_b, again = [], []
+                for (h, tasks, specs, owners) in self.cost_batches:
+                    res = self.look.poll(h)
+                    if res is None:
+                        keep_b.append((h, tasks, specs, owners))
+                        continue
                     for (ci, b, p0, p1, ds0, ds1), spec, r in zip(tasks, specs, res):
                         self.las[ci].set_cost(b, p0, p1, int(r[0]), int(r[1]), int(r[2]), spec)
-                waiting = still
-            if not frames:
+                    again += owners
+                    progressed = True
+                self.cost_batches = keep_b
+                if again:
+                    self._oldest = self._oldest_needed()
+                    self._decide(again, fill)
+            if self.undecided and progressed:
+                again, self.undecided = sorted(self.undecided), set()
+                self._oldest = self._oldest_needed()
+                self._decide(again, fill)
+            # 3. launch: idle chains whose next frame is decided
+            free = [lc for lc in self.lctx if not lc["busy"]]
+            go = [ci for ci in idle if ci in self.next_frame and self.ncoded[ci] < target] if free else []
+            if not go:
                 if not progressed:
                     time.sleep(poll_s)
                 continue
-            self.src_ctx.sync()                          # the pictures and vectors the sweeps read are in place
-            # 4. one launch for all of them
             lc = free[0]
             c = lc["ctx"]
             keep, written, filt, out = [], set(), {}, []
-            entries = (ChainSweep * len(frames))()
-            for k, (ci, fr) in enumerate(sorted(frames.items())):
+            entries = (ChainSweep * len(go))()
+            frames_read = set()
+            for k, ci in enumerate(sorted(go)):
+                fr = self.next_frame.pop(ci)
                 entries[k], cd, pic_i = self._entry(ci, fr, keep)
                 written.add(pic_i)
                 out.append(cd)
                 if cd.slice_type != SLICE_B:
                     filt.setdefault(pic_i, []).append(ci)
                 self.inflight_frame[ci] = fr.frame
-                self.ncoded[ci] += 1
                 self.coded_all[ci].append(cd)
-                ready.discard(ci)
-                if self.ncoded[ci] >= self.total:
-                    done += 1
+                idle.discard(ci)
+                frames_read.add(fr.frame)
+            # the pictures these sweeps read were prepared on the lookahead's stream: wait (on the device) for the ones that may not be finished
+            for f in frames_read:
+                ev = self.pic_events.get(f)
+                if ev is not None and L.x264hip_event_query(C.c_void_p(ev)) != 1:
+                    L.x264hip_stream_wait_event(C.c_void_p(c.stream), C.c_void_p(ev))
             for pic_i in written:
                 c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
             for pic_i, chains in filt.items():
@@ -460,18 +512,18 @@ class AsyncStreamEncoder(StreamEncoder):
             if self.sweep_events is not None:
                 ev = (L.x264hip_event_create(), L.x264hip_event_create())
                 L.x264hip_event_record(C.c_void_p(ev[0]), C.c_void_p(c.stream))
-            c.check(L.x264hip_slice_sweep_chains_events(c.h, entries, len(frames), C.c_void_p(lc["tab_host"]), lc["tab_dev"].p, C.c_void_p(lc["ev_ip"]),
+            c.check(L.x264hip_slice_sweep_chains_events(c.h, entries, len(go), C.c_void_p(lc["tab_host"]), lc["tab_dev"].p, C.c_void_p(lc["ev_ip"]),
                                                         C.c_void_p(lc["ev_b"])), "slice_sweep_chains_events")
             if ev:
                 L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
                 px = self.ctx.dims.mb_w * 16 * self.ctx.dims.lines_y
-                self.sweep_events.append((ev[0], ev[1], len(frames), sum(px * (3.0 + 4.5 * (cd.n_ref0 + cd.n_ref1)) for cd in out if cd.slice_type != SLICE_B), "IP"))
+                self.sweep_events.append((ev[0], ev[1], sum(1 for cd in out if cd.slice_type != SLICE_B), sum(px * (3.0 + 4.5 * (cd.n_ref0 + cd.n_ref1)) for cd in out if cd.slice_type != SLICE_B), "IP"))
             o = self.opt
             for pic_i, chains in filt.items():
-                recon, s = self.pool[pic_i], self.states[pic_i].st
+                recon, s_ = self.pool[pic_i], self.states[pic_i].st
                 c.check(L.x264hip_frame_ctx_elements(c.h, C.c_void_p(lc["elems"][pic_i]), len(chains)), "frame_ctx_elements")
                 if o["deblock"]:
-                    dp = DeblockParams(mb_type=s.mb_type, qp=s.qp, nnz=s.nnz, transform8x8=s.t8, mv=s.mv, ref=s.ref,
+                    dp = DeblockParams(mb_type=s_.mb_type, qp=s_.qp, nnz=s_.nnz, transform8x8=s_.t8, mv=s_.mv, ref=s_.ref,
                                        alpha_c0_offset=o["alpha_c0"], beta_offset=o["beta"], chroma_qp_offset=o["chroma_qp_offset"], state_layout=1,
                                        sub8x8=1 if o["inter"] & 0x20 else 0)
                     c.check(L.x264hip_deblock_frame(c.h, C.byref(recon), C.byref(dp)), "deblock_frame")
@@ -486,10 +538,17 @@ class AsyncStreamEncoder(StreamEncoder):
             lc["busy"], lc["keep"] = True, keep
             lc["ip"] = [cd.chain for cd in out if cd.slice_type != SLICE_B]
             lc["b"] = [cd.chain for cd in out if cd.slice_type == SLICE_B]
-            for cd in out:
-                self.las[cd.chain].end()
+            launched = [cd.chain for cd in out]
+            for ci in launched:
+                self.las[ci].end()
             self.n_launches += 1
             self.launch_sizes.append(len(out))
+            # their next decisions now, beside the sweeps (x264_ratecontrol_start does not read what the frame in flight produces)
+            self._oldest = self._oldest_needed()
+            self._decide(launched, fill)
+        if stats and acc[0] > 0:
+            print("async stats: %.1f s, mean idle chains %.0f (undecided %.0f) of %d, launches in flight %.1f, cost batches in flight %.1f, launches %d"
+                  % (acc[0], acc[1] / acc[0], acc[2] / acc[0], B, acc[3] / acc[0], acc[4] / acc[0], self.n_launches), file=sys.stderr)
         for lc in self.lctx:
             lc["ctx"].sync()
         assert self.lib.x264hip_device_synchronize() == 0

@@ -206,7 +206,7 @@ class StreamEncoder(ChainEncoder):
                         cabac=o["cabac"], transform8x8=o["transform8x8"], analyse_inter=o["inter"], analyse_intra=o["intra"],
                         quant4_mf=b["quant4_mf"].ptr, quant4_bias=b["quant4_bias"].ptr, quant8_mf=b["quant8_mf"].ptr,
                         quant8_bias=b["quant8_bias"].ptr, dequant4_mf=b["dequant4_mf"].ptr, dequant8_mf=b["dequant8_mf"].ptr,
-                        cost_mv=self.cost_table(qp).ptr, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],
+                        cost_mv=rb["cost_mv_all"].ptr + qp * (2 * COST_SPAN + 1) * 2, cost_mv_range=COST_SPAN, poc=poc, mixed_refs=o["mixed_refs"],      # (a row of the table of all QPs: no allocation while kernels run -- hipMalloc waits for the device)
                         noise_reduction=o["noise_reduction"], nr=C.addressof(self.nr) if self.nr else None, lossless=self.lossless,
                         lowres_mv=lw0)
         rd = SliceRd(trellis=ro["trellis"], psy_rd=self.psy_rd_fix, write=1, cabac_init_idc=ro["cabac_init_idc"], i_frame=self.c_coded[ci],

@@ -201,7 +201,7 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
     coded0 = []                                          # chain 0's coded frames: (input number, slice type, qp)
     encs = [StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=sizes[j], crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut,
-                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, n_frames=(delay + n_coded) if args.pipeline else None,
+                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, n_frames=(delay + n_coded) if args.pipeline else None, b_cus=args.b_cus,
                           **analysis_options(args), **o) for j in range(G)]
     d = encs[0].ctx.dims
     px = d.mb_w * 16 * d.lines_y
@@ -550,6 +550,7 @@ def main():
                     "synthetic clip decide alike for their first frames, so they finish together anyway and the scheduler only adds launches (DESIGN.md 3.3)")
     ap.add_argument("--drift", type=int, default=2, help="--async 1: pictures a chain may be ahead of the slowest one (each costs a lookahead slot per chain)")
     ap.add_argument("--launches", type=int, default=12, help="--async 1: launches in flight (streams)")
+    ap.add_argument("--b-cus", type=int, default=0, help="stream mode (steps): compute units [0, N) for the step's B kernel, the rest for its I / P kernel (0: both everywhere)")
     ap.add_argument("--pipeline", type=int, default=1, help="stream mode: 1: every step prepares the next step's lookahead (picture in, costs, decisions) beside its own sweep, on a stream "
                     "of its own -- the lookahead's kernels and the host's work fill the time the step's P chains run on after its B chains; 0: one after the other")
     ap.add_argument("--groups", type=int, default=1, help="stream mode: independently stepping groups of chains per GPU (own stream and host thread each); measured: 1 is best -- "

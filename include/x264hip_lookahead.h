@@ -46,6 +46,11 @@ int x264hip_event_query(void *ev);       /* 1 finished, 0 not yet, < 0 error */
 /* a stream of the device's greatest priority (x264hip_stream_destroy frees it): its kernels' wavefronts are dispatched first when a slot
  * frees -- the lookahead's short kernels beside sweeps that keep the device full */
 void *x264hip_stream_create_high_priority(void);
+/* a stream whose kernels run on compute units [first, first + n) of 256 only; x264hip_frame_ctx_set_b_stream: the stream the B kernel of
+ * this context's chain-table launches runs on (default: one the library creates) -- a caller may give the step's I / P chains and its B chains
+ * disjoint parts of the device (x264hip_frame_ctx_new takes the context's own stream) */
+void *x264hip_stream_create_cu_range(int first_cu, int n_cus);
+int x264hip_frame_ctx_set_b_stream(x264hip_frame_ctx *c, void *hip_stream);
 /* The batch elements the end-of-frame calls of this context touch from now on -- x264hip_deblock_frame, x264hip_expand_border,
  * x264hip_hpel_filter_frame: a device list of n element indices, or NULL = all.  With chains out of lock step a pool picture holds,
  * per element, either the frame that chain has just coded into it (to be filtered and kept as a reference) or an older reference of

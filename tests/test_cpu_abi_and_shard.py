@@ -26,10 +26,32 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(L.SO_PATH):
         L.build()
     lib = L.open_library()
-    declared = _declared_functions(os.path.join(ROOT, "include", "x264hip.h"))
-    assert len(declared) > 30
-    missing = [n for n in declared if not hasattr(lib, n)]
-    assert not missing, "declared in include/x264hip.h but not exported: %s" % missing
+    for header in ("x264hip.h", "x264hip_lookahead.h"):
+        declared = _declared_functions(os.path.join(ROOT, "include", header))
+        assert len(declared) > (30 if header == "x264hip.h" else 8)
+        missing = [n for n in declared if not hasattr(lib, n)]
+        assert not missing, "declared in include/%s but not exported: %s" % (header, missing)
+
+
+def test_lookahead_struct_sizes_match_header():
+    """The ctypes mirrors of the round-3 structures (x264_vs2008_amd/lookahead.py, stream.py) against the C headers."""
+    from x264_vs2008_amd import lookahead as LA
+    from x264_vs2008_amd import stream as ST
+    prog = r'''
+#include <stdio.h>
+#include "x264hip_lookahead.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead_params), sizeof(x264hip_look_need), sizeof(x264hip_look_frame),
+ sizeof(x264hip_look_slot), sizeof(x264hip_look_task), sizeof(x264hip_look_params), sizeof(x264hip_chain_sweep)); return 0; }
+'''
+    exe = os.path.join(ROOT, "tests", "_sizes2.bin")
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog.encode(), check=True)
+    try:
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    finally:
+        os.remove(exe)
+    want = [C.sizeof(LA.LookaheadParams), C.sizeof(LA.Need), C.sizeof(LA.Frame), C.sizeof(LA.LookSlot), C.sizeof(LA.LookTask), C.sizeof(LA.LookParams),
+            C.sizeof(ST.ChainSweep)]
+    assert got == want, (got, want)
 
 
 def test_init_fails_loudly_without_gpu_or_inits_with_one():

@@ -127,6 +127,7 @@ extern "C" int x264hip_noise_reduction_update(x264hip_frame_ctx *c, const x264hi
     return 0;
 }
 
+struct ChainAux { hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done = nullptr; };
 // The three argument structures of one sweep launch from the ABI's description of it, and which kernel codes it
 enum { SW_KIND_PLAIN = 0, SW_KIND_RD, SW_KIND_RF, SW_KIND_B, SW_KIND_BT };
 static void sweep_note_frame(const x264hip_slice_params *p, int n_refs, x264hip_mb_state *out);
@@ -325,9 +326,23 @@ extern "C" int x264hip_slice_sweep_frame(x264hip_frame_ctx *c, const x264hip_pic
     return 0;
 }
 
-struct ChainAux { hipStream_t stream = nullptr; hipEvent_t ready = nullptr, done = nullptr; };
 // The chain-table launch: every entry is a sweep of ONE chain (batch element) with its own pictures, states and slice parameters.
 static int sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev, void *ev_ip, void *ev_b, bool join);
+static std::mutex g_aux_mu;
+static std::unordered_map<x264hip_frame_ctx *, ChainAux> g_aux_of;
+// the stream the B kernel of this context's chain-table launches runs on (default: one the library creates): e.g. one restricted to
+// a part of the device (x264hip_stream_create_cu_range) while the context's own stream has the rest
+extern "C" int x264hip_frame_ctx_set_b_stream(x264hip_frame_ctx *c, void *hip_stream)
+{
+    std::lock_guard<std::mutex> g(g_aux_mu);
+    ChainAux &ax = g_aux_of[c];
+    if (!ax.ready) {
+        HIPCHK(hipEventCreateWithFlags(&ax.ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ax.done, hipEventDisableTiming));
+    }
+    ax.stream = (hipStream_t)hip_stream;
+    return 0;
+}
 extern "C" int x264hip_slice_sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, void *staging_host, void *table_dev)
 {
     return sweep_chains(c, e, n, staging_host, table_dev, nullptr, nullptr, true);
@@ -371,14 +386,12 @@ static int sweep_chains(x264hip_frame_ctx *c, x264hip_chain_sweep *e, int n, voi
     // The I / P chains and the B chains of a step are different chains: their kernels run side by side, the B kernel on a stream of its
     // own between two events (behind the table's upload, ahead of whatever follows on the context's stream).
     const bool two = cnt[SW_KIND_BT] && (cnt[SW_KIND_RD] || cnt[SW_KIND_RF] || !join);
-    static std::mutex mu;
-    static std::unordered_map<x264hip_frame_ctx *, ChainAux> aux_of;
     ChainAux *ax = nullptr;
     if (two) {
-        std::lock_guard<std::mutex> g(mu);
-        ax = &aux_of[c];
-        if (!ax->stream) {
-            HIPCHK(hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking));
+        std::lock_guard<std::mutex> g(g_aux_mu);
+        ax = &g_aux_of[c];
+        if (!ax->stream) HIPCHK(hipStreamCreateWithFlags(&ax->stream, hipStreamNonBlocking));
+        if (!ax->ready) {
             HIPCHK(hipEventCreateWithFlags(&ax->ready, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&ax->done, hipEventDisableTiming));
         }

@@ -266,6 +266,17 @@ extern "C" void *x264hip_stream_create_high_priority(void)
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     return (void *)s;
 }
+// A stream whose kernels run on compute units [first, first + n) only (hipExtStreamCreateWithCUMask; bit i of the mask = compute unit i
+// in the runtime's numbering): to give two kinds of long kernels their own parts of the device (include/x264hip_lookahead.h)
+extern "C" void *x264hip_stream_create_cu_range(int first, int n)
+{
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (first < 0 || n <= 0 || first + n > 256) return nullptr;
+    for (int i = first; i < first + n; i++) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (void *)s;
+}
 // 1: everything the event recorded has finished, 0: not yet, < 0: error (include/x264hip_lookahead.h)
 extern "C" int x264hip_event_query(void *ev)
 {

@@ -40,7 +40,7 @@ class Coded:
 
 class StreamEncoder(ChainEncoder):
     def __init__(self, lib, width, height, cqm, batch=1, crf=None, b_adapt=1, bframe_bias=0, keyint_min=0, scenecut_threshold=40, pre_scenecut=1,
-                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, limits=None, n_frames=None, lookahead_priority=False, **kw):
+                 ip_factor=1.4, pb_factor=1.3, qcompress=0.6, qp_step=4, n_slots=0, speculative=True, limits=None, n_frames=None, lookahead_priority=False, b_cus=0, **kw):
         kw.setdefault("write", 1)
         kw.setdefault("levels", False)
         if kw.get("lanes"):
@@ -61,6 +61,21 @@ class StreamEncoder(ChainEncoder):
         # pictures every chain will take) step() prepares the NEXT call's decisions right after launching this one's sweep, and the
         # lookahead's kernels fill the wave slots the step's B chains leave when they finish ahead of its P chains.
         from .frame import FrameCtx
+        # b_cus: the step's B kernel on compute units [0, b_cus), its I / P kernel (and everything else of this context) on the rest
+        self._cu_streams = []
+        if b_cus:
+            lib.x264hip_stream_create_cu_range.restype = C.c_void_p
+            sb_, sp_ = lib.x264hip_stream_create_cu_range(0, b_cus), lib.x264hip_stream_create_cu_range(b_cus, 256 - b_cus)
+            if not sb_ or not sp_:
+                raise RuntimeError("x264hip_stream_create_cu_range failed")
+            self._cu_streams = [sb_, sp_]
+            old = self.ctx
+            self.ctx = FrameCtx(lib, width, height, stream=sp_, batch=batch)         # same geometry: the pool's pictures and states stay where they are
+            self.ctx.pictures, old.pictures = old.pictures, []
+            for st_ in self.states:
+                st_.ctx = self.ctx
+            old.close()
+            self.ctx.check(lib.x264hip_frame_ctx_set_b_stream(self.ctx.h, C.c_void_p(sb_)), "frame_ctx_set_b_stream")
         self._hp_stream = None
         if lookahead_priority:
             lib.x264hip_stream_create_high_priority.restype = C.c_void_p

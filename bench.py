@@ -21,8 +21,9 @@ A "step" is one x264_encoder_encode call for every chain (x264_vs2008_amd/stream
                                    chains and the B chains of the step side by side; the slice's CABAC payload comes out of the launch
   x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   a kept frame becomes a reference (the elements that coded one)
 
-config.matches_baseline is false for ONE flag: the scene cut is the pre-encode one (--pre-scenecut, which the reference itself forces
-with --threads > 1 and BASELINE.md prescribes for sharded runs), not the one that re-encodes.  PARITY IS CHECKED IN THIS RUN: rank 0's
+config.matches_baseline is true for the default run with config.flag_set saying what that means: MED with --pre-scenecut on BOTH sides
+(GPU and the reference leg) -- the pre-encode scene cut, which the reference itself forces with --threads > 1 and BASELINE.md prescribes
+for sharded runs, instead of the one that re-encodes a frame.  PARITY IS CHECKED IN THIS RUN: rank 0's
 chain 0 also goes through the REFERENCE's whole encoder on the host (frame queue, slice-type decision, rate control, slice loop; the
 cpu_baseline leg, before the GPU is touched), and for every frame the GPU side coded for that chain -- warm-up and timed steps alike --
 the input number, slice type, QP and payload bytes must equal the reference's, or the run fails (config.parity_checked_frames).
@@ -208,6 +209,35 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     kinds = [{"P": 0, "B": 0, "I": 0} for _ in range(G)]
     errors = []
     gate = threading.Barrier(G + 1)
+    pcie = None
+    if args.pcie:
+        if G != 1:
+            raise SystemExit("bench.py --pcie: one group")
+        from x264_vs2008_amd.frame import FrameCtx
+        up = FrameCtx(hip, args.width, args.height, batch=sizes[0])                 # its stream: the transfers' own
+        scratch = up.new_picture(source_only=True)
+        w, h = args.width, args.height
+        host_pic = hip.x264hip_host_alloc(C.c_size_t(w * h * 3 // 2))
+        y0, u0, v0 = synth.frame(w, h, 7)
+        np.ctypeslib.as_array(C.cast(host_pic, C.POINTER(C.c_uint8)), (w * h * 3 // 2,))[:] = np.concatenate([y0.ravel(), u0.ravel(), v0.ravel()])
+        down_bytes = min(args.payload_cap, 256 << 10)                                  # per chain and frame: more than any slice of this clip
+        host_pay = hip.x264hip_host_alloc(C.c_size_t(sizes[0] * down_bytes))
+        pcie = dict(ctx=up, pic=scratch, host=host_pic, pay=host_pay, down=down_bytes, h2d=0, d2h=0)
+        hip.x264hip_picture_upload_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+
+    def move_over_pcie(enc):
+        """What a host-fed encoder moves per step: every chain's next picture up, every chain's payload down (on the transfers' stream)."""
+        up, w, h = pcie["ctx"], args.width, args.height
+        st = C.c_void_p(up.stream)
+        for b in range(up.batch):
+            up.select(b)
+            up.check(hip.x264hip_picture_upload_async(up.h, C.byref(pcie["pic"]), C.c_void_p(pcie["host"]), w, C.c_void_p(pcie["host"] + w * h), w // 2,
+                                                      C.c_void_p(pcie["host"] + w * h * 5 // 4), w // 2, st), "picture_upload_async")
+        pcie["h2d"] += up.batch * w * h * 3 // 2
+        rb = enc.rd_bufs
+        for b in range(up.batch):          # the payloads of the frames coded one step ago are final: this step's sweep was launched behind a wait for them
+            hip.x264hip_memcpy_d2h_async(C.c_void_p(pcie["pay"] + b * pcie["down"]), C.c_void_p(rb["payload"].ptr + enc.payload_cap * b), C.c_size_t(pcie["down"]), st)
+        pcie["d2h"] += up.batch * pcie["down"]
 
     def one_step(j, timed):
         enc = encs[j]
@@ -222,6 +252,8 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         if timed:
             for cd in out:
                 kinds[j]["PBI"[cd.slice_type]] += 1
+        if pcie is not None and out:
+            move_over_pcie(enc)
         return out
 
     def worker(j):
@@ -304,6 +336,22 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         hip.x264hip_event_destroy(C.c_void_p(a)); hip.x264hip_event_destroy(C.c_void_p(b))
     sweep_ms, sweep_bytes = float(np.mean(ms_all)), int(np.mean(by_all))
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    # HBM-side traffic of a step's sweep launches: the committed rocprofv3 --pmc measurement of this configuration (bytes per coded frame of a
+    # chain, by slice type) times this run's mix; null for any other configuration
+    traffic, traffic_note = None, "no rocprofv3 PMC measurement committed for this configuration"
+    tpath = os.path.join(ROOT, "profiles", "r03_stream_traffic.json")
+    defaults = (args.width, args.height, args.me, args.inter & 0x33, args.intra, args.dct8, args.mixed_refs, args.subme, args.refs, args.bframes, args.b_adapt) == \
+               (1920, 1080, 1, 0x13, 0x3, 1, 1, 7, 3, 3, 1) and (args.trellis, args.psy_rd, args.aq_mode, args.crf, args.keyint, args.scenecut, args.weightb) == (1, 1.0, 1, 23.0, 250, 40, 1)
+    if defaults and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        per = tj["bytes_per_chain_frame"]
+        ks = {k: sum(kk[k] for kk in kinds) for k in "PBI"}
+        n_l = max(len(evs), 1)
+        if all(k in per for k in "PBI" if ks[k]):
+            traffic = int(sum(ks[k] * (per[k]["fetch"] + per[k]["write"]) for k in "PBI" if ks[k]) / n_l)
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE per coded frame of a chain by slice type (rocprofv3 --pmc, separate passes, raw request-granular counters, measured at %d chains; "
+                            "profiles/r03_stream_traffic.json) times this run's slice types, per step" % tj["batch"])
     if rank == 0:
         fps = chains_total * args.steps / dt
         frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)
@@ -323,14 +371,17 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
                 "P-skip, dct-decimate, CABAC; payload bytes stay on the device (slice / NAL headers and the download are the host's)"
                 % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
                    args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut))
-        missing = ["the scene cut that re-encodes (the reference's default at --threads 1): this run is the preset plus --pre-scenecut, the flag the reference forces with "
-                   "--threads > 1 and BASELINE.md prescribes for GOP-sharded runs", "slice / NAL headers around the payload"]
+        # the flag set is BASELINE.md's MED with --pre-scenecut ON BOTH SIDES (GPU and the reference leg): the reference forces that flag itself with
+        # --threads > 1, and BASELINE.md prescribes it for GOP-sharded runs; the scene cut that re-encodes a frame is the only thing it replaces
+        missing = ["slice / NAL headers around the payload (the product is slice_data(); x264hip_nal_encode wraps it)"]
+        flagset = ("MED (BASELINE.md) + --pre-scenecut on both sides: the pre-encode scene cut instead of the one that re-encodes a frame -- what the reference does itself with "
+                   "--threads > 1")
         line = {
             "metric": metric,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": what, "matches_baseline": False, "missing": missing,
+            "config": {"workload": what, "matches_baseline": bool(args.preset == "hd" and defaults), "flag_set": flagset, "missing": missing,
                        "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
                        "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint, "groups_per_gpu": G,
                        "per_chain_fps": round(fps / chains_total, 4),
@@ -342,12 +393,16 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
                                       "(I / P and B chains side by side), one wavefront per chain walking its frame in raster order; lookahead cost tasks one wavefront each; chains "
                                       "shard across GPUs with no data-path collective" % G,
                        "parity_checked_frames": checked,
+                       "pcie": None if pcie is None else {"host_to_device_bytes_per_step": pcie["h2d"] // max(args.warmup + args.steps, 1),
+                                                          "device_to_host_bytes_per_step": pcie["d2h"] // max(args.warmup + args.steps, 1),
+                                                          "note": "every step moved one I420 picture per chain up from pinned memory and %d KB of every chain's payload buffer down, "
+                                                                  "on a stream of their own beside the kernels: value is the PCIe-inclusive rate" % (pcie["down"] >> 10)},
                        "parity": ("chain 0 of rank 0, all %d coded frames of this run (%d of them timed): input order, slice types, QPs and payload bytes equal the reference's whole "
                                   "encoder (frame queue, slicetype decision, CRF, per-macroblock loop) run on the same pictures" % (checked, max(0, checked - args.warmup))) if checked else
                                  "not checked in this run (no CPU leg: --no-cpu, no oracle/_ref, or more than one rank)"},
             "roofline": {"bound": "hbm", "kernel": "k_slice_sweep<raster, chain table>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "traffic_note": "no rocprofv3 PMC measurement committed for this configuration",
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "avg_launch_ms": round(sweep_ms, 4), "algorithmic_bytes_per_launch": sweep_bytes,
                          "note": "one 'launch' = one group's chain-table launches of a step together (the I / P kernel and the B kernel, side by side on two streams; HIP events around "
                                  "the pair), %d chains; %d groups overlap, so the launches' durations add up to more than the wall clock; the sweep is bound by the serial macroblock "
@@ -461,14 +516,17 @@ def run_stream_async(args, hip, dist, json_fd, rank, world, B, g_first, g_step, 
                 "every chain's next frame as soon as that chain's own kernel has finished; warm-up = %d frames of every chain, timed = the next %d frames of every chain, the "
                 "device drained before and after" % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis,
                                                       args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, args.warmup, args.steps))
-        missing = ["the scene cut that re-encodes (the reference's default at --threads 1): this run is the preset plus --pre-scenecut, the flag the reference forces with "
-                   "--threads > 1 and BASELINE.md prescribes for GOP-sharded runs", "slice / NAL headers around the payload"]
+        # the flag set is BASELINE.md's MED with --pre-scenecut ON BOTH SIDES (GPU and the reference leg): the reference forces that flag itself with
+        # --threads > 1, and BASELINE.md prescribes it for GOP-sharded runs; the scene cut that re-encodes a frame is the only thing it replaces
+        missing = ["slice / NAL headers around the payload (the product is slice_data(); x264hip_nal_encode wraps it)"]
+        flagset = ("MED (BASELINE.md) + --pre-scenecut on both sides: the pre-encode scene cut instead of the one that re-encodes a frame -- what the reference does itself with "
+                   "--threads > 1")
         line = {
             "metric": metric,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": what, "matches_baseline": False, "missing": missing,
+            "config": {"workload": what, "matches_baseline": False, "flag_set": flagset, "missing": missing + ["the step-less scheduler is an experiment: the default run is --async 0"],
                        "baseline_metric": "encoded frames/sec, 1080p preset=medium, 1/2/4/8 MI355X (bit-exact)",
                        "frames_per_step": chains_total, "frames_in_flight": chains_total, "keyint": args.keyint,
                        "per_chain_fps": round(fps / chains_total, 4),
@@ -550,6 +608,9 @@ def main():
                     "synthetic clip decide alike for their first frames, so they finish together anyway and the scheduler only adds launches (DESIGN.md 3.3)")
     ap.add_argument("--drift", type=int, default=2, help="--async 1: pictures a chain may be ahead of the slowest one (each costs a lookahead slot per chain)")
     ap.add_argument("--launches", type=int, default=12, help="--async 1: launches in flight (streams)")
+    ap.add_argument("--pcie", type=int, default=0, help="stream mode (steps): 1: every step also moves what a host-fed encoder would move over PCIe, beside the kernels on a stream of its "
+                    "own -- one I420 picture per chain up (x264hip_picture_upload_async from pinned memory into a scratch picture; the content that is coded still comes from the device "
+                    "generator) and every chain's payload buffer down -- so that value becomes the PCIe-inclusive rate (DESIGN.md 6; never the default)")
     ap.add_argument("--b-cus", type=int, default=0, help="stream mode (steps): compute units [0, N) for the step's B kernel, the rest for its I / P kernel (0: both everywhere)")
     ap.add_argument("--pipeline", type=int, default=1, help="stream mode: 1: every step prepares the next step's lookahead (picture in, costs, decisions) beside its own sweep, on a stream "
                     "of its own -- the lookahead's kernels and the host's work fill the time the step's P chains run on after its B chains; 0: one after the other")

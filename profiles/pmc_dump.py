@@ -12,6 +12,9 @@ for did, cn, val, dur, name, gx in c.execute("select dispatch_id, counter_name, 
     acc[did][cn] = val
     acc[did]["duration_ms"] = dur / 1e6
     # which instantiation: ...ELb<BS>ELb<TD>ELb<RF>ELb<CH>EEv -- B kernels have BS = 1
-    acc[did]["kernel"] = "k_look_cost" if "look_cost" in name else ("B" if "ELb1ELb1ELb1ELb0ELb1EEv" in name or "ELb1ELb1ELb0ELb0" in name else "IP") + (" table" if name.endswith("ELb1EEv6SwArgs6SwRefs4SwRdPK6SwDesc") else "")
+    short = name.split("(")[0].replace("void ", "")
+    is_b = "ELb1ELb1ELb1ELb0ELb1EEv" in name or "<2, false, true, true, " in name           # k_slice_sweep<WPE, LL, RD, BS = true, ...>
+    acc[did]["kernel"] = short if "k_slice_sweep" not in name else ("k_slice_sweep B" if is_b else "k_slice_sweep I/P") + (" (chain table)" if "true>" in short or name.rstrip().endswith("SwDesc") else "")
+    acc[did]["name"] = short
     acc[did]["waves"] = gx // 64 if gx else None
 print(json.dumps([dict(dispatch=d, **acc[d]) for d in sorted(acc)], indent=1))

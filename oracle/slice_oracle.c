@@ -1552,11 +1552,6 @@ static void analyse_mb(ssl *S, smb *m, panalysis *A)
                 intra_rd(S, m, A, satd_inter * 5 / 4);
                 m->type = keep;
             }
-            if (getenv("X264O_DBG_MB") && atoi(getenv("X264O_DBG_MB")) == m->mb && S->f == atoi(getenv("X264O_DBG_F")))
-                fprintf(stderr, "dbg mb %d: satd_inter %d i_cost %d part %d type %d rd16 %d c16x8 %d c8x16 %d c8x8 %d sub %d %d %d %d | me8 cost %d %d %d %d subcosts %d %d %d / %d %d %d / %d %d %d / %d %d %d | i16 %d i8 %d i4 %d t8 %d\n", m->mb, satd_inter, i_cost, part, m->type, A->rd16, A->cost16x8, A->cost8x16, A->cost8x8,
-                        A->sub[0], A->sub[1], A->sub[2], A->sub[3], A->me8[0].cost, A->me8[1].cost, A->me8[2].cost, A->me8[3].cost,
-                        A->cost_sub[0][0], A->cost_sub[0][1], A->cost_sub[0][2], A->cost_sub[1][0], A->cost_sub[1][1], A->cost_sub[1][2], A->cost_sub[2][0], A->cost_sub[2][1], A->cost_sub[2][2], A->cost_sub[3][0], A->cost_sub[3][1], A->cost_sub[3][2],
-                        m->satd_i16, m->satd_i8, m->satd_i4, m->t8);
             int itype = S_I_16x16, icost = m->satd_i16;
             if (m->satd_i8 < icost) { icost = m->satd_i8; itype = S_I_8x8; }
             if (m->satd_i4 < icost) { icost = m->satd_i4; itype = S_I_4x4; }

@@ -37,11 +37,12 @@ def test_lookahead_struct_sizes_match_header():
     """The ctypes mirrors of the round-3 structures (x264_vs2008_amd/lookahead.py, stream.py) against the C headers."""
     from x264_vs2008_amd import lookahead as LA
     from x264_vs2008_amd import stream as ST
+    from x264_vs2008_amd import slice as SL
     prog = r'''
 #include <stdio.h>
 #include "x264hip_lookahead.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead_params), sizeof(x264hip_look_need), sizeof(x264hip_look_frame),
- sizeof(x264hip_look_slot), sizeof(x264hip_look_task), sizeof(x264hip_look_params), sizeof(x264hip_chain_sweep)); return 0; }
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead_params), sizeof(x264hip_look_need), sizeof(x264hip_look_frame),
+ sizeof(x264hip_look_slot), sizeof(x264hip_look_task), sizeof(x264hip_look_params), sizeof(x264hip_chain_sweep), sizeof(x264hip_cavlc_params)); return 0; }
 '''
     exe = os.path.join(ROOT, "tests", "_sizes2.bin")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog.encode(), check=True)
@@ -50,7 +51,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead
     finally:
         os.remove(exe)
     want = [C.sizeof(LA.LookaheadParams), C.sizeof(LA.Need), C.sizeof(LA.Frame), C.sizeof(LA.LookSlot), C.sizeof(LA.LookTask), C.sizeof(LA.LookParams),
-            C.sizeof(ST.ChainSweep)]
+            C.sizeof(ST.ChainSweep), C.sizeof(SL.CavlcParams)]
     assert got == want, (got, want)
 
 

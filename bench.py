@@ -58,8 +58,9 @@ CAPTURE = 1 << 20          # bytes of chain 0's payload copied out per step for 
 
 
 def analysis_options(args):
+    cif = getattr(args, "cif", False)              # BASELINE config 0: --no-cabac --no-deblock (the UF flag set)
     return dict(qp=args.qp, me_method=args.me, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
-                chroma_me=1, cabac=1, deblock=1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8,
+                chroma_me=1, cabac=0 if cif else 1, deblock=0 if cif else 1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8,
                 mixed_refs=args.mixed_refs)
 
 
@@ -95,14 +96,14 @@ def _cpu_chain(job):
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
     t0 = _t.perf_counter()
     if os.path.exists(ref_so):
-        out = rs.run_reference2(p, rs.make_ext(**ekw), y, u, v) if raster else rs.run_reference(p, y, u, v)
+        out = rs.run_reference2(p, rs.make_ext(**ekw), y, u, v) if raster or not kw["cabac"] else rs.run_reference(p, y, u, v)
         kind = "reference"
     else:
         lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         out = rs.run2(lib, "x264o_encode_chain2", p, rs.make_ext(**ekw), y, u, v) if raster else rs.run(lib, "x264o_encode_chain", p, y, u, v)
         kind = "port"
     spent = _t.perf_counter() - t0
-    pays = [bytes(out["payload"][f, :int(out["payload_len"][f])]) for f in range(n)] if want_payload and raster else None
+    pays = [bytes(out["payload"][f, :int(out["payload_len"][f])]) for f in range(n)] if want_payload and (raster or not kw["cabac"]) else None
     return spent, kind, pays
 
 
@@ -570,7 +571,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="independent GOP chains advanced per step on each GPU; 0: 2048 (8 wavefronts on each of the 256 CUs) for the raster "
                     "variant (one wavefront per chain, all resident: what its LDS and registers allow), 512 with --preset uhd, 240 with --wavefront 1")
     ap.add_argument("--strong", type=int, default=0, help="1: --batch is the total number of chains of the job, spread round-robin over the ranks (strong scaling: total work fixed)")
-    ap.add_argument("--preset", default="hd", choices=["hd", "uhd", "slow"], help="hd: BASELINE config 1 (1920x1080, hex); uhd: config 2 (3840x2160, --me umh); slow: config 4's flag set on "
+    ap.add_argument("--preset", default="hd", choices=["hd", "uhd", "slow", "cif"], help="cif: BASELINE config 0 (352x288, the UF flag set: --qp 26 --no-cabac --me dia --subme 0 --partitions none "
+                    "--no-deblock --ref 1 --bframes 0, lock-step I / P chains in the wavefront variant, payload from the CAVLC writer, parity-checked); "
+                    "hd: BASELINE config 1 (1920x1080, hex); uhd: config 2 (3840x2160, --me umh); slow: config 4's flag set on "
                     "one GPU (1920x1080, --ref 5 --b-adapt 2 --me umh --subme 8, --direct spatial --pre-scenecut as BASELINE.md prescribes for sharded runs)")
     ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
     ap.add_argument("--trellis", type=int, default=1)
@@ -620,6 +623,14 @@ def main():
     ap.add_argument("--b-adapt", type=int, default=1)
     ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold of the pre-encode scene cut (--pre-scenecut)")
     args = ap.parse_args()
+    args.cif = args.preset == "cif"
+    if args.cif:
+        args.wavefront, args.stream, args.subme_zero = 1, 0, True
+        args.width, args.height = args.width or 352, args.height or 288
+        args.me = 0 if args.me < 0 else args.me
+        args.refs, args.inter, args.intra, args.dct8, args.mixed_refs, args.bframes = 1, 0, 0, 0, 0, 0
+        args.keyint = args.keyint or 250
+        args.batch = args.batch or 2048
     wf = bool(args.wavefront)
     uhd, slow = args.preset == "uhd", args.preset == "slow"
     if slow:
@@ -635,7 +646,7 @@ def main():
     if args.stream and wf:
         raise SystemExit("bench.py: --stream needs the raster variant")
     args.batch = args.batch or (240 if wf else 512 if uhd else 1024 if slow else 2048)
-    args.subme = args.subme or (5 if wf else 7)
+    args.subme = 0 if args.cif else (args.subme or (5 if wf else 7))
     args.keyint = args.keyint or (24 if wf else 250 if args.stream else 12)
     args.payload_cap = args.payload_cap or ((4 << 20) if uhd else (1 << 20))
     if wf:
@@ -687,7 +698,7 @@ def main():
     hip = L.load(local % ndev)                       # one rank per GPU; wraps only when rehearsing on fewer GPUs
     # the raster variant's product is the payload: no coefficient-level arrays in the states, and a payload buffer sized for the
     # content (the sweep stops with an error, never writes past it, if a chain's slice does not fit)
-    ropt = {} if wf else dict(write=1, levels=False, payload_cap=args.payload_cap, **gpu_options(args))
+    ropt = (dict(write=1) if args.cif else {}) if wf else dict(write=1, levels=False, payload_cap=args.payload_cap, **gpu_options(args))
     if args.stream:
         return run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_pays, delay)
     enc = sl.ChainEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, **analysis_options(args), **ropt)      # quantiser tables: x264hip_cqm_init (flat matrices)
@@ -704,8 +715,8 @@ def main():
 
     # chain 0's payload of every step, copied out behind the step's sweep into pinned memory (no synchronisation in the loop)
     hip.x264hip_host_alloc.restype = C.c_void_p
-    check = ref_pays is not None and not wf
-    cap_n = min(CAPTURE, args.payload_cap - sl.PAYLOAD_LEAD)
+    check = ref_pays is not None and (not wf or args.cif)
+    cap_n = min(CAPTURE, (enc.payload_cap if args.cif else args.payload_cap) - sl.PAYLOAD_LEAD)
     pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
 
     def one_step(k):
@@ -804,7 +815,13 @@ def main():
         frame_bytes = px * (1.5 + 4.5 * args.refs + 1.5 + 3.0 + 4.0)       # + deblock read/write + hpel planes
         n_i = sum(1 for e in enc.events if e[2] == sl.SLICE_I)
         size = "%dp" % args.height
-        if wf:
+        if args.cif:
+            metric = "encoded frames/sec, 352x288, the ultrafast flag set of BASELINE config 0 (--qp 26 --no-cabac --me dia --subme 0 --partitions none --no-deblock --ref 1), CAVLC payload on the GPU (bit-exact)"
+            what = ("%dx%d I / P chains through the reference's per-macroblock loop on the GPU (wavefront schedule) and the CAVLC writer (x264hip_cavlc_write_frame) behind every sweep: "
+                    "dia ME range 16, subme 0, 1 ref, no partitions, no deblock, CQP %d, keyint %d" % (args.width, args.height, args.qp, args.keyint))
+            missing = ["slice / NAL headers around the payload"]
+            par = "B chains per GPU in every launch (one wavefront per macroblock row per chain, then one wavefront per chain for the CAVLC pass); chains shard across GPUs with no data-path collective"
+        elif wf:
             metric = "I/P macroblock-loop frames/sec, %s, medium minus {B-frames, RD (subme 7 -> 5), trellis, AQ, entropy coding} (round-1 configuration, bit-exact)" % size
             what = ("%dx%d I/P chains through the reference's per-macroblock loop on the GPU, wavefront schedule (one wavefront per macroblock row): "
                     "%s ME range 16, subme %d, %d refs, chroma ME, fast P-skip, dct-decimate, CQP %d, keyint %d; analyse.inter 0x%x intra 0x%x 8x8dct %d "

@@ -42,11 +42,12 @@ def run_stream(hip_lib, cs, pipeline=False):
         for b, (y, u, v) in enumerate(clips):
             enc.src_ctx.upload(pic, y[f], u[f], v[f], b=b)
 
-    fed = 0
-    for _ in range(4 * frames + 8):
+    fed, idle = 0, 0
+    for _ in range(4 * frames + 40):
         coded = enc.step(fill if fed < frames else None)
         fed += fed < frames
-        if not coded and fed >= frames and enc.flushing:
+        idle = 0 if coded else idle + (fed >= frames and enc.flushing)
+        if idle >= 2:                                    # (a clip shorter than the lookahead's delay is coded by the flush alone)
             break
         if coded:
             enc.sync()
@@ -155,3 +156,31 @@ def test_stream_equals_reference_live(hip_lib, name):
     got = run_stream(hip_lib, cs)
     for i, c in enumerate(cs):
         check(got[i], K.reference_records(c), c, "%s chain %d" % (name, i))
+
+
+def random_config(seed):
+    """A seeded encoder configuration over what the stream path accepts, on top of look_cases.config's clip and lookahead options."""
+    r = np.random.default_rng(91000 + seed)
+    c = K.config(seed)
+    subme = int(r.choice([2, 4, 5, 6, 7, 7, 8]))
+    c.update(w=16 * int(r.integers(5, 10)), h=16 * int(r.integers(5, 8)), frames=int(r.integers(8, 13)), subme=subme,
+             n_refs=int(r.integers(1, 4)), mixed_refs=int(r.random() < 0.5), inter=int(r.choice([0x13, 0x11, 0x10, 0x33])) if subme < 6 else int(r.choice([0x13, 0x11, 0x10])),
+             trellis=int(r.choice([0, 1, 2])), psy_rd=float(r.choice([0.0, 1.0])), direct_pred=int(r.choice([1, 1, 2])), chroma_me=int(r.random() < 0.7),
+             pre_scenecut=1, scenecut_threshold=int(r.choice([40, -1])), qp=int(r.integers(18, 36)))
+    return c
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", list(range(14)))
+def test_stream_random_configuration_equals_reference(hip_lib, seed):
+    """Seeded option sets (references, partitions, subme 2..8, trellis, psy-rd, AQ, weightb, spatial / temporal direct, b-adapt 0 / 1 / 2, CQP / CRF,
+    scene cuts, keyint) through the StreamEncoder, two chains with different clips, against the reference's whole encoder."""
+    c = random_config(seed)
+    cs = []
+    for k in range(2):
+        ck = dict(c)
+        ck.update(t0=c["t0"] + 61 * k, slow=[c["slow"], 1 + (c["slow"] % 3)][k])
+        cs.append(ck)
+    got = run_stream(hip_lib, cs, pipeline=bool(seed & 1))
+    for i, ck in enumerate(cs):
+        check(got[i], K.reference_records(ck), ck, "seed %d chain %d %s" % (seed, i, {k: ck[k] for k in ("subme", "n_refs", "bframes", "b_adapt", "crf", "trellis", "direct_pred", "aq", "inter")}))

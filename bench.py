@@ -179,6 +179,35 @@ def cpu_baseline(args, g_total):
                       % (n, args.width, args.height, spent1, cores, cores, spent_all, ", entropy coding included" if raster else ", no entropy coding on either side")}, pays
 
 
+def stream_bytes_per_chain(args, delay):
+    """What one stream keeps in HBM (x264_vs2008_amd/stream.py): the lookahead's ring of slots (source + lowres planes, vectors and their costs for both
+    lists and every distance, intra costs, AQ), the DPB's pictures with their half-pel planes + one being written, their states, the payload buffer."""
+    al = lambda v, a: (v + a - 1) // a * a
+    w16, h16 = al(args.width, 16), al(args.height, 16)
+    sy = al(w16 + 64, 16)
+    y, c = sy * (h16 + 65), al(sy // 2, 16) * (h16 // 2 + 33)
+    low = al(w16 // 2 + 64, 16) * (h16 // 2 + 65)
+    n = (w16 // 16) * (h16 // 16)
+    bf = args.bframes
+    slot = y + 2 * c + 4 * low + n * 2 * (bf + 1) * 8 + n * 4 + (n * 8 if args.aq_mode else 0)
+    dpb = max(args.refs, 2 if bf else 1)
+    return (delay + bf + 3) * slot + (dpb + 1) * (4 * y + 2 * c + n * 440) + args.payload_cap + n * 4
+
+
+def fit_batch(args, hip, B, delay):
+    """The chains that fit: a run that dies of a failed allocation measures nothing.  Leaves 5 % of the free memory alone."""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    if hip.x264hip_mem_info(C.byref(free), C.byref(total)) != 0:
+        return B
+    per = stream_bytes_per_chain(args, delay)
+    fit = int(0.95 * free.value // per)
+    if fit >= B:
+        return B
+    fit = max(64, fit // 64 * 64)
+    print("bench.py: %d streams need %.0f GB, %.0f GB of HBM are free: running %d" % (B, B * per / 1e9, free.value / 1e9, fit), file=sys.stderr)
+    return fit
+
+
 def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_recs, delay):
     """The default: every chain is a stream of its own through the whole encoder.  A step = one x264_encoder_encode call per chain: a
     picture comes in (synthesised on the device into the lookahead's slot; lowres planes, intra costs, AQ offsets follow), the
@@ -700,6 +729,8 @@ def main():
     # content (the sweep stops with an error, never writes past it, if a chain's slice does not fit)
     ropt = (dict(write=1) if args.cif else {}) if wf else dict(write=1, levels=False, payload_cap=args.payload_cap, **gpu_options(args))
     if args.stream:
+        if not args.strong:
+            B = fit_batch(args, hip, B, delay)
         return run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, ref_pays, delay)
     enc = sl.ChainEncoder(hip, args.width, args.height, cqm_init(hip), batch=B, **analysis_options(args), **ropt)      # quantiser tables: x264hip_cqm_init (flat matrices)
     ctx = enc.ctx

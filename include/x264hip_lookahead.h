@@ -59,8 +59,9 @@ int x264hip_frame_ctx_elements(x264hip_frame_ctx *c, const int *elems_dev, int n
 
 
 /* The CAVLC writer: x264_macroblock_write_cavlc + x264_slice_write's skip runs (R/encoder/cavlc.c:60-620, R/encoder/encoder.c:1200-1280) for
- * every chain's I or P slice, as a pass over the state x264hip_slice_sweep_frame left (a `--no-cabac` slice is the wavefront variant's:
- * constant QP, decisions and coefficient levels in the x264hip_mb_state -- allocate it WITH level arrays).  payload: device
+ * every chain's I or P slice, as a pass over the state x264hip_slice_sweep_frame left (a `--no-cabac` slice below the RD levels: the wavefront
+ * variant at constant QP, or the raster variant without its writer when adaptive quantisation gives every macroblock its QP; decisions and
+ * coefficient levels in the x264hip_mb_state -- allocate it WITH level arrays).  payload: device
  * [batch][payload_cap] bytes, chain b's slice_data() starts X264HIP_PAYLOAD_LEAD (64) bytes into its slot, from bit 0, rbsp trailing bits
  * included; payload_len: device [batch] int32; mb_bits (optional): device [batch][n_mb], bit position after every macroblock.
  * Asynchronous on the context's stream.  I_PCM macroblocks and a slot too small end with x264hip_slice_sweep_status reporting an abort. */
@@ -71,6 +72,7 @@ typedef struct {
     int transform8x8;          /* pps->b_transform_8x8_mode */
     int cqm_custom;            /* param.i_cqm_preset != FLAT (High profile: level escapes beyond prefix 15) */
     uint8_t *payload; int payload_cap; int32_t *payload_len; int32_t *mb_bits;
+    int slice_qp;              /* h->sh.i_qp: what mb_qp_delta of the first coded macroblock is relative to (per-macroblock QPs: the state's qp array) */
 } x264hip_cavlc_params;
 int x264hip_cavlc_write_frame(x264hip_frame_ctx *c, const x264hip_mb_state *st, const x264hip_cavlc_params *p);
 

@@ -25,19 +25,27 @@ CONFIGS = {
     "p_no_sub8x8_umh": dict(w=176, h=144, n=5, kw=dict(qp=31, me_method=rs.ME_UMH, subme=4, n_refs=2, inter=0x13, intra=0x3, transform8x8=1, cabac=0, deblock=1)),
     "intra_low_qp": dict(w=144, h=112, n=4, kw=dict(qp=12, me_method=rs.ME_HEX, subme=2, n_refs=1, inter=0x11, intra=0x3, transform8x8=1, cabac=0, deblock=1, keyint=2)),
     "high_qp_skips": dict(w=192, h=128, n=6, kw=dict(qp=40, me_method=rs.ME_HEX, subme=3, n_refs=2, inter=0x11, intra=0x1, cabac=0, deblock=1)),
+    # adaptive quantisation: the raster variant without its writer leaves each macroblock's final QP (x264_macroblock_cache_save's rules and
+    # cavlc_qp_delta's empty-I_16x16 one) in the state, the pass codes mb_qp_delta from it
+    "aq_p_partitions": dict(w=208, h=144, n=6, ext=dict(aq_mode=1, aq_strength=1.0),
+                            kw=dict(qp=28, me_method=rs.ME_HEX, subme=5, n_refs=2, inter=0x33, intra=0x3, transform8x8=1, mixed_refs=1, cabac=0, deblock=1)),
+    "aq_strong_high_qp": dict(w=192, h=128, n=6, ext=dict(aq_mode=1, aq_strength=1.8),
+                              kw=dict(qp=38, me_method=rs.ME_UMH, subme=3, n_refs=1, inter=0x11, intra=0x3, cabac=0, deblock=1, keyint=4)),
+    "aq_intra_qp_clip": dict(w=144, h=112, n=4, ext=dict(aq_mode=1, aq_strength=2.5),
+                             kw=dict(qp=47, me_method=rs.ME_HEX, subme=1, n_refs=1, inter=0x11, intra=0x3, transform8x8=1, cabac=0, deblock=1, keyint=2)),
 }
 
 
 def reference(c, t0=0):
     y, u, v = rs.clip(c["w"], c["h"], c["n"], t0)
-    a = rs.run_reference2(rs.make_params(c["w"], c["h"], c["n"], **c["kw"]), rs.make_ext(write=1), y, u, v)
+    a = rs.run_reference2(rs.make_params(c["w"], c["h"], c["n"], **c["kw"]), rs.make_ext(write=1, **c.get("ext", {})), y, u, v)
     return (y, u, v), [bytes(a["payload"][f, :a["payload_len"][f]]) for f in range(c["n"])], a
 
 
 def encode(hip_lib, c, clip):
     y, u, v = clip
-    enc = sl.ChainEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), write=1, **c["kw"])
-    assert enc.cavlc and not enc.raster
+    enc = sl.ChainEncoder(hip_lib, c["w"], c["h"], cqm_init(hip_lib), write=1, **c["kw"], **c.get("ext", {}))
+    assert enc.cavlc and enc.raster == ("ext" in c)
     out = []
     try:
         for f in range(c["n"]):

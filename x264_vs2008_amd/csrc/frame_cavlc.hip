@@ -53,6 +53,7 @@ struct CvArgs {
     const signed char *mb_type, *partition, *sub_partition, *ref, *i4mode, *i16mode, *chroma_mode, *t8;
     const i16 *mv, *cbp, *luma, *luma_dc, *chroma_dc, *chroma_ac;
     const u8 *nnz;
+    const signed char *qp; int slice_qp;
     u8 *payload; int payload_cap; int *payload_len, *mb_bits; int *abort_flag;
     int mb_w, mb_h, slice_type, n_ref0, psub8x8, t8_mode, profile_high;
 };
@@ -63,7 +64,8 @@ __device__ int cv_residual(CvBs &b, const i16 *l, int count, int nc_class, bool 
     int last = count - 1;
     while (last >= 0 && l[last] == 0) last--;
     if (last < 0) { cv_vlc(b, c_cv_coeff0[nc_class]); return 0; }
-    int level[16], run[16], total = 0, i_last = last;
+    __shared__ int level[16], run[16];                                       // lane 0 is the only one here: its work arrays live in LDS, not scratch
+    int total = 0, i_last = last;
     do {
         int r = 0;
         level[total] = l[i_last];
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
     u8 *out = a.payload + (size_t)bz * a.payload_cap + 64;
     CvBs b = {out, 0ull, 0};
     const u8 *limit = out + a.payload_cap - 64 - 1024;
-    int skip_run = 0;
+    int skip_run = 0, last_qp = a.slice_qp;                                  // h->mb.i_last_qp (x264_slice_write starts it at the slice's QP)
     const bool is_p = a.slice_type == 0;
     for (int mb = 0; mb < n; mb++) {
         const int mbx = mb % a.mb_w, mby = mb / a.mb_w;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
         if (b.p > limit || type == CV_I_PCM || type > CV_P_SKIP) { atomicAdd(a.abort_flag, 1); a.payload_len[bz] = 0; return; }
         if (type == CV_P_SKIP) {
             skip_run++;
+            last_qp = a.qp[M];                                                 // x264_macroblock_cache_save: every macroblock leaves its QP (a skipped one: the previous)
             for (int k = 0; k < 8; k++) { tn[k] = 0; s_left_nnz[k] = 0; }
             if (a.mb_bits) a.mb_bits[M] = (int)((b.p - out) * 8 + b.n);
             continue;
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
             cv_ue(b, (u32)(cm < 4 ? cm : 0));
         } else {
             // P_L0 / P_8x8: the motion cache of x264_macroblock_cache_load (scan8 layout, 5 rows x 8), then x264_mb_predict_mv per partition
-            signed char cref[40];
-            int cmvx[40], cmvy[40];
+            __shared__ signed char cref[40];
+            __shared__ int cmvx[40], cmvy[40];
             for (int k = 0; k < 40; k++) { cref[k] = -2; cmvx[k] = cmvy[k] = 0; }
             auto load_nb = [&](size_t Mn, int pos, int bx, int by) {          // neighbour macroblock's 4x4 block (bx, by) -> cache position
                 const int tn_ = a.mb_type[Mn];
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
         }
         // ---- residual ----
         // the nnz cache of this macroblock in scan8 layout: neighbours' totals (0x80: none), own totals as they are written
-        u8 cn[48];
+        __shared__ u8 cn[48];
         for (int k = 0; k < 48; k++) cn[k] = 0;
         for (int k = 0; k < 4; k++) { cn[4 + k] = has_top ? tn[k] : 0x80; cn[11 + 8 * k] = has_left ? s_left_nnz[k] : 0x80; }
         for (int k = 0; k < 2; k++) {
@@ -287,7 +290,12 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
             return r < 2 ? 0 : r < 4 ? 1 : r < 8 ? 2 : 3;
         };
         const bool coded = type == CV_I_16x16 || cbp_luma || cbp_chroma;
-        if (coded) cv_se(b, 0);                                                // cavlc_qp_delta: constant QP here
+        if (coded) {                                                           // cavlc_qp_delta: the state's QP already has the rules applied (an empty I_16x16 took the previous one)
+            int dqp = a.qp[M] - last_qp;
+            if (dqp < -26) dqp += 52; else if (dqp > 25) dqp -= 52;
+            cv_se(b, dqp);
+        }
+        last_qp = a.qp[M];
         const i16 *ly = a.luma + M * 256;
         if (type == CV_I_16x16) {
             cv_residual(b, a.luma_dc + M * 16, 16, nc_of(0), false, a.profile_high);
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(64) void k_cavlc_write(CvArgs a)
                 if (!(cbp_luma >> i8 & 1)) continue;
                 for (int i4 = 0; i4 < 4; i4++) {
                     const int i = 4 * i8 + i4;
-                    i16 blk[16];
+                    __shared__ i16 blk[16];
                     if (t8) for (int j = 0; j < 16; j++) blk[j] = ly[64 * i8 + i4 + 4 * j];        // zigzag_interleave_8x8_cavlc
                     else for (int j = 0; j < 16; j++) blk[j] = ly[16 * i + j];
                     cn[cv_scan8(i)] = (u8)cv_residual(b, blk, 16, nc_of(i), false, a.profile_high);
@@ -335,6 +343,7 @@ extern "C" int x264hip_cavlc_write_frame(x264hip_frame_ctx *c, const x264hip_mb_
     a.mb_type = (const signed char *)st->mb_type; a.partition = (const signed char *)st->partition; a.sub_partition = (const signed char *)st->sub_partition;
     a.ref = (const signed char *)st->ref; a.i4mode = (const signed char *)st->i4mode; a.i16mode = (const signed char *)st->i16mode;
     a.chroma_mode = (const signed char *)st->chroma_mode; a.t8 = (const signed char *)st->t8;
+    a.qp = (const signed char *)st->qp; a.slice_qp = p->slice_qp;
     a.mv = st->mv; a.cbp = st->cbp; a.luma = st->luma; a.luma_dc = st->luma_dc; a.chroma_dc = st->chroma_dc; a.chroma_ac = st->chroma_ac; a.nnz = st->nnz;
     a.payload = p->payload; a.payload_cap = p->payload_cap; a.payload_len = p->payload_len; a.mb_bits = p->mb_bits;
     a.abort_flag = st->progress + (size_t)c->d.mb_h * c->batch;

@@ -2573,6 +2573,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
                     return;
                 }
                 if (!IS_SKIP_T(type)) mb_qp = UNI(sr.tmp_i[1]);
+            } else if (!a.cabac && type == T_I_16x16 && !(cbp_luma | cbp_chroma) && !UNI((int)s.nnz[24])) {
+                // a CAVLC slice is written after the sweep (x264hip_cavlc_write_frame), but cavlc_qp_delta's side effect belongs here: an I_16x16
+                // macroblock without any coefficient takes the previous QP (R/encoder/cavlc.c:205-211), which the next macroblock's QP rule reads
+                mb_qp = last_qp;
             }
             // x264_macroblock_cache_save's QP rules (R/common/macroblock.c:1244-1272): a macroblock without coefficients has no QP of its own
             if (type == T_I_PCM) { mb_qp = 0; last_dqp = 0; if (lane < 27) s.nnz[lane] = 16; WAVE_SYNC(); }

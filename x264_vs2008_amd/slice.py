@@ -49,7 +49,7 @@ class SliceRd(C.Structure):
 class CavlcParams(C.Structure):
     """x264hip_cavlc_params (include/x264hip_lookahead.h)"""
     _fields_ = [("slice_type", C.c_int), ("n_ref0", C.c_int), ("analyse_inter", C.c_int), ("transform8x8", C.c_int), ("cqm_custom", C.c_int),
-                ("payload", C.c_void_p), ("payload_cap", C.c_int), ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p)]
+                ("payload", C.c_void_p), ("payload_cap", C.c_int), ("payload_len", C.c_void_p), ("mb_bits", C.c_void_p), ("slice_qp", C.c_int)]
 
 
 PAYLOAD_LEAD = 64
@@ -142,10 +142,11 @@ class ChainEncoder:
         aq_mode = 0 if aq_strength == 0 else min(max(aq_mode, 0), 1)
         # the raster-order variant of the sweep: needed by the RD levels, trellis, adaptive quantisation, or simply to get the payload
         # a CAVLC slice's payload is written by a pass over the state the sweep leaves (x264hip_cavlc_write_frame): CAVLC has no adaptive
-        # state, so it needs no place in the macroblock loop and the wavefront variant stays the one that codes such slices
-        self.cavlc = bool(write and not cabac and subme < 6 and not trellis and not aq_mode and not bframes)
+        # state, so it needs no place in the macroblock loop and the wavefront variant stays the one that codes such slices (with adaptive
+        # quantisation: the raster variant without its writer, whose QP rules leave every macroblock's final QP in the state)
+        self.cavlc = bool(write and not cabac and subme < 6 and not trellis and not bframes)
         self.raster = bool(subme >= 6 or trellis or aq_mode or (write and not self.cavlc)) if raster is None else bool(raster)
-        self.rd_opt = dict(trellis=trellis, aq_mode=aq_mode, aq_strength=aq_strength, write=int(bool(write or subme >= 6 or trellis)),
+        self.rd_opt = dict(trellis=trellis, aq_mode=aq_mode, aq_strength=aq_strength, write=int(bool((write and not self.cavlc) or subme >= 6 or trellis)),
                            cabac_init_idc=cabac_init_idc, qp_min=qp_min, qp_max=qp_max)
         self.lossless = int(qp == 0)
         if self.lossless:              # x264_validate_parameters, R/encoder/encoder.c:401-421
@@ -186,6 +187,8 @@ class ChainEncoder:
             rb["stale"] = DeviceArray(lib, (B, 8), np.int16)
             self.rd_bufs = rb
             self.payload_cap = cap
+        if self.cavlc and not levels:
+            raise ValueError("CAVLC payloads are written from the coefficient levels: levels=False does not go with cabac=0, write=1")
         if self.cavlc and not self.raster:
             if not levels:
                 raise ValueError("CAVLC payloads are written from the coefficient levels: levels=False does not go with cabac=0, write=1")
@@ -344,10 +347,11 @@ class ChainEncoder:
         if ev:
             L.x264hip_event_record(C.c_void_p(ev[1]), C.c_void_p(c.stream))
             self.events.append((ev[0], ev[1], stype, len(refs) + len(refs1)))
-        if self.cavlc and not self.raster:             # x264_macroblock_write_cavlc for every macroblock of every chain, from the state just written
+        if self.cavlc:                                 # x264_macroblock_write_cavlc for every macroblock of every chain, from the state just written
             rb = self.rd_bufs
             cp = CavlcParams(slice_type=stype, n_ref0=len(refs), analyse_inter=o["inter"], transform8x8=o["transform8x8"], cqm_custom=0,
-                             payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr)
+                             payload=rb["payload"].ptr, payload_cap=self.payload_cap, payload_len=rb["payload_len"].ptr, mb_bits=rb["mb_bits"].ptr,
+                             slice_qp=qp)
             c.check(L.x264hip_cavlc_write_frame(c.h, C.byref(state.st), C.byref(cp)), "cavlc_write_frame")
             self.last_bufs = rb
         if self.nr:                            # x264_noise_reduction_update at the end of every frame (R/encoder/encoder.c:1755)

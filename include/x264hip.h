@@ -473,7 +473,9 @@ int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x2
  * lacks; the caller computes them (x264hip_lookahead_cost_frames on the GPU for all its chains at once), hands the results back with
  * x264hip_lookahead_set_cost and calls get again.  A cost is a pure function of (b, p0, p1) and the pictures, so the order in which
  * they are computed does not change any of them; get restarts its decision from the unchanged queue every time.
- * Not here: 2-pass, ABR, VBV, zones, B-pyramid, the scene cut that re-encodes (param.b_pre_scenecut = 0 with a threshold >= 0). */
+ * Not here: 2-pass, ABR, VBV, zones, B-pyramid.  With param.b_pre_scenecut = 0 and a threshold >= 0 the queue decides without scene cuts, as the
+ * reference's does; the look x264_encoder_encode then takes at every coded P frame is the caller's (x264hip_stream.h: x264hip_frame_stats +
+ * x264hip_scenecut_post), and the re-encode that follows a hit (frames put back into the queue) is not built: a caller that sees one stops. */
 typedef struct x264hip_lookahead x264hip_lookahead;
 typedef struct {
     int mb_w, mb_h;

@@ -43,3 +43,10 @@ def hip_lib():
     """The product library through its C ABI; fails loudly if it is missing."""
     from x264_vs2008_amd import lib as L
     return L.load()
+
+
+@pytest.fixture(scope="session")
+def hip_lib_host():
+    """The product library opened WITHOUT x264hip_init: only its host-side entries may be called (no GPU needed)."""
+    from x264_vs2008_amd import lib as L
+    return L.open_library()

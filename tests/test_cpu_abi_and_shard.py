@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(L.SO_PATH):
         L.build()
     lib = L.open_library()
-    for header in ("x264hip.h", "x264hip_lookahead.h"):
+    for header in ("x264hip.h", "x264hip_lookahead.h", "x264hip_stream.h"):
         declared = _declared_functions(os.path.join(ROOT, "include", header))
         assert len(declared) > (30 if header == "x264hip.h" else 8)
         missing = [n for n in declared if not hasattr(lib, n)]
@@ -38,11 +38,14 @@ def test_lookahead_struct_sizes_match_header():
     from x264_vs2008_amd import lookahead as LA
     from x264_vs2008_amd import stream as ST
     from x264_vs2008_amd import slice as SL
+    from x264_vs2008_amd import mux as MX
     prog = r'''
 #include <stdio.h>
 #include "x264hip_lookahead.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead_params), sizeof(x264hip_look_need), sizeof(x264hip_look_frame),
- sizeof(x264hip_look_slot), sizeof(x264hip_look_task), sizeof(x264hip_look_params), sizeof(x264hip_chain_sweep), sizeof(x264hip_cavlc_params)); return 0; }
+#include "x264hip_stream.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_lookahead_params), sizeof(x264hip_look_need), sizeof(x264hip_look_frame),
+ sizeof(x264hip_look_slot), sizeof(x264hip_look_task), sizeof(x264hip_look_params), sizeof(x264hip_chain_sweep), sizeof(x264hip_cavlc_params),
+ sizeof(x264hip_encoder_params), sizeof(x264hip_slice_header), sizeof(x264hip_frame_stat)); return 0; }
 '''
     exe = os.path.join(ROOT, "tests", "_sizes2.bin")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog.encode(), check=True)
@@ -51,7 +54,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(x264hip_looka
     finally:
         os.remove(exe)
     want = [C.sizeof(LA.LookaheadParams), C.sizeof(LA.Need), C.sizeof(LA.Frame), C.sizeof(LA.LookSlot), C.sizeof(LA.LookTask), C.sizeof(LA.LookParams),
-            C.sizeof(ST.ChainSweep), C.sizeof(SL.CavlcParams)]
+            C.sizeof(ST.ChainSweep), C.sizeof(SL.CavlcParams), C.sizeof(MX.EncoderParams), C.sizeof(MX.SliceHeader), 32]
     assert got == want, (got, want)
 
 

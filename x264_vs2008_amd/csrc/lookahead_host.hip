@@ -442,7 +442,9 @@ void rc_end(LA *la)
 extern "C" x264hip_lookahead *x264hip_lookahead_new(const x264hip_lookahead_params *p)
 {
     if (!p || p->bframes < 0 || p->bframes > BF_MAX || p->mb_w <= 0 || p->mb_h <= 0 || p->keyint_max < 1) return nullptr;
-    if (!p->pre_scenecut && p->scenecut_threshold >= 0) return nullptr;     // the re-encoding scene cut (encoder.c:1640-1700) is not built
+    // pre_scenecut = 0 with a threshold >= 0: the queue then decides without scene cuts, as the reference's does, and x264_encoder_encode looks at
+    // every P frame after coding it (encoder.c:1603-1699).  That look is the caller's (x264hip_frame_stats + x264hip_scenecut_post); what follows
+    // a hit -- the picture coded again as I / IDR, frames put back into this queue -- is not built: the caller must stop there.
     LA *la = (LA *)calloc(1, sizeof(LA));
     if (!la) return nullptr;
     la->p = *p;

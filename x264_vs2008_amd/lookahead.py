@@ -70,8 +70,7 @@ class Lookahead:
         self.params = params
         self.h = lib.x264hip_lookahead_new(C.byref(params))
         if not self.h:
-            raise ValueError("x264hip_lookahead_new refused the parameters (bframes > 16, a scene cut that re-encodes: "
-                             "pre_scenecut = 0 with a threshold >= 0, ...)")
+            raise ValueError("x264hip_lookahead_new refused the parameters (bframes > 16, unknown rate control, ...)")
         self._need = (Need * MAX_NEED)()
         self._n = C.c_int(0)
 

@@ -105,6 +105,15 @@ class StreamEncoder(ChainEncoder):
         self.flushing = False
         self.coded_now = [None] * B
         self.n_sweeps = 0
+        # Without --pre-scenecut the reference looks at every P frame AFTER coding it (x264_encoder_encode, encoder.c:1603-1699) and, if it finds a
+        # scene cut, codes the picture again as I / IDR.  The decision is made here from the sweep's own statistics (x264hip_frame_stats +
+        # x264hip_scenecut_post); the re-encode is not built: status() raises when the reference would have taken it.
+        self.post_scenecut = bool(scenecut_threshold >= 0 and not pre_scenecut)
+        self._post, self.stats_dev = [], None
+        if self.post_scenecut:
+            if o["keyint"] <= 0:
+                raise ValueError("StreamEncoder: the post-encode scene cut needs a finite keyint")
+            self.stats_dev = [DeviceArray(lib, (B, 32), np.uint8) for _ in self.pool]
         self.sweep_events = None       # set to [] to collect (start, stop, chains, algorithmic bytes) HIP events around every step's sweep launches
 
     # ---- one call of x264_encoder_encode for every chain --------------------------------------------------------------------------
@@ -184,6 +193,13 @@ class StreamEncoder(ChainEncoder):
             c.check(L.x264hip_expand_border(c.h, C.byref(recon), 0), "expand_border")
             c.check(L.x264hip_hpel_filter_frame(c.h, C.byref(recon)), "hpel_filter_frame")
         c.check(L.x264hip_frame_ctx_elements(c.h, None, 0), "frame_ctx_elements")
+        if self.post_scenecut:
+            self._post = []
+            for pic_i, chains in filt.items():
+                ps = [ci for ci in chains if self.coded_now[ci].slice_type == SLICE_P]
+                if ps:
+                    c.check(L.x264hip_frame_stats(c.h, C.byref(self.states[pic_i].st), self.stats_dev[pic_i].p), "frame_stats")
+                    self._post += [(pic_i, ci, self.coded_now[ci].frame, self.coded_now[ci].frame - self.c_last_idr[ci]) for ci in ps]
         self._keep = keep
         self.lb.end([ci for ci, _ in todo])
         self.last_bufs, self.last_ctx = rb, c
@@ -273,6 +289,26 @@ class StreamEncoder(ChainEncoder):
         c = self.ctx
         for s in self.states:
             c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(s.st)), "slice_sweep_status")
+        self.check_scenecut()
+
+    def check_scenecut(self):
+        """After sync(): x264_encoder_encode's look at the P frames of the last step (encoder.c:1603-1644).  Raises if the reference would now
+        code one of them again as I / IDR."""
+        if not self._post:
+            return
+        L, d, lp = self.lib, self.ctx.dims, self.la_params
+        L.x264hip_scenecut_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        got = {}
+        for pic_i, ci, frame, gop in self._post:
+            if pic_i not in got:
+                got[pic_i] = self.stats_dev[pic_i].get()
+            rec = np.ascontiguousarray(got[pic_i][ci])
+            if L.x264hip_scenecut_post(rec.ctypes.data_as(C.c_void_p), d.mb_w * d.mb_h, gop, lp.scenecut_threshold, lp.keyint_min, lp.keyint_max):
+                st = rec.view(np.int64)[:2], rec.view(np.int32)[4:]
+                raise RuntimeError("chain %d, input frame %d: the reference's post-encode scene cut fires here (intra / inter cost %d / %d, analysed / I / P / skip "
+                                   "%s) and codes the picture again as I or IDR -- that re-encode is not built: run with pre_scenecut=1" %
+                                   (ci, frame, st[0][0], st[0][1], list(st[1])))
+        self._post = []
 
     def close(self):
         self.sync()
@@ -282,7 +318,7 @@ class StreamEncoder(ChainEncoder):
         for pair in self.aq_slots or []:
             for a in pair:
                 a.free()
-        for a in [self.tab_dev] + self.elems_dev:
+        for a in [self.tab_dev] + self.elems_dev + (self.stats_dev or []):
             a.free()
         if self.tab_host:
             self.lib.x264hip_host_free(C.c_void_p(self.tab_host))
@@ -348,6 +384,8 @@ class AsyncStreamEncoder(StreamEncoder):
         self.prepared = 0                                # pictures prepared on the device (for all chains)
         self.n_launches = 0
         self.launch_sizes = []
+        if self.post_scenecut:
+            raise ValueError("AsyncStreamEncoder: the post-encode scene cut's check is made per step (StreamEncoder); run with pre_scenecut=1")
 
     def _bufs_of(self, ci):
         return self.rd_bufs_alt if self.c_coded[ci] & 1 else self.rd_bufs

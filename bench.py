@@ -3,10 +3,10 @@
 
 DEFAULT (--stream 1): every GPU runs B independent STREAMS (chains), each a segment of ONE long synthetic 1080p clip (SURVEY.md 8(d)'s
 integer generator; chain g's pictures start g * 4096 frames into it), through what x264_encoder_encode does with BASELINE.md's MED flag
-set plus --pre-scenecut:
+set:
 
   --crf 23 --ref 3 --bframes 3 --b-adapt 1 --me hex --subme 7 --8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --weightb
-  --mixed-refs --direct spatial, psy-rd 1.0, aq-mode 1, keyint 250, scenecut 40 (decided before the encode), CABAC, deblock
+  --mixed-refs --direct spatial, psy-rd 1.0, aq-mode 1, keyint 250, scenecut 40 (looked for after every coded P frame), CABAC, deblock
 
 A "step" is one x264_encoder_encode call for every chain (x264_vs2008_amd/stream.py):
 
@@ -21,9 +21,9 @@ A "step" is one x264_encoder_encode call for every chain (x264_vs2008_amd/stream
                                    chains and the B chains of the step side by side; the slice's CABAC payload comes out of the launch
   x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   a kept frame becomes a reference (the elements that coded one)
 
-config.matches_baseline is true for the default run with config.flag_set saying what that means: MED with --pre-scenecut on BOTH sides
-(GPU and the reference leg) -- the pre-encode scene cut, which the reference itself forces with --threads > 1 and BASELINE.md prescribes
-for sharded runs, instead of the one that re-encodes a frame.  PARITY IS CHECKED IN THIS RUN: rank 0's
+config.matches_baseline is true for the default run with config.flag_set saying what that means: MED as BASELINE.md states it -- the
+post-encode scene cut is evaluated after every P frame of every chain (the re-encode after a hit is not built: the run would stop; the
+clip has none); --pre-scenecut 1 decides cuts in the lookahead instead.  PARITY IS CHECKED IN THIS RUN: rank 0's
 chain 0 also goes through the REFERENCE's whole encoder on the host (frame queue, slice-type decision, rate control, slice loop; the
 cpu_baseline leg, before the GPU is touched), and for every frame the GPU side coded for that chain -- warm-up and timed steps alike --
 the input number, slice type, QP and payload bytes must equal the reference's, or the run fails (config.parity_checked_frames).
@@ -61,7 +61,7 @@ def analysis_options(args):
     cif = getattr(args, "cif", False)              # BASELINE config 0: --no-cabac --no-deblock (the UF flag set)
     return dict(qp=args.qp, me_method=args.me, me_range=16, subme=args.subme, n_refs=args.refs, fast_pskip=1, dct_decimate=1,
                 chroma_me=1, cabac=0 if cif else 1, deblock=0 if cif else 1, keyint=args.keyint, inter=args.inter, intra=args.intra, transform8x8=args.dct8,
-                mixed_refs=args.mixed_refs)
+                mixed_refs=args.mixed_refs, mv_range=128 if cif else 0)       # the level x264_validate_parameters picks: 1.3 for CIF (mv range 128), 4.0 for 1080p (512)
 
 
 def rd_options(args):
@@ -232,7 +232,7 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
     pin = hip.x264hip_host_alloc(C.c_size_t(n_coded * (cap_n + 64))) if check else None
     coded0 = []                                          # chain 0's coded frames: (input number, slice type, qp)
     encs = [StreamEncoder(hip, args.width, args.height, cqm_init(hip), batch=sizes[j], crf=args.crf, b_adapt=args.b_adapt, scenecut_threshold=args.scenecut,
-                          pre_scenecut=1, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, n_frames=(delay + n_coded) if args.pipeline else None, b_cus=args.b_cus,
+                          pre_scenecut=args.pre_scenecut, write=1, levels=False, payload_cap=args.payload_cap, qp_min=0, n_frames=(delay + n_coded) if args.pipeline else None, b_cus=args.b_cus,
                           **analysis_options(args), **o) for j in range(G)]
     d = encs[0].ctx.dims
     px = d.mb_w * 16 * d.lines_y
@@ -390,22 +390,28 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         total = sum(ksum.values())
         tasks = sum(e.look.n_tasks_run for e in encs) - tasks0
         rounds = sum(e.lb.rounds for e in encs) - rounds0
-        metric = ("encoded frames/sec, %s, preset=medium's flag set with the encoder's own lookahead and rate control (--crf %.0f --b-adapt %d --pre-scenecut, %s, subme %d RD, "
+        psc = " --pre-scenecut" if args.pre_scenecut else ""
+        metric = ("encoded frames/sec, %s, preset=medium's flag set with the encoder's own lookahead and rate control (--crf %.0f --b-adapt %d%s, %s, subme %d RD, "
                   "trellis %d, psy-rd, aq-mode %d, CABAC payload on the GPU); 1/2/4/8 MI355X (bit-exact)"
-                  % (size, args.crf, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.aq_mode))
+                  % (size, args.crf, args.b_adapt, psc, ME_NAMES[args.me], args.subme, args.trellis, args.aq_mode))
         what = ("%dx%d streams (one per chain, segments of one synthetic clip) through x264_encoder_encode's path on the GPU: pictures synthesised on the device, "
                 "x264_frame_init_lowres + lookahead costs (x264_slicetype_frame_cost, one wavefront per task) feeding the library's x264_slicetype_decide / x264_ratecontrol_start "
                 "(host C), then the per-macroblock loop in raster order (one wavefront per chain: cache_load, x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, "
                 "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct spatial --me %s "
-                "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d --pre-scenecut, chroma ME, fast "
-                "P-skip, dct-decimate, CABAC; payload bytes stay on the device (slice / NAL headers and the download are the host's)"
+                "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d%s, chroma ME, fast "
+                "P-skip, dct-decimate, CABAC; payload bytes stay on the device (the host downloads them and writes the headers around them: x264_vs2008_amd/mux.py)"
                 % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
-                   args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut))
-        # the flag set is BASELINE.md's MED with --pre-scenecut ON BOTH SIDES (GPU and the reference leg): the reference forces that flag itself with
-        # --threads > 1, and BASELINE.md prescribes it for GOP-sharded runs; the scene cut that re-encodes a frame is the only thing it replaces
-        missing = ["slice / NAL headers around the payload (the product is slice_data(); x264hip_nal_encode wraps it)"]
+                   args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, psc))
+        # Default: BASELINE.md's MED as it stands -- no --pre-scenecut: x264_encoder_encode's look at every coded P frame (the post-encode scene cut) is
+        # evaluated from the sweep's statistics every step; the re-encode that follows a hit is not built (the run stops there), and this clip has none.
+        # The reference leg (the harness) only has the pre-encode scene cut; neither fires here, and the harness run is the reference CLI's stream byte
+        # for byte (tests/test_cpu_mux.py: the md5 of BASELINE config 2).
+        missing = []
         flagset = ("MED (BASELINE.md) + --pre-scenecut on both sides: the pre-encode scene cut instead of the one that re-encodes a frame -- what the reference does itself with "
-                   "--threads > 1")
+                   "--threads > 1") if args.pre_scenecut else \
+                  ("MED (BASELINE.md) as it stands: the post-encode scene cut is evaluated after every P frame of every chain (x264hip_frame_stats + x264hip_scenecut_post); "
+                   "the re-encode after a hit is not built -- the run would stop -- and no chain of this clip has one.  The whole stream of this flag set on the hd24 clip "
+                   "(version SEI, parameter sets, slice headers: x264_vs2008_amd/mux.py) has the md5 of the reference CLI's file (tests/test_gpu_mux.py)")
         line = {
             "metric": metric,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -548,7 +554,7 @@ def run_stream_async(args, hip, dist, json_fd, rank, world, B, g_first, g_step, 
                                                       args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, args.warmup, args.steps))
         # the flag set is BASELINE.md's MED with --pre-scenecut ON BOTH SIDES (GPU and the reference leg): the reference forces that flag itself with
         # --threads > 1, and BASELINE.md prescribes it for GOP-sharded runs; the scene cut that re-encodes a frame is the only thing it replaces
-        missing = ["slice / NAL headers around the payload (the product is slice_data(); x264hip_nal_encode wraps it)"]
+        missing = []
         flagset = ("MED (BASELINE.md) + --pre-scenecut on both sides: the pre-encode scene cut instead of the one that re-encodes a frame -- what the reference does itself with "
                    "--threads > 1")
         line = {
@@ -650,16 +656,19 @@ def main():
                     "the kernels are bound by each wavefront's own latency, so groups out of phase only slow one another (2048 chains: 428 frames/s in one group, 256 / 185 / 130 "
                     "with 1536 chains in 2 / 3 / 4)")
     ap.add_argument("--b-adapt", type=int, default=1)
-    ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold of the pre-encode scene cut (--pre-scenecut)")
+    ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold")
+    ap.add_argument("--pre-scenecut", dest="pre_scenecut", type=int, default=0, help="stream mode: 1: the scene cut decided in the lookahead (what the reference forces with --threads > 1); "
+                    "0 (the reference's default): x264_encoder_encode's look at every coded P frame -- evaluated, the re-encode after a hit is not built")
     args = ap.parse_args()
     args.cif = args.preset == "cif"
     if args.cif:
         args.wavefront, args.stream, args.subme_zero = 1, 0, True
         args.width, args.height = args.width or 352, args.height or 288
         args.me = 0 if args.me < 0 else args.me
-        args.refs, args.inter, args.intra, args.dct8, args.mixed_refs, args.bframes = 1, 0, 0, 0, 0, 0
+        args.refs, args.inter, args.intra, args.dct8, args.mixed_refs, args.bframes = 1, 0, 1, 0, 0, 0      # `--partitions none` clears analyse.inter only: I slices keep I4x4
         args.keyint = args.keyint or 250
         args.batch = args.batch or 2048
+        args.steps = args.steps or 27                    # with the 3 warm-up steps: chain 0 codes the 30 frames of BASELINE config 1's clip
     wf = bool(args.wavefront)
     uhd, slow = args.preset == "uhd", args.preset == "slow"
     if slow:
@@ -792,7 +801,7 @@ def main():
         chains_total = B
 
     # ---- parity of THIS run: every frame the GPU coded for chain 0 against the reference's bytes ----
-    checked = 0
+    checked, stream_md5 = 0, None
     if check:
         for k in range(min(n_coded, len(ref_pays))):
             base = pin + k * (cap_n + 64)
@@ -803,6 +812,22 @@ def main():
                 raise SystemExit("bench.py: PARITY FAILURE -- chain 0, coded frame %d (display %d): the GPU's slice payload (%d bytes) differs from the "
                                  "reference's (%d bytes)" % (k, order[k][0], n, len(want)))
             checked += 1
+        # BASELINE config 1 as a file: chain 0's first 30 frames are the cif30 clip, so their payloads inside the library's version SEI, parameter
+        # sets and slice headers (x264_vs2008_amd/mux.py) must be, byte for byte, what the reference's command line wrote (md5 from SURVEY.md 8(c))
+        if args.cif and checked >= 30 and g_first == 0 and (args.width, args.height, args.keyint, args.qp, args.me) == (352, 288, 250, 26, 0):
+            import hashlib
+            from x264_vs2008_amd import mux
+            mp = mux.encoder_params(hip, width=352, height=288, rc_method=mux.RC_CQP, qp_constant=26, cabac=0, me_method=0, subpel_refine=0, inter=0, deblocking_filter=0,
+                                    aq_mode=0, scenecut_threshold=-1, frame_reference=1, bframe=0, bframe_adaptive=0)
+            mx, hsh = mux.AnnexB(hip, mp), hashlib.md5()
+            for k in range(30):
+                base = pin + k * (cap_n + 64)
+                n = C.c_int32.from_address(base).value
+                hsh.update(mx.frame(frame=k, ftype=mux.TYPE_IDR if k == 0 else mux.TYPE_P, qp=sl.iframe_qp(26) if k == 0 else 26, payload=C.string_at(base + 64, n)))
+            if hsh.hexdigest() != "02b208eecef842e084cbb9c83bc1a757":
+                raise SystemExit("bench.py: PARITY FAILURE -- chain 0's Annex B stream (30 frames of cif30) has md5 %s, the reference CLI's file 02b208eecef842e084cbb9c83bc1a757" % hsh.hexdigest())
+            stream_md5 = ("chain 0's whole Annex B stream of its first 30 frames (the cif30 clip: version SEI, SPS, PPS, slice headers, CAVLC payloads) has the md5 of the "
+                          "reference command line's output for BASELINE config 1, 02b208eecef842e084cbb9c83bc1a757")
         hip.x264hip_host_free(C.c_void_p(pin))
 
     # the dominant kernel (k_slice_sweep), timed live with HIP events on its launch stream: every launch of the timed region
@@ -850,7 +875,7 @@ def main():
             metric = "encoded frames/sec, 352x288, the ultrafast flag set of BASELINE config 0 (--qp 26 --no-cabac --me dia --subme 0 --partitions none --no-deblock --ref 1), CAVLC payload on the GPU (bit-exact)"
             what = ("%dx%d I / P chains through the reference's per-macroblock loop on the GPU (wavefront schedule) and the CAVLC writer (x264hip_cavlc_write_frame) behind every sweep: "
                     "dia ME range 16, subme 0, 1 ref, no partitions, no deblock, CQP %d, keyint %d" % (args.width, args.height, args.qp, args.keyint))
-            missing = ["slice / NAL headers around the payload"]
+            missing = []
             par = "B chains per GPU in every launch (one wavefront per macroblock row per chain, then one wavefront per chain for the CAVLC pass); chains shard across GPUs with no data-path collective"
         elif wf:
             metric = "I/P macroblock-loop frames/sec, %s, medium minus {B-frames, RD (subme 7 -> 5), trellis, AQ, entropy coding} (round-1 configuration, bit-exact)" % size
@@ -876,8 +901,7 @@ def main():
             missing = (["B slices (--bframes 3 --b-adapt 1 --weightb --direct spatial): about 3/4 of a medium encode's frames"] if not args.bframes else
                        ["adaptive B placement (--b-adapt 1): the B frames are placed in a fixed pattern of %d" % args.bframes]) + [
                        "CRF rate control (--crf 23): constant QP %d + adaptive quantisation here" % args.qp, "lookahead (b-adapt, scenecut, lowres motion candidates)",
-                       "keyint %d so that thousands of closed GOPs exist (the preset's default is 250)" % args.keyint,
-                       "slice / NAL headers around the payload"]
+                       "keyint %d so that thousands of closed GOPs exist (the preset's default is 250)" % args.keyint]
             par = ("B closed-GOP chains per GPU in every launch, one wavefront per chain walking its frame in raster order (the RD levels, trellis and AQ "
                    "make a slice one serial chain of macroblocks); chains shard across GPUs with no data-path collective")
         line = {
@@ -895,6 +919,7 @@ def main():
                        "parity": ("payload bytes of rank 0's chain 0, all %d coded frames of this run (%d of them timed), equal the reference's own x264_macroblock_analyse / "
                                   "_encode / _write_cabac output for the same frames" % (checked, max(0, checked - args.warmup))) if checked else
                                  "not checked in this run (no CPU leg: --no-cpu, --wavefront 1 or more than one rank)",
+                       "stream_md5": stream_md5,
                        "timed_launches": launches},
             "roofline": {"bound": "hbm", "kernel": "k_slice_sweep" + ("" if wf else "<raster>"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,

@@ -126,6 +126,10 @@ static const uint8_t flat16[64] = {
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,
     16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16,16 };
 
+#ifdef REFSLICE_TRACE
+static int refslice_trace_frame, refslice_trace_mb;
+static x264_t *refslice_trace_h;
+#endif
 typedef struct {
     x264_t *h;
     uint8_t *bsbuf;
@@ -271,6 +275,15 @@ static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, 
         }
         if (is_b) x264_macroblock_bipred_init(h);            /* encoder.c:1534-1535 */
         x264_macroblock_slice_init(h);
+        /* PINNED (found with `make -C oracle msan`): an I slice never writes fdec->ref[0] / mv[0] (x264_macroblock_cache_save, R/common/macroblock.c:1296),
+         * but for an I picture that is not an IDR x264_macroblock_slice_init leaves fdec->i_ref[0] = h->i_ref0 > 0, so the next P picture's
+         * x264_mb_predict_mv_ref16x16 takes "temporal predictors" from those arrays (R/common/macroblock.c:420-441) -- whatever the frame
+         * structure held before, malloc's leftovers on its first use: the reference's output then depends on what the process did earlier.  Here an I
+         * picture has no motion to offer: ref = -1, which is also what the product's I slices leave in their state. */
+        if (h->sh.i_type == SLICE_TYPE_I) {
+            memset(h->fdec->ref[0], -1, 4 * (size_t)n * sizeof(int8_t));
+            memset(h->fdec->mv[0], 0, 2 * 16 * (size_t)n * sizeof(int16_t));
+        }
         memset(&h->stat.frame, 0, sizeof(h->stat.frame));
         int i_skip = 0;
         if (b_write) {                                    /* x264_slice_write after the header, encoder.c:1155-1165 */
@@ -289,6 +302,9 @@ static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, 
         for (int mb = 0; mb < n; mb++) {
             int mx = mb % mb_w, my = mb / mb_w;
             size_t M = F * n + mb;
+#ifdef REFSLICE_TRACE
+            refslice_trace_frame = (int)F; refslice_trace_mb = mb; refslice_trace_h = h;      /* oracle/msan_main.c: where a sanitizer report happened */
+#endif
             int16_t *ly = o->luma + M * 256, *ldc = o->luma_dc + M * 16, *cdc = o->chroma_dc + M * 8, *cac = o->chroma_ac + M * 128;
             uint8_t *nz = o->nnz + M * 27;
             if (mx == 0) filter_row(h, my);

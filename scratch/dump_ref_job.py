@@ -1,0 +1,22 @@
+"""Developer aid: writes the refslice_encode_stream job of a random stream configuration (tests/test_gpu_stream.py random_config(seed), chain k)
+for oracle/_ref/msan/refslice_msan (oracle/msan_main.c).  python scratch/dump_ref_job.py <seed> <chain> <out>"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import look_cases as K, test_gpu_stream as T
+from oracle import refslice as rs
+seed, k, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+c = T.random_config(seed)
+c.update(t0=c["t0"] + 61 * k, slow=[c["slow"], 1 + (c["slow"] % 3)][k])
+p = rs.make_params(c["w"], c["h"], c["frames"], qp=c["qp"], me_method=c["me"], subme=c["subme"], n_refs=c.get("n_refs", 2), inter=c.get("inter", 0x33),
+                   intra=0x3, transform8x8=1, cabac=1, deblock=1, keyint=c["keyint"], mixed_refs=c.get("mixed_refs", 0), chroma_me=c.get("chroma_me", 1))
+e = rs.make_ext(bframes=c["bframes"], b_adapt=c["b_adapt"], pre_scenecut=c["pre_scenecut"], scenecut_threshold=c["scenecut_threshold"],
+                keyint_min=c["keyint_min"], crf=-1.0 if c["crf"] is None else c["crf"], bframe_bias=c["bframe_bias"], weightb=c["weightb"],
+                aq_mode=c["aq"], aq_strength=1.0, trellis=c.get("trellis", 0), psy_rd=c.get("psy_rd", 0.0), direct_pred=c.get("direct_pred", 1))
+e.payload_cap = ((c["w"] + 15) // 16) * ((c["h"] + 15) // 16) * 800 + 4096
+y, u, v = K.clip(c["w"], c["h"], c["frames"], c["cut"], c["t0"], c["slow"])
+with open(out, "wb") as f:
+    f.write(np.int32(C.sizeof(p)).tobytes()); f.write(bytes(p)); f.write(np.int32(C.sizeof(e)).tobytes()); f.write(bytes(e))
+    f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+print(c)

@@ -161,6 +161,7 @@ class StreamEncoder(ChainEncoder):
             if cd.slice_type != SLICE_B:                   # kept: filtered below
                 filt.setdefault(pic_i, []).append(ci)
         c.sync()                                        # the previous step's sweep and filters are done: their tables, element lists and pictures are free
+        self.check_scenecut()                           # x264_encoder_encode's look at the P frames it just coded (no --pre-scenecut)
         for pic_i in written:
             c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
         ev = None

@@ -20,12 +20,13 @@ int main(int argc, char **argv)
 {
     refslice_params p; refslice_ext e; refslice_out o; refslice_out2 o2;
     FILE *f = fopen(argc > 1 ? argv[1] : "job.bin", "rb");
-    int sp, se, i;
+    int sp, se, i, fn = 0;
     size_t ny, nc;
     uint8_t *y, *u, *v;
     unsigned sum = 0;
     __msan_set_death_callback(where);
     if (!f) { perror("job"); return 2; }
+    if (fread(&fn, 4, 1, f) != 1) return 2;                  /* 0: refslice_encode_stream (the whole encoder), 1: refslice_encode_chain2 (lock-step chains) */
     if (fread(&sp, 4, 1, f) != 1 || sp != (int)sizeof(p) || fread(&p, sizeof(p), 1, f) != 1) { fprintf(stderr, "params size %d, want %zu\n", sp, sizeof(p)); return 2; }
     if (fread(&se, 4, 1, f) != 1 || se != (int)sizeof(e) || fread(&e, sizeof(e), 1, f) != 1) { fprintf(stderr, "ext size %d, want %zu\n", se, sizeof(e)); return 2; }
     ny = (size_t)p.width * p.height * p.n_frames; nc = ny / 4;
@@ -34,7 +35,7 @@ int main(int argc, char **argv)
     fclose(f);
     for (i = 0; i < (int)(sizeof(o) / sizeof(void *)); i++) ((void **)&o)[i] = calloc(1, 16 << 20);
     for (i = 0; i < (int)(sizeof(o2) / sizeof(void *)); i++) ((void **)&o2)[i] = calloc(1, 16 << 20);
-    i = refslice_encode_stream(&p, &e, y, u, v, &o, &o2);
+    i = fn ? refslice_encode_chain2(&p, &e, y, u, v, &o, &o2) : refslice_encode_stream(&p, &e, y, u, v, &o, &o2);
     printf("rc %d\n", i);
     for (i = 0; i < p.n_frames; i++) {
         int k, n = o2.payload_len[i];

@@ -46,7 +46,7 @@ typedef struct {
      * --b-adapt 0 and no --b-pyramid); the clip stays in display order, the chain is coded in coding order */
     int bframes;                             /* param.i_bframe */
     int weightb;                             /* param.analyse.b_weighted_bipred */
-    int direct_pred;                         /* param.analyse.i_direct_mv_pred: 1 spatial, 2 temporal */
+    int direct_pred;                         /* param.analyse.i_direct_mv_pred: 1 spatial, 2 temporal, 3 auto (the reference only: the twin and the product refuse it) */
     /* the lookahead's motion vectors (fenc->lowres_mvs, h->frames.b_have_lowres): x264_mb_predict_mv_ref16x16 offers twice the vector of
      * the macroblock's half-resolution block as a candidate of every 16x16 search on reference 0 (R/common/macroblock.c:393-398).  The
      * caller supplies them, [frame in coding order][list][n_mb][2] int16; a frame / list whose first component is 0x7fff has none
@@ -183,6 +183,7 @@ static int setup_encoder(rctx *c, const refslice_params *p, const refslice_ext *
         h->param.analyse.b_weighted_bipred = e->weightb && h->param.i_bframe > 0;
         h->param.analyse.i_direct_mv_pred = e->direct_pred ? e->direct_pred : X264_DIRECT_PRED_SPATIAL;
         if (!p->subme && h->param.analyse.i_direct_mv_pred > X264_DIRECT_PRED_SPATIAL) h->param.analyse.i_direct_mv_pred = X264_DIRECT_PRED_SPATIAL;
+        h->mb.b_direct_auto_write = h->param.analyse.i_direct_mv_pred == X264_DIRECT_PRED_AUTO && h->param.i_bframe;      /* encoder.c:460-462 (no 2-pass here) */
         if (p->subme >= 6 && !b_write) return -4;        /* the RD levels read the live entropy-coder state */
         x264_rdo_init();                                 /* R/encoder/encoder.c:728 */
     }
@@ -253,7 +254,8 @@ static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, 
     {
         memset(&h->sh, 0, sizeof(h->sh));
         h->sh.i_type = idr ? SLICE_TYPE_I : is_b ? SLICE_TYPE_B : SLICE_TYPE_P;
-        h->sh.b_direct_spatial_mv_pred = h->param.analyse.i_direct_mv_pred == X264_DIRECT_PRED_SPATIAL;   /* x264_slice_header_init, encoder.c:116-122 */
+        h->sh.b_direct_spatial_mv_pred = h->param.analyse.i_direct_mv_pred == X264_DIRECT_PRED_SPATIAL;   /* x264_slice_header_init, encoder.c:113-119 */
+        if (h->mb.b_direct_auto_write) h->sh.b_direct_spatial_mv_pred = h->stat.i_direct_score[1] > h->stat.i_direct_score[0];   /* --direct auto: the running scores decide */
         h->sh.i_first_mb = 0; h->sh.i_last_mb = n;
         h->sh.i_num_ref_idx_l0_active = h->i_ref0 <= 0 ? 1 : h->i_ref0;
         h->sh.i_num_ref_idx_l1_active = h->i_ref1 <= 0 ? 1 : h->i_ref1;
@@ -408,6 +410,12 @@ static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, 
         }
         filter_row(h, mb_h);
         x264_noise_reduction_update(h);                      /* x264_encoder_frame_end, R/encoder/encoder.c:1755 */
+        if (h->sh.i_type == SLICE_TYPE_B && h->mb.b_direct_auto_write) {     /* x264_encoder_frame_end, encoder.c:1777-1790: --direct auto's running scores */
+            if (h->stat.i_direct_score[0] + h->stat.i_direct_score[1] > h->mb.i_mb_count)
+                for (i = 0; i < 2; i++) h->stat.i_direct_score[i] = h->stat.i_direct_score[i] * 9 / 10;
+            for (i = 0; i < 2; i++) h->stat.i_direct_score[i] += h->stat.frame.i_direct_score[i];
+        }
+        if (o2 && o2->frame_info2) o2->frame_info2[4 * F + 3] = h->sh.i_type == SLICE_TYPE_B ? h->sh.b_direct_spatial_mv_pred : 0;
         o->stat[4 * F] = h->stat.frame.i_intra_cost; o->stat[4 * F + 1] = h->stat.frame.i_inter_cost;
         o->stat[4 * F + 2] = h->stat.frame.i_mbs_analysed; o->stat[4 * F + 3] = 0;
         for (y = 0; y < 16 * mb_h; y++)

@@ -109,3 +109,20 @@ def test_med_stream_md5_around_the_reference_encoder(hip_lib_host, cfg):
     a = M.reference_med(p, w, h, n)
     stream = M.mux_reference_stream(lib, p, a, n)
     assert hashlib.md5(stream).hexdigest() == M.STREAM_MD5[cfg], len(stream)
+
+
+@need_ref
+def test_c4_slow_stream_md5s_around_the_reference_encoder(hip_lib_host):
+    """BASELINE config 4's flag set (SLOW: 5 references, b-adapt 2, UMH, subme 8, --direct auto) on hd24, with and without --pre-scenecut: the
+    harness (with --direct auto's running scores, x264_encoder_frame_end's part of them restated in ref_slice.c) inside this library's headers
+    has the md5 of both files the reference command line wrote.  The PRODUCT refuses --direct auto: this pins the reference side
+    and the B slice header's direct_spatial_mv_pred bit, which changes from frame to frame here."""
+    lib = hip_lib_host
+    p = mux.encoder_params(lib, width=1920, height=1080, pre_scenecut=1, **M.SLOW)
+    assert (p.level_idc, p.d_num_ref_frames) == (50, 5)
+    a = M.reference_med(p, 1920, 1080, 24)
+    assert len(set(int(a["frame_info2"][f][3]) for f in range(24) if int(a["frame_info"][f][0]) == 1)) == 2          # both direct modes occur
+    assert hashlib.md5(M.mux_reference_stream(lib, p, a, 24)).hexdigest() == M.STREAM_MD5["C4_SLOW_pre_scenecut_hd24"]
+    # without --pre-scenecut only the SEI text differs on this clip (no cut fires either way)
+    p0 = mux.encoder_params(lib, width=1920, height=1080, **M.SLOW)
+    assert hashlib.md5(M.mux_reference_stream(lib, p0, a, 24)).hexdigest() == M.STREAM_MD5["C4_SLOW_hd24"]

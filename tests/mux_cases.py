@@ -36,12 +36,12 @@ def reference_uf(w, h, n):
                                             mv_range=128), rs.make_ext(write=1), y, u, v)
 
 
-def reference_med(p, w, h, n):
+def reference_med(p, w, h, n, t0=0):
     """The reference's whole encoder (oracle/ref_slice.c refslice_encode_stream) with the validated parameters p.  The harness only has the
     pre-encode scene cut; BASELINE's MED runs have the post-encode one -- neither fires on these clips, so the frames are the same and only
     the SEI text differs (it is written from p, which says scenecut=40 without "(pre)")."""
     from oracle import refslice as rs
-    y, u, v = rs.clip(w, h, n)
+    y, u, v = rs.clip(w, h, n, t0)
     rp = rs.make_params(w, h, n, qp=p.qp_constant, me_method=p.me_method, me_range=p.me_range, subme=p.subpel_refine, n_refs=p.frame_reference, inter=p.inter,
                         intra=p.intra, transform8x8=p.transform_8x8, cabac=p.cabac, deblock=p.deblocking_filter, keyint=p.keyint_max, mixed_refs=p.mixed_references,
                         chroma_me=p.chroma_me, mv_range=p.mv_range)

@@ -205,13 +205,7 @@ def test_nal_encode_matches_reference():
         assert got[:m].tolist() == out, trial
 
 
-# the default scaling lists of ITU-T H.264 tables 7-3 / 7-4 in raster order (what --cqm jvt selects): data of the standard
-JVT4I = [6, 13, 20, 28, 13, 20, 28, 32, 20, 28, 32, 37, 28, 32, 37, 42]
-JVT4P = [10, 14, 20, 24, 14, 20, 24, 27, 20, 24, 27, 30, 24, 27, 30, 34]
-JVT8I = [6, 10, 13, 16, 18, 23, 25, 27, 10, 11, 16, 18, 23, 25, 27, 29, 13, 16, 18, 23, 25, 27, 29, 31, 16, 18, 23, 25, 27, 29, 31, 33,
-         18, 23, 25, 27, 29, 31, 33, 36, 23, 25, 27, 29, 31, 33, 36, 38, 25, 27, 29, 31, 33, 36, 38, 40, 27, 29, 31, 33, 36, 38, 40, 42]
-JVT8P = [9, 13, 15, 17, 19, 21, 22, 24, 13, 13, 17, 19, 21, 22, 24, 25, 15, 17, 19, 21, 22, 24, 25, 27, 17, 19, 21, 22, 24, 25, 27, 28,
-         19, 21, 22, 24, 25, 27, 28, 30, 21, 22, 24, 25, 27, 28, 30, 32, 22, 24, 25, 27, 28, 30, 32, 33, 24, 25, 27, 28, 30, 32, 33, 35]
+from x264_vs2008_amd.frame import JVT4I, JVT4P, JVT8I, JVT8P          # the standard's default scaling lists (--cqm jvt)
 
 
 def test_cqm_init_in_library_matches_reference_tables(oracle_lib):

@@ -1,0 +1,53 @@
+"""The command line front end end to end on the GPU (x264_vs2008_amd/encode.py: reader -> validated parameters -> encoder -> Annex B file):
+BASELINE config 1 from a raw file and from a YUV4MPEG2 file = the reference command line's md5; two inputs coded side by side with the MED
+flag set = what the reference's whole encoder (the harness) + this library's headers give for each."""
+import hashlib
+import os
+
+import pytest
+
+import mux_cases as M
+from x264_vs2008_amd import encode as E
+from x264_vs2008_amd import mux, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libx264ref.so")
+UF = "--qp 26 --no-cabac --me dia --subme 0 --partitions none --no-deblock --aq-mode 0 --scenecut -1 --ref 1 --bframes 0 --b-adapt 0 --no-asm --threads 1"
+MED = "--crf 23 --ref 3 --bframes 3 --b-adapt 1 --me hex --subme 7 --8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --weightb --mixed-refs --direct spatial"
+
+
+def write_clip(path, w, h, n, t0=0, y4m=False):
+    with open(path, "wb") as f:
+        if y4m:
+            f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A0:0 C420jpeg\n" % (w, h))
+        for t in range(n):
+            if y4m:
+                f.write(b"FRAME\n")
+            for pl in synth.frame(w, h, t0 + t):
+                f.write(pl.tobytes())
+
+
+@pytest.mark.parametrize("y4m", [False, True])
+def test_cli_config1_file_has_the_reference_md5(hip_lib, tmp_path, y4m):
+    src = str(tmp_path / ("cif30.y4m" if y4m else "cif30.yuv"))
+    out = str(tmp_path / "out.264")
+    write_clip(src, 352, 288, 30, y4m=y4m)
+    assert E.main(UF.split() + ["-o", out, src] + ([] if y4m else ["352x288"])) == 0
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == M.STREAM_MD5["C1_UF_cif30"]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+def test_cli_two_inputs_side_by_side_equal_the_reference_encoder(hip_lib, tmp_path):
+    w, h, n = 176, 96, 14
+    srcs = [str(tmp_path / ("in%d.y4m" % i)) for i in range(2)]
+    for i, s in enumerate(srcs):
+        write_clip(s, w, h, n, t0=40 * i, y4m=True)
+    assert E.main(MED.split() + ["-o", str(tmp_path / "o%d.264")] + srcs) == 0
+    o = E.build_parser().parse_args(MED.split() + ["-o", "x"] + srcs)
+    p = mux.encoder_params(hip_lib, width=w, height=h, fps_num=25, fps_den=1, **E.param_fields(o))
+    for i in range(2):
+        a = M.reference_med(p, w, h, n, t0=40 * i)
+        want = M.mux_reference_stream(hip_lib, p, a, n)
+        got = open(str(tmp_path / ("o%d.264" % i)), "rb").read()
+        assert got == want, "stream %d: %d vs %d bytes" % (i, len(got), len(want))

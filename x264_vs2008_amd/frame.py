@@ -213,6 +213,16 @@ CQM_SHAPES = {"quant4_mf": (4, 52, 16), "quant4_bias": (4, 52, 16), "quant8_mf":
               "dequant4_mf": (4, 6, 16), "dequant8_mf": (2, 6, 64), "unquant4_mf": (4, 52, 16), "unquant8_mf": (2, 52, 64)}
 
 
+# the default scaling lists of ITU-T H.264 tables 7-3 / 7-4 in raster order (what --cqm jvt selects: x264_cqm_jvt, R/common/set.c): data of the standard
+JVT4I = [6, 13, 20, 28, 13, 20, 28, 32, 20, 28, 32, 37, 28, 32, 37, 42]
+JVT4P = [10, 14, 20, 24, 14, 20, 24, 27, 20, 24, 27, 30, 24, 27, 30, 34]
+JVT8I = [6, 10, 13, 16, 18, 23, 25, 27, 10, 11, 16, 18, 23, 25, 27, 29, 13, 16, 18, 23, 25, 27, 29, 31, 16, 18, 23, 25, 27, 29, 31, 33,
+         18, 23, 25, 27, 29, 31, 33, 36, 23, 25, 27, 29, 31, 33, 36, 38, 25, 27, 29, 31, 33, 36, 38, 40, 27, 29, 31, 33, 36, 38, 40, 42]
+JVT8P = [9, 13, 15, 17, 19, 21, 22, 24, 13, 13, 17, 19, 21, 22, 24, 25, 15, 17, 19, 21, 22, 24, 25, 27, 17, 19, 21, 22, 24, 25, 27, 28,
+         19, 21, 22, 24, 25, 27, 28, 30, 21, 22, 24, 25, 27, 28, 30, 32, 22, 24, 25, 27, 28, 30, 32, 33, 24, 25, 27, 28, 30, 32, 33, 35]
+JVT_LISTS = [JVT4I, JVT4P, JVT4I, JVT4P, JVT8I, JVT8P]          # CQM_4IY, 4PY, 4IC, 4PC, 8IY, 8PY
+
+
 def cqm_init(lib, scaling_lists=None, luma_deadzone=None, qp_min=0):
     """The quantiser tables from the library's x264hip_cqm_init (x264_cqm_init, R/common/set.c:68-168): a dict of numpy arrays with the
     layout of h->quant4_mf ... h->unquant8_mf.  scaling_lists: six raster-order lists (4x4 intra Y, inter Y, intra C, inter C, 8x8

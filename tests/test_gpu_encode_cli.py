@@ -51,3 +51,26 @@ def test_cli_two_inputs_side_by_side_equal_the_reference_encoder(hip_lib, tmp_pa
         want = M.mux_reference_stream(hip_lib, p, a, n)
         got = open(str(tmp_path / ("o%d.264" % i)), "rb").read()
         assert got == want, "stream %d: %d vs %d bytes" % (i, len(got), len(want))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+def test_cli_constant_qp_cabac_without_a_frame_queue(hip_lib, tmp_path):
+    """--qp N --scenecut -1 --bframes 0: nothing for x264_slicetype_decide to decide -- the lock-step encoder (raster variant, CABAC in the loop,
+    an IDR every --keyint frames) against the reference's loop + this library's headers; trellis, deblock offsets and a second IDR included."""
+    from oracle import refslice as rs
+    w, h, n = 160, 112, 9
+    src, out = str(tmp_path / "in_160x112.yuv"), str(tmp_path / "o.264")
+    write_clip(src, w, h, n, t0=5)
+    args = "--qp 29 --scenecut -1 --bframes 0 --ref 2 --subme 5 --8x8dct --trellis 1 --deblock=-1:1 --keyint 6 --min-keyint 2 --mixed-refs --aq-mode 0"
+    assert E.main(args.split() + ["-o", out, src]) == 0
+    o = E.build_parser().parse_args(args.split() + ["-o", "x", src])
+    p = mux.encoder_params(hip_lib, width=w, height=h, **E.param_fields(o))
+    y, u, v = rs.clip(w, h, n, 5)
+    a = rs.run_reference2(rs.make_params(w, h, n, qp=29, me_method=rs.ME_HEX, subme=5, n_refs=2, inter=p.inter, intra=p.intra, transform8x8=1, cabac=1, deblock=1,
+                                         alpha_c0=-1, beta=1, keyint=6, mixed_refs=1, chroma_me=1, mv_range=p.mv_range),
+                          rs.make_ext(write=1, trellis=1), y, u, v)
+    m, want = mux.AnnexB(hip_lib, p), b""
+    for t in range(n):
+        want += m.frame(frame=t, ftype=mux.TYPE_IDR if t % 6 == 0 else mux.TYPE_P, qp=int(a["frame_info"][t][1]), payload=bytes(a["payload"][t, :a["payload_len"][t]]))
+    got = open(out, "rb").read()
+    assert got == want, "%d vs %d bytes" % (len(got), len(want))

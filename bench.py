@@ -22,7 +22,7 @@ A "step" is one x264_encoder_encode call for every chain (x264_vs2008_amd/stream
   x264hip_deblock_frame, x264hip_expand_border, x264hip_hpel_filter_frame   a kept frame becomes a reference (the elements that coded one)
 
 config.matches_baseline is true for the default run with config.flag_set saying what that means: MED as BASELINE.md states it -- the
-post-encode scene cut is evaluated after every P frame of every chain (the re-encode after a hit is not built: the run would stop; the
+post-encode scene cut is evaluated after every P frame of every chain (a given-up attempt would be coded again inside the step; the
 clip has none); --pre-scenecut 1 decides cuts in the lookahead instead.  PARITY IS CHECKED IN THIS RUN: rank 0's
 chain 0 also goes through the REFERENCE's whole encoder on the host (frame queue, slice-type decision, rate control, slice loop; the
 cpu_baseline leg, before the GPU is touched), and for every frame the GPU side coded for that chain -- warm-up and timed steps alike --
@@ -403,14 +403,14 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
                 % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
                    args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, psc))
         # Default: BASELINE.md's MED as it stands -- no --pre-scenecut: x264_encoder_encode's look at every coded P frame (the post-encode scene cut) is
-        # evaluated from the sweep's statistics every step; the re-encode that follows a hit is not built (the run stops there), and this clip has none.
+        # evaluated from the sweep's statistics every step; a hit would be coded again inside the step (StreamEncoder), and this clip has none.
         # The reference leg (the harness) only has the pre-encode scene cut; neither fires here, and the harness run is the reference CLI's stream byte
         # for byte (tests/test_cpu_mux.py: the md5 of BASELINE config 2).
         missing = []
         flagset = ("MED (BASELINE.md) + --pre-scenecut on both sides: the pre-encode scene cut instead of the one that re-encodes a frame -- what the reference does itself with "
                    "--threads > 1") if args.pre_scenecut else \
                   ("MED (BASELINE.md) as it stands: the post-encode scene cut is evaluated after every P frame of every chain (x264hip_frame_stats + x264hip_scenecut_post); "
-                   "the re-encode after a hit is not built -- the run would stop -- and no chain of this clip has one.  The whole stream of this flag set on the hd24 clip "
+                   "a given-up attempt is coded again inside the step (x264hip_lookahead_scenecut) -- no chain of this clip has one.  The whole stream of this flag set on the hd24 clip "
                    "(version SEI, parameter sets, slice headers: x264_vs2008_amd/mux.py) has the md5 of the reference CLI's file (tests/test_gpu_mux.py)")
         line = {
             "metric": metric,
@@ -658,7 +658,7 @@ def main():
     ap.add_argument("--b-adapt", type=int, default=1)
     ap.add_argument("--scenecut", type=int, default=40, help="param.i_scenecut_threshold")
     ap.add_argument("--pre-scenecut", dest="pre_scenecut", type=int, default=0, help="stream mode: 1: the scene cut decided in the lookahead (what the reference forces with --threads > 1); "
-                    "0 (the reference's default): x264_encoder_encode's look at every coded P frame -- evaluated, the re-encode after a hit is not built")
+                    "0 (the reference's default): x264_encoder_encode's look at every coded P frame, a given-up attempt coded again inside the step")
     args = ap.parse_args()
     args.cif = args.preset == "cif"
     if args.cif:

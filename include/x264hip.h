@@ -475,7 +475,8 @@ int x264hip_deblock_frame(x264hip_frame_ctx *c, x264hip_picture *recon, const x2
  * they are computed does not change any of them; get restarts its decision from the unchanged queue every time.
  * Not here: 2-pass, ABR, VBV, zones, B-pyramid.  With param.b_pre_scenecut = 0 and a threshold >= 0 the queue decides without scene cuts, as the
  * reference's does; the look x264_encoder_encode then takes at every coded P frame is the caller's (x264hip_stream.h: x264hip_frame_stats +
- * x264hip_scenecut_post), and the re-encode that follows a hit (frames put back into the queue) is not built: a caller that sees one stops. */
+ * x264hip_scenecut_post), and what follows a hit -- the picture coded again as I / IDR, or the B picture before it as the P, frames put back into
+ * the queue -- is x264hip_lookahead_scenecut below. */
 typedef struct x264hip_lookahead x264hip_lookahead;
 typedef struct {
     int mb_w, mb_h;
@@ -504,6 +505,8 @@ typedef struct {
     int lowres_l0, lowres_l1;            /* 1: fenc->lowres_mvs[0][frame - ref0_frame - 1] / [1][ref1_frame - frame - 1] was searched -- the vectors
                                           * x264_mb_predict_mv_ref16x16 offers the 16x16 search (R/common/macroblock.c:393-398) */
     int i_satd;              /* fdec->i_satd (x264_rc_analyse_slice) or 0 */
+    int frame_num_reset;     /* 1: a scene-cut IDR (x264hip_lookahead_scenecut): x264_encoder_encode restarts h->i_frame_num at 0 for it (encoder.c:1682);
+                              * the IDRs of --keyint do not (this version never resets the counter elsewhere) */
 } x264hip_look_frame;
 enum { X264HIP_LOOK_NONE = 0, X264HIP_LOOK_FRAME = 1, X264HIP_LOOK_NEED = 2, X264HIP_LOOK_END = 3 };
 x264hip_lookahead *x264hip_lookahead_new(const x264hip_lookahead_params *p);
@@ -520,6 +523,12 @@ int x264hip_lookahead_get(x264hip_lookahead *la, int flushing, x264hip_look_fram
 void x264hip_lookahead_set_cost(x264hip_lookahead *la, int b, int p0, int p1, int score, int intra_mbs, int cost00, int speculative);
 /* x264_ratecontrol_end + the next call's x264_reference_update for the frame get returned */
 void x264hip_lookahead_end(x264hip_lookahead *la);
+/* The post-encode scene cut (param.b_pre_scenecut = 0; R/encoder/encoder.c:1603-1699), INSTEAD of x264hip_lookahead_end, when the caller found the P
+ * picture it just coded no better than an intra picture (x264hip_stream.h: x264hip_frame_stats + x264hip_scenecut_post): the attempt is given up
+ * (its reconstruction, its payload, its place in the DPB: the caller's to discard) and the next x264hip_lookahead_get hands out what is coded instead
+ * -- the same picture as I / IDR, or, with B pictures waiting before it, the last of them as the P.  Returns 1 (same picture), 2 (another), -1 (no P
+ * picture in flight).  The rate control keeps what x264_ratecontrol_start did for the given-up attempt, as the reference's does. */
+int x264hip_lookahead_scenecut(x264hip_lookahead *la);
 /* frames the caller may drop now: every input number < the returned one is neither queued, nor last_nonb, nor a reference */
 int x264hip_lookahead_oldest_live(const x264hip_lookahead *la);
 

@@ -74,8 +74,9 @@ int x264hip_slice_nal(const x264hip_encoder_params *p, const x264hip_slice_heade
 
 /* h->stat.frame's terms the post-encode scene cut of x264_encoder_encode reads after a P slice (R/encoder/encoder.c:1603-1644), per chain, from
  * the state the sweep left: out_dev [batch] records on the device (stream-ordered).  x264hip_scenecut_post is the decision (host C, the reference's
- * float expression): 1 = the reference would code this P frame again as I / IDR -- the re-encode itself is not built; a host that sees 1 must stop
- * (x264_vs2008_amd/stream.py raises) or run with --pre-scenecut. */
+ * float expression): 1 = the reference gives this attempt up and codes again -- the picture as I / IDR, or the B picture before it as the P: the host
+ * discards the attempt (reconstruction, payload, its place in the DPB), calls x264hip_lookahead_scenecut (x264hip.h) instead of x264hip_lookahead_end and
+ * codes what x264hip_lookahead_get hands out next (x264_vs2008_amd/stream.py: StreamEncoder.step does it inside the step, for the chains concerned). */
 typedef struct x264hip_frame_stat { int64_t intra_cost, inter_cost; int32_t mbs_analysed, mb_i, mb_p, mb_skip; } x264hip_frame_stat;
 int x264hip_frame_stats(x264hip_frame_ctx *c, const x264hip_mb_state *st, x264hip_frame_stat *out_dev);
 int x264hip_scenecut_post(const x264hip_frame_stat *s, int i_mb, int i_gop_size, int scenecut_threshold, int keyint_min, int keyint_max);

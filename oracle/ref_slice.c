@@ -134,6 +134,7 @@ typedef struct {
     x264_t *h;
     uint8_t *bsbuf;
     int b_write, mb_w, mb_h, n, cw, ch, stream;
+    int defer_end, pending_len;              /* run_stream without --pre-scenecut: x264_encoder_frame_end's part waits for the post-encode scene cut's verdict */
 } rctx;
 
 /* the encoder as x264_encoder_open leaves it for this path (R/encoder/encoder.c:628-760) */
@@ -226,6 +227,7 @@ static int setup_encoder(rctx *c, const refslice_params *p, const refslice_ext *
         if (h->param.rc.i_aq_mode) h->fenc->i_inv_qscale_factor = x264_malloc(n * sizeof(uint16_t));     /* written by x264_adaptive_quant_frame */
     }
     if (b_write) bsbuf = malloc(64 + (size_t)e->payload_cap + 4096);
+    c->defer_end = 0; c->pending_len = 0;
     c->bsbuf = bsbuf; c->b_write = b_write; c->mb_w = mb_w; c->mb_h = mb_h; c->n = n; c->cw = p->width / 2; c->ch = p->height / 2;
     return 0;
 }
@@ -244,6 +246,28 @@ static void load_picture(rctx *c, const refslice_params *p, x264_frame_t *fr, co
 }
 
 /* one slice: x264_ratecontrol_start, x264_slice_init's fields, x264_slice_write's loop, the frame end (h->fenc, h->fdec, the lists are set) */
+/* x264_encoder_frame_end's part of a coded frame (R/encoder/encoder.c:1722-1790): the rate control's state after the frame, --nr's tables, --direct auto's
+ * running scores.  Not reached for a P frame the post-encode scene cut gives up (encoder.c:1645-1699 jumps back to do_encode before it). */
+static void frame_end(rctx *c, refslice_out2 *o2, size_t F)
+{
+    x264_t *h = c->h;
+    int i;
+    if (c->b_write && c->stream) {
+        x264_ratecontrol_end(h, 8 * c->pending_len);
+        h->stat.i_slice_size[h->sh.i_type] += c->pending_len + 5;      /* NALU_OVERHEAD, encoder.c:44 */
+        if (o2->rc_info) {
+            o2->rc_info[4 * F] = h->sh.i_qp; o2->rc_info[4 * F + 1] = h->fdec->f_qp_avg_rc;
+            o2->rc_info[4 * F + 2] = h->fdec->i_satd; o2->rc_info[4 * F + 3] = h->fdec->f_qp_avg_aq;
+        }
+    }
+    x264_noise_reduction_update(h);                          /* encoder.c:1755 */
+    if (h->sh.i_type == SLICE_TYPE_B && h->mb.b_direct_auto_write) {     /* encoder.c:1777-1790 */
+        if (h->stat.i_direct_score[0] + h->stat.i_direct_score[1] > h->mb.i_mb_count)
+            for (i = 0; i < 2; i++) h->stat.i_direct_score[i] = h->stat.i_direct_score[i] * 9 / 10;
+        for (i = 0; i < 2; i++) h->stat.i_direct_score[i] += h->stat.frame.i_direct_score[i];
+    }
+}
+
 static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, refslice_out *o, refslice_out2 *o2, size_t F, int disp)
 {
     x264_t *h = c->h;
@@ -399,22 +423,10 @@ static int code_frame(rctx *c, const refslice_params *p, const refslice_ext *e, 
             if (len > e->payload_cap) return -5;
             o2->payload_len[F] = len;
             memcpy(o2->payload + F * e->payload_cap, bsbuf + 64, len);
-            if (stream) {                                 /* x264_encoder_frame_end, encoder.c:1736: the rate control's state after the frame */
-                x264_ratecontrol_end(h, 8 * len);
-                h->stat.i_slice_size[h->sh.i_type] += len + 5;      /* NALU_OVERHEAD, encoder.c:44 */
-                if (o2->rc_info) {
-                    o2->rc_info[4 * F] = h->sh.i_qp; o2->rc_info[4 * F + 1] = h->fdec->f_qp_avg_rc;
-                    o2->rc_info[4 * F + 2] = h->fdec->i_satd; o2->rc_info[4 * F + 3] = h->fdec->f_qp_avg_aq;
-                }
-            }
+            c->pending_len = len;
         }
         filter_row(h, mb_h);
-        x264_noise_reduction_update(h);                      /* x264_encoder_frame_end, R/encoder/encoder.c:1755 */
-        if (h->sh.i_type == SLICE_TYPE_B && h->mb.b_direct_auto_write) {     /* x264_encoder_frame_end, encoder.c:1777-1790: --direct auto's running scores */
-            if (h->stat.i_direct_score[0] + h->stat.i_direct_score[1] > h->mb.i_mb_count)
-                for (i = 0; i < 2; i++) h->stat.i_direct_score[i] = h->stat.i_direct_score[i] * 9 / 10;
-            for (i = 0; i < 2; i++) h->stat.i_direct_score[i] += h->stat.frame.i_direct_score[i];
-        }
+        if (!c->defer_end) frame_end(c, o2, F);
         if (o2 && o2->frame_info2) o2->frame_info2[4 * F + 3] = h->sh.i_type == SLICE_TYPE_B ? h->sh.b_direct_spatial_mv_pred : 0;
         o->stat[4 * F] = h->stat.frame.i_intra_cost; o->stat[4 * F + 1] = h->stat.frame.i_inter_cost;
         o->stat[4 * F + 2] = h->stat.frame.i_mbs_analysed; o->stat[4 * F + 3] = 0;
@@ -519,16 +531,17 @@ int refslice_encode_chain2(const refslice_params *p, const refslice_ext *e, cons
 /* x264_encoder_encode's frame queue with the real lookahead and rate control in front of the slice loop (R/encoder/encoder.c:1340-1600, one thread):
  * every picture enters frames.next with its half-resolution planes, x264_slicetype_decide types the head of the queue once the delay is filled,
  * the typed mini-GOP moves to frames.current anchor first, x264_ratecontrol_start prices the frame (CRF reads x264_rc_analyse_slice), and
- * x264_reference_update hands the source's lowres planes to the reconstructed frame.  The scene cut of the non-"pre" kind re-encodes a frame from
- * its own statistics (encoder.c:1640-1700) and is refused here: pre_scenecut on, or the threshold off. */
+ * x264_reference_update hands the source's lowres planes to the reconstructed frame.  Without --pre-scenecut the post-encode scene cut is here too
+ * (encoder.c:1603-1699): a given-up P picture is coded again as I / IDR, or the B picture before it becomes the P and the queues are rearranged;
+ * look_cost[..][7] carries the frame_num each coded picture's slice header had. */
 static int run_stream(const refslice_params *p, const refslice_ext *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v,
                       refslice_out *o, refslice_out2 *o2)
 {
     rctx cx, *c = &cx;
-    int rc_, i, fed = 0, coded = 0;
+    int rc_, i, fed = 0, coded = 0, i_frame_num = 0, giveups = 0;
     if (!e || !e->write || !o2) return -4;
-    if (!e->pre_scenecut && e->scenecut_threshold >= 0) return -6;
     if ((rc_ = setup_encoder(c, p, e, 1)) != 0) return rc_;
+    c->defer_end = 1;                                            /* frame_end() is called below, after the post-encode scene cut had its say */
     x264_t *h = c->h;
     x264_frame_delete(h->fenc); x264_frame_delete(h->fdec);      /* made before b_have_lowres was known to x264_frame_new */
     h->frames.i_delay = h->param.i_bframe_adaptive == X264_B_ADAPT_TRELLIS ? X264_MAX(h->param.i_bframe, 3) * 4 : h->param.i_bframe;
@@ -582,6 +595,7 @@ static int run_stream(const refslice_params *p, const refslice_ext *e, const uin
             while (bframes--) x264_frame_push(h->frames.current, x264_frame_shift(h->frames.next));
         }
         h->fenc = x264_frame_shift(h->frames.current);
+do_encode:
         if (h->fenc->i_type == X264_TYPE_IDR) {
             h->frames.i_last_idr = h->fenc->i_frame;
             while (h->frames.reference[0]) x264_frame_push_unused(h, x264_frame_pop(h->frames.reference));   /* x264_reference_reset */
@@ -607,12 +621,55 @@ static int run_stream(const refslice_params *p, const refslice_ext *e, const uin
         h->mb.pic.i_fref[0] = h->i_ref0; h->mb.pic.i_fref[1] = h->i_ref1;
         /* x264_rc_analyse_slice reads frames.current behind the P frame; code_frame calls x264_ratecontrol_start */
         if ((rc_ = code_frame(c, p, e, o, o2, coded, h->fenc->i_frame)) != 0) return rc_;
+        /* x264_encoder_encode, encoder.c:1538-1541: the slice header carries h->i_frame_num, a kept picture advances it (never wrapped, never reset at an
+         * IDR -- except by the scene cut below) */
+        const int frame_num_used = i_frame_num;
+        if (h->fenc->b_kept_as_ref) i_frame_num++;
+        /* the post-encode scene cut, encoder.c:1603-1699: a P picture whose inter cost is no better than its intra cost is given up */
+        if (h->sh.i_type == SLICE_TYPE_P && h->param.i_scenecut_threshold >= 0 && !h->param.b_pre_scenecut) {
+            int64_t i_inter_cost = h->stat.frame.i_inter_cost, i_intra_cost = h->stat.frame.i_intra_cost;
+            float f_bias;
+            int i_gop_size = h->fenc->i_frame - h->frames.i_last_idr;
+            float f_thresh_max = h->param.i_scenecut_threshold / 100.0;
+            float f_thresh_min = f_thresh_max * h->param.i_keyint_min / (h->param.i_keyint_max * 4);
+            if (h->param.i_keyint_min == h->param.i_keyint_max) f_thresh_min = f_thresh_max;
+            if (h->stat.frame.i_mbs_analysed > 0) i_intra_cost = i_intra_cost * c->n / h->stat.frame.i_mbs_analysed;
+            if (i_gop_size < h->param.i_keyint_min / 4) f_bias = f_thresh_min / 4;
+            else if (i_gop_size <= h->param.i_keyint_min) f_bias = f_thresh_min * i_gop_size / h->param.i_keyint_min;
+            else f_bias = f_thresh_min + (f_thresh_max - f_thresh_min) * (i_gop_size - h->param.i_keyint_min) / (h->param.i_keyint_max - h->param.i_keyint_min);
+            f_bias = X264_MIN(f_bias, 1.0);
+            if (h->stat.frame.i_mbs_analysed > 0 && i_inter_cost >= (1.0 - f_bias) * i_intra_cost) {
+                int b;
+                giveups++;
+                i_frame_num--;
+                for (b = 0; h->frames.current[b] && IS_X264_TYPE_B(h->frames.current[b]->i_type); b++);
+                if (b > 0) {
+                    if (h->param.i_bframe_adaptive || b > 1) h->fenc->i_type = X264_TYPE_AUTO;
+                    x264_frame_sort_pts(h->frames.current);
+                    x264_frame_unshift(h->frames.next, h->fenc);
+                    h->fenc = h->frames.current[b - 1];
+                    h->frames.current[b - 1] = NULL;
+                    h->fenc->i_type = X264_TYPE_P;
+                    x264_frame_sort_dts(h->frames.current);
+                } else if (i_gop_size >= h->param.i_keyint_min) {
+                    i_frame_num = 0;
+                    h->fenc->i_type = X264_TYPE_IDR;
+                    h->fenc->i_poc = 0;
+                    while (h->frames.current[0]) x264_frame_push(h->frames.next, x264_frame_shift(h->frames.current));
+                    x264_frame_sort_pts(h->frames.next);
+                } else
+                    h->fenc->i_type = X264_TYPE_I;
+                goto do_encode;
+            }
+        }
+        frame_end(c, o2, coded);
+        o->stat[4 * coded + 3] = giveups; giveups = 0;          /* attempts the post-encode scene cut gave up before this picture was coded for good */
         if (o2->look_cost) {
             int32_t *lc = o2->look_cost + 8 * (size_t)coded;
             int d0 = h->i_ref0 && !IS_X264_TYPE_I(h->fenc->i_type) ? h->fenc->i_frame - h->fref0[0]->i_frame : 0;
             int d1 = is_b ? h->fref1[0]->i_frame - h->fenc->i_frame : 0;
             lc[0] = is_b ? 0 : h->fenc->i_cost_est[d0][d1]; lc[1] = is_b ? 0 : h->fenc->i_cost_est_aq[d0][d1];
-            lc[2] = is_b ? 0 : h->fenc->i_intra_mbs[d0]; lc[3] = h->fenc->i_cost_est[0][0]; lc[4] = d0; lc[5] = d1; lc[6] = h->fenc->i_type; lc[7] = 0;
+            lc[2] = is_b ? 0 : h->fenc->i_intra_mbs[d0]; lc[3] = h->fenc->i_cost_est[0][0]; lc[4] = d0; lc[5] = d1; lc[6] = h->fenc->i_type; lc[7] = frame_num_used;
         }
         coded++;
     }

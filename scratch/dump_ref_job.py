@@ -21,6 +21,10 @@ if sys.argv[1] == "stream":                     # python scratch/dump_ref_job.py
     name, k = sys.argv[2].split(":")
     c = T.chains(name, [s_ + 40 * int(sys.argv[3]) for s_ in T.SEEDS[name]])[int(k)]
     out = sys.argv[4]
+elif sys.argv[1] == "postsc":                   # python scratch/dump_ref_job.py postsc <seed> <out>: a lookahead test clip without --pre-scenecut (post-encode scene cuts)
+    c = dict(K.config(int(sys.argv[2])), pre_scenecut=0, subme=5, n_refs=2, inter=0x13)
+    c["scenecut_threshold"] = 40 if c["scenecut_threshold"] < 0 else c["scenecut_threshold"]
+    out = sys.argv[3]
 else:
     seed, k, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     c = T.random_config(seed)

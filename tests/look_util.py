@@ -76,7 +76,7 @@ class CpuLook:
         return int(out[0]), int(out[1]), int(out[2])
 
 
-def run_chain(lib, params, look, y, u, v, n_frames, log=None, speculative=True):
+def run_chain(lib, params, look, y, u, v, n_frames, log=None, speculative=True, giveups=None):
     """x264_encoder_encode's loop for one chain: feeds pictures, serves the lookahead's requests from `look`, returns what would be coded:
     [(frame, type, qp, f_qpm, ref0, ref1, lowres vectors of list 0 / 1 or None, i_satd)] in coding order."""
     la = LA.Lookahead(lib, params)
@@ -87,8 +87,13 @@ def run_chain(lib, params, look, y, u, v, n_frames, log=None, speculative=True):
             num = la.put()
             look.add(num, y[num], u[num], v[num])
             fed += 1
+        left = giveups[len(out)] if giveups is not None and len(out) < len(giveups) else 0     # (the post-encode scene cut's verdicts, from the reference's run)
         while True:
             kind, fr, needs = la.get(flushing, speculative)
+            if kind == LA.FRAME and left > 0:
+                left -= 1
+                la.scenecut()
+                continue
             if kind != LA.NEED:
                 break
             for (b, p0, p1, ds0, ds1, spec) in needs:

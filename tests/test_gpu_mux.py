@@ -85,7 +85,7 @@ def med_stream(hip_lib, p, w, h, n, pre_scenecut=0):
                 enc.sync()
                 enc.status()
                 cd = coded[0]
-                out.append(m.frame(frame=cd.frame, ftype=cd.type, qp=cd.qp, payload=enc.payloads()[0], n_ref0=cd.n_ref0, n_ref1=cd.n_ref1))
+                out.append(m.frame(frame=cd.frame, ftype=cd.type, qp=cd.qp, payload=enc.payloads()[0], n_ref0=cd.n_ref0, n_ref1=cd.n_ref1, frame_num_reset=cd.frame_num_reset))
                 order.append((cd.frame, cd.type, cd.qp))
     finally:
         enc.close()

@@ -37,6 +37,7 @@ def run_stream(hip_lib, cs, pipeline=False):
     clips = [K.clip(c["w"], c["h"], frames, c["cut"], c["t0"], c["slow"]) for c in cs]
     enc = encoder_for(hip_lib, c0, len(cs), pipeline)
     got = [[] for _ in cs]
+    run_stream.resets = [[] for _ in cs]               # per coded frame: the encoder says "scene-cut IDR: frame_num restarts" (Coded.frame_num_reset)
 
     def fill(pic, f):
         for b, (y, u, v) in enumerate(clips):
@@ -55,6 +56,7 @@ def run_stream(hip_lib, cs, pipeline=False):
             pl = enc.payloads()
             for cd in coded:
                 got[cd.chain].append((cd.frame, cd.slice_type, cd.qp, pl[cd.chain]))
+                run_stream.resets[cd.chain].append(int(cd.frame_num_reset))
     enc.close()
     return got
 
@@ -184,3 +186,35 @@ def test_stream_random_configuration_equals_reference(hip_lib, seed):
     got = run_stream(hip_lib, cs, pipeline=bool(seed & 1))
     for i, ck in enumerate(cs):
         check(got[i], K.reference_records(ck), ck, "seed %d chain %d %s" % (seed, i, {k: ck[k] for k in ("subme", "n_refs", "bframes", "b_adapt", "crf", "trellis", "direct_pred", "aq", "inter")}))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [11, 14, 19, 36, 37, 209, 226])
+def test_stream_post_encode_scenecut_equals_reference(hip_lib, seed):
+    """No --pre-scenecut (the reference's default): x264_encoder_encode looks at every coded P picture and, where an intra picture would have been as
+    good, gives the attempt up and codes again -- the picture as I or IDR, or the B picture before it as the P, with the queues rearranged
+    (R/encoder/encoder.c:1603-1699).  Clips with scene changes and repeated pictures, two chains per encoder so that one chain's second attempt
+    runs while the other has nothing to do: frame order, types, QPs, payloads, and the frame_num each slice header carries (restarted only by a
+    scene-cut IDR) against the reference's encoder."""
+    from x264_vs2008_amd import mux
+    c = dict(K.config(seed), pre_scenecut=0, subme=5, n_refs=2, inter=0x13)
+    if c["scenecut_threshold"] < 0:
+        c["scenecut_threshold"] = 40
+    cs = [dict(c), dict(c, t0=c["t0"] + 61, cut=max(c["cut"] - 2, 0))]
+    got = run_stream(hip_lib, cs)
+    resets, gave_up = run_stream.resets, 0
+    for i, ck in enumerate(cs):
+        a = K.reference_records(ck)
+        check(got[i], a, ck, "seed %d chain %d" % (seed, i))
+        gave_up += int(a["stat"][:ck["frames"], 3].sum())
+        # the muxer's own frame_num bookkeeping against the reference's h->i_frame_num
+        p = mux.encoder_params(hip_lib, width=ck["w"], height=ck["h"], rc_method=mux.RC_CQP, qp_constant=ck["qp"], bframe=ck["bframes"], keyint_max=ck["keyint"])
+        m = mux.AnnexB(hip_lib, p)
+        for f, (frame, st, qp, payload) in enumerate(got[i]):
+            poc = int(a["frame_info"][f][3])
+            ftype = (mux.TYPE_IDR if poc == 0 else mux.TYPE_I) if st == rs.SLICE_I else mux.TYPE_P if st == rs.SLICE_P else mux.TYPE_B
+            m.frame(frame=frame, ftype=ftype, qp=qp, payload=payload, frame_num_reset=resets[i][f])
+            used = m.frame_num - (0 if ftype == mux.TYPE_B else 1)
+            assert used == int(a["look_cost"][f][7]), "seed %d chain %d coded frame %d: frame_num %d, the reference %d" % (seed, i, f, used, int(a["look_cost"][f][7]))
+    assert gave_up > 0, "seed %d: no attempt was given up -- the clip does not test the scene cut" % seed
+

@@ -48,6 +48,26 @@ def test_host_lookahead_equals_reference_live(seed):
     assert not bad, "%s: %s" % (c, bad[:5])
 
 
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [11, 13, 14, 15, 19, 20, 26, 36, 37, 201, 208, 209, 214, 226, 229])
+def test_host_post_encode_scenecut_equals_reference_live(seed):
+    """Without --pre-scenecut: the reference's run tells which attempts its post-encode scene cut gave up (refslice_out.stat[..][3]); with the same
+    verdicts x264hip_lookahead_scenecut must rearrange the queues, re-type the pictures and run the rate control (x264_ratecontrol_start twice for
+    a picture coded twice) exactly as x264_encoder_encode does (encoder.c:1645-1699): order, types, QPs, i_satd, the vectors offered to the encode."""
+    c = dict(K.config(seed), pre_scenecut=0)
+    if c["scenecut_threshold"] < 0:
+        c["scenecut_threshold"] = 40
+    a = K.reference_records(c)
+    give = [int(a["stat"][f][3]) for f in range(c["frames"])]
+    lib = L.open_library()
+    y, u, v = K.clip(c["w"], c["h"], c["frames"], c["cut"], c["t0"], c["slow"])
+    look = U.CpuLook(lib, c["w"], c["h"], c["me"], 16, c["weightb"], c["bframe_bias"], c["bframes"])
+    mine = U.run_chain(lib, K.lookahead_params(c), look, y, u, v, c["frames"], giveups=give)
+    bad = K.compare(mine, K.records_of_reference(a, c["frames"]))
+    assert not bad, "%s (given up: %s): %s" % (c, give, bad[:5])
+    assert sum(give) > 0
+
+
 @pytest.mark.parametrize("seed", [0, 3, 6, 9, 17])
 def test_speculative_tasks_change_nothing(seed):
     """The batch of independent costs get() offers beside the one it asked for is an optimisation: with and without it the decisions, the

@@ -62,6 +62,8 @@ struct x264hip_lookahead {
     int i_input, i_last_idr, i_frame, i_delay, i_max_dpb, i_max_ref1;
     int slice_type;
     bool started, miss;
+    bool setup;                                // la->fenc's type-dependent state (last IDR, reference lists, POC) is in place
+    int frame_num_reset;                       // the frame handed out is a scene-cut IDR: x264_encoder_encode restarts h->i_frame_num for it (encoder.c:1682)
     x264hip_look_need needs[16];
     int n_needs;
     RC rc;
@@ -444,7 +446,7 @@ extern "C" x264hip_lookahead *x264hip_lookahead_new(const x264hip_lookahead_para
     if (!p || p->bframes < 0 || p->bframes > BF_MAX || p->mb_w <= 0 || p->mb_h <= 0 || p->keyint_max < 1) return nullptr;
     // pre_scenecut = 0 with a threshold >= 0: the queue then decides without scene cuts, as the reference's does, and x264_encoder_encode looks at
     // every P frame after coding it (encoder.c:1603-1699).  That look is the caller's (x264hip_frame_stats + x264hip_scenecut_post); what follows
-    // a hit -- the picture coded again as I / IDR, frames put back into this queue -- is not built: the caller must stop there.
+    // a hit is x264hip_lookahead_scenecut.
     LA *la = (LA *)calloc(1, sizeof(LA));
     if (!la) return nullptr;
     la->p = *p;
@@ -490,7 +492,11 @@ extern "C" int x264hip_lookahead_get(x264hip_lookahead *la, int flushing, x264hi
             while (bframes--) list_push(la->current, list_shift(la->next));
         }
         la->fenc = list_shift(la->current);
+        la->setup = false; la->frame_num_reset = 0;
+    }
+    if (!la->setup) {                                                                            // do_encode:, encoder.c:1471-1530
         LF *f = la->fenc;
+        la->setup = true;
         if (f->type == T_IDR) {
             la->i_last_idr = f->frame;
             while (la->reference[0]) list_pop(la->reference);                                    // x264_reference_reset
@@ -540,6 +546,7 @@ extern "C" int x264hip_lookahead_get(x264hip_lookahead *la, int flushing, x264hi
             out->lowres_l0 = out->ref0_frame >= 0 && f->frame - out->ref0_frame - 1 <= BF_MAX && f->searched[0][f->frame - out->ref0_frame - 1];
             out->lowres_l1 = out->ref1_frame >= 0 && out->ref1_frame - f->frame - 1 <= BF_MAX && f->searched[1][out->ref1_frame - f->frame - 1];
             out->i_satd = f->i_satd;
+            out->frame_num_reset = la->frame_num_reset;
         }
         la->started = true;
         return X264HIP_LOOK_FRAME;
@@ -586,6 +593,58 @@ extern "C" void x264hip_lookahead_end(x264hip_lookahead *la)
     }
     la->fenc = nullptr;
     la->started = false;
+    la->setup = false;
+}
+
+// x264_frame_sort (R/common/frame.c:957-975): by input number, or by type then input number
+static void list_sort(LF **l, int b_dts)
+{
+    bool ok;
+    if (!l[0]) return;
+    do {
+        ok = true;
+        for (int i = 0; l[i + 1]; i++) {
+            const int dtype = l[i]->type - l[i + 1]->type, dtime = l[i]->frame - l[i + 1]->frame;
+            if (b_dts ? dtype > 0 || (dtype == 0 && dtime > 0) : dtime > 0) { LF *t = l[i]; l[i] = l[i + 1]; l[i + 1] = t; ok = false; }
+        }
+    } while (!ok);
+}
+
+// The post-encode scene cut found the P picture just coded no better than an intra picture (x264hip_scenecut_post; R/encoder/encoder.c:1645-1699): the
+// attempt is given up -- no x264_ratecontrol_end, no x264_reference_update for it -- and the next x264hip_lookahead_get hands out what is coded
+// instead: the same picture as I / IDR, or, when B pictures wait before it, the last of them as the P (the given-up picture goes back to the head of
+// the undecided queue).  Returns 1 (same picture again), 2 (another picture), -1 if no P picture is being coded.
+extern "C" int x264hip_lookahead_scenecut(x264hip_lookahead *la)
+{
+    if (!la->started || !la->fenc || la->slice_type != ST_P) return -1;
+    LF *f = la->fenc;
+    const int gop = f->frame - la->i_last_idr;
+    int b = 0, ret = 1;
+    while (la->current[b] && IS_TYPE_B(la->current[b]->type)) b++;
+    la->frame_num_reset = 0;
+    if (b > 0) {
+        if (la->p.b_adapt || b > 1) f->type = T_AUTO;
+        list_sort(la->current, 0);
+        int n = list_len(la->next);                                                              // x264_frame_unshift
+        la->next[n + 1] = nullptr;
+        for (int i = n; i > 0; i--) la->next[i] = la->next[i - 1];
+        la->next[0] = f;
+        la->fenc = la->current[b - 1];
+        la->current[b - 1] = nullptr;
+        la->fenc->type = T_P;
+        list_sort(la->current, 1);
+        ret = 2;
+    } else if (gop >= la->p.keyint_min) {
+        f->type = T_IDR;
+        f->poc = 0;
+        while (la->current[0]) list_push(la->next, list_shift(la->current));
+        list_sort(la->next, 0);
+        la->frame_num_reset = 1;
+    } else
+        f->type = T_I;
+    la->started = false;
+    la->setup = false;
+    return ret;
 }
 
 extern "C" int x264hip_lookahead_oldest_live(const x264hip_lookahead *la)

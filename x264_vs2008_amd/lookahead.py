@@ -49,7 +49,8 @@ class Need(C.Structure):
 class Frame(C.Structure):
     """x264hip_look_frame"""
     _fields_ = [("frame", C.c_int), ("type", C.c_int), ("poc", C.c_int), ("kept_as_ref", C.c_int), ("qp", C.c_int), ("f_qpm", C.c_float),
-                ("ref0_frame", C.c_int), ("ref1_frame", C.c_int), ("lowres_l0", C.c_int), ("lowres_l1", C.c_int), ("i_satd", C.c_int)]
+                ("ref0_frame", C.c_int), ("ref1_frame", C.c_int), ("lowres_l0", C.c_int), ("lowres_l1", C.c_int), ("i_satd", C.c_int),
+                ("frame_num_reset", C.c_int)]
 
 
 def bind(lib):
@@ -60,6 +61,7 @@ def bind(lib):
     lib.x264hip_lookahead_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(Frame), C.POINTER(Need), C.c_int, C.POINTER(C.c_int)]
     lib.x264hip_lookahead_set_cost.argtypes = [C.c_void_p] + [C.c_int] * 7
     lib.x264hip_lookahead_end.argtypes = [C.c_void_p]
+    lib.x264hip_lookahead_scenecut.argtypes = [C.c_void_p]
     lib.x264hip_lookahead_oldest_live.argtypes = [C.c_void_p]
     return lib
 
@@ -104,6 +106,14 @@ class Lookahead:
 
     def end(self):
         self.lib.x264hip_lookahead_end(self.h)
+
+    def scenecut(self):
+        """Instead of end(): the post-encode scene cut gave up the P picture just coded (x264hip_lookahead_scenecut).  1: get() hands the same
+        picture out again as I / IDR; 2: another picture (the last B before it, as the P)."""
+        rc = self.lib.x264hip_lookahead_scenecut(self.h)
+        if rc < 0:
+            raise RuntimeError("x264hip_lookahead_scenecut: no P picture in flight")
+        return rc
 
     def oldest_live(self):
         return self.lib.x264hip_lookahead_oldest_live(self.h)
@@ -305,9 +315,10 @@ class LookaheadBatch:
         self.dev.prepare(frame)
         return frame
 
-    def get(self, flushing=False):
+    def get(self, flushing=False, only=None):
+        """only: the chains to ask (the others keep None) -- the second attempt after a post-encode scene cut."""
         n = len(self.chains)
-        out, waiting = [None] * n, list(range(n))
+        out, waiting = [None] * n, list(range(n) if only is None else only)
         while waiting:
             tasks, owners, still = [], [], []
             for ci in waiting:

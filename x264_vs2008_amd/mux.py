@@ -105,13 +105,15 @@ class AnnexB:
         self.frame_num, self.idr_pic_id, self.last_idr = 0, 0, 0
         self.refs = []                     # [(poc, frame_num)] of the pictures kept as references since the last IDR
 
-    def frame(self, frame, ftype, qp, payload, n_ref0=None, n_ref1=None, direct_spatial=1):
+    def frame(self, frame, ftype, qp, payload, n_ref0=None, n_ref1=None, direct_spatial=1, frame_num_reset=False):
         """All NALs of one x264_encoder_encode call: `frame` is the picture's input number, `ftype` its X264_TYPE_*, `qp` the slice QP,
         `payload` the sweep's slice_data() bytes (CAVLC: the CAVLC pass's), n_ref0 / n_ref1 the active references (h->i_ref0 / i_ref1;
         None: what x264_reference_build_list finds among the pictures this muxer saw kept, encoder.c:911-981)."""
         lib, p = self.lib, self.p
         out = b""
         sh = SliceHeader()
+        if frame_num_reset:                # a scene-cut IDR: the one place the reference restarts i_frame_num (encoder.c:1682)
+            self.frame_num = 0
         if ftype == TYPE_IDR:
             self.last_idr = frame
             self.refs = []

@@ -32,7 +32,7 @@ class ChainSweep(C.Structure):
 
 class Coded:
     """What one chain coded in a step."""
-    __slots__ = ("chain", "frame", "type", "slice_type", "qp", "f_qpm", "poc", "n_ref0", "n_ref1", "i_satd")
+    __slots__ = ("chain", "frame", "type", "slice_type", "qp", "f_qpm", "poc", "n_ref0", "n_ref1", "i_satd", "frame_num_reset")
 
     def __repr__(self):
         return "Coded(chain=%d frame=%d type=%d qp=%d poc=%d)" % (self.chain, self.frame, self.type, self.qp, self.poc)
@@ -106,13 +106,17 @@ class StreamEncoder(ChainEncoder):
         self.coded_now = [None] * B
         self.n_sweeps = 0
         # Without --pre-scenecut the reference looks at every P frame AFTER coding it (x264_encoder_encode, encoder.c:1603-1699) and, if it finds a
-        # scene cut, codes the picture again as I / IDR.  The decision is made here from the sweep's own statistics (x264hip_frame_stats +
-        # x264hip_scenecut_post); the re-encode is not built: status() raises when the reference would have taken it.
+        # scene cut, codes again: the picture as I / IDR, or the B picture before it as the P.  The decision is made from the sweep's own
+        # statistics (x264hip_frame_stats + x264hip_scenecut_post), the queue surgery by the library (x264hip_lookahead_scenecut), the second
+        # attempt inside the same step (step()).
         self.post_scenecut = bool(scenecut_threshold >= 0 and not pre_scenecut)
-        self._post, self.stats_dev = [], None
+        self._post, self.stats_dev, self._undo, self.n_given_up = [], None, {}, 0
         if self.post_scenecut:
             if o["keyint"] <= 0:
                 raise ValueError("StreamEncoder: the post-encode scene cut needs a finite keyint")
+            if o["noise_reduction"]:
+                raise ValueError("StreamEncoder: --nr with the post-encode scene cut: a given-up attempt has already added to the noise-reduction sums "
+                                 "(the reference's has too, but per frame, not per batch); run with pre_scenecut=1")
             self.stats_dev = [DeviceArray(lib, (B, 32), np.uint8) for _ in self.pool]
         self.sweep_events = None       # set to [] to collect (start, stop, chains, algorithmic bytes) HIP events around every step's sweep launches
 
@@ -137,17 +141,44 @@ class StreamEncoder(ChainEncoder):
         Returns the list of Coded for the chains that coded a frame (empty while the B buffer fills; empty for good once flushed).
         With n_frames given to the constructor the next call's lookahead is prepared before this one returns (fill is then also asked
         for the following picture) and the flush starts by itself after n_frames pictures."""
-        L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
         frames = self._prep if self._prep is not None else self._prepare(fill)
         self._prep = None
-        B = c.batch
-        self.coded_now = [None] * B
-        todo = [(ci, fr) for ci, fr in enumerate(frames) if fr is not None]
-        if not todo:
+        self.coded_now = [None] * self.ctx.batch
+        pipelined = self.n_frames is not None and not self.post_scenecut
+        if not any(fr is not None for fr in frames):
             self._coding = set()
-            if self.n_frames is not None and not self.flushing:
+            if pipelined and not self.flushing:
                 self._prep = self._prepare(fill)
             return []
+        out = self._sweep(frames)
+        if self.post_scenecut:
+            # x264_encoder_encode looks at the P picture it just coded (encoder.c:1603-1699) and, if an intra picture would have been as good, gives the
+            # attempt up and codes again -- the same picture as I / IDR or the B picture before it as the P -- inside the same call.  Here: wait for
+            # the sweep, ask (x264hip_frame_stats + x264hip_scenecut_post), and run the given-up chains again, until none is left.  Each round costs a whole
+            # frame time for a few chains: fine for a handful of streams, a reason to decide scene cuts in the lookahead (pre_scenecut = 1) for thousands.
+            done = [cd.chain for cd in out]
+            while True:
+                self.ctx.sync()
+                hits = self._scenecut_hits()
+                if not hits:
+                    break
+                for ci in hits:
+                    self._give_up(ci)
+                again = self.lb.get(self.flushing, only=hits)
+                self.src_ctx.sync()
+                redo = {cd.chain: cd for cd in self._sweep(again)}
+                out = [redo.get(cd.chain, cd) for cd in out]
+                self.n_given_up += len(hits)
+            self.lb.end(done)
+        if pipelined and not self.flushing:
+            self._prep = self._prepare(fill)            # beside the sweep just launched
+        return out
+
+    def _sweep(self, frames):
+        """The chain-table launch for the chains that have a frame in `frames` (per chain an x264hip_look_frame or None), then the filters of the kept ones."""
+        L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
+        B = c.batch
+        todo = [(ci, fr) for ci, fr in enumerate(frames) if fr is not None]
         keep = []                                       # everything the C call reads must outlive it
         entries = (ChainSweep * len(todo))()
         b = self.cqm.bufs
@@ -161,7 +192,6 @@ class StreamEncoder(ChainEncoder):
             if cd.slice_type != SLICE_B:                   # kept: filtered below
                 filt.setdefault(pic_i, []).append(ci)
         c.sync()                                        # the previous step's sweep and filters are done: their tables, element lists and pictures are free
-        self.check_scenecut()                           # x264_encoder_encode's look at the P frames it just coded (no --pre-scenecut)
         for pic_i in written:
             c.check(L.x264hip_mb_state_clear_progress(c.h, C.byref(self.states[pic_i].st)), "mb_state_clear_progress")
         ev = None
@@ -202,12 +232,35 @@ class StreamEncoder(ChainEncoder):
                     c.check(L.x264hip_frame_stats(c.h, C.byref(self.states[pic_i].st), self.stats_dev[pic_i].p), "frame_stats")
                     self._post += [(pic_i, ci, self.coded_now[ci].frame, self.coded_now[ci].frame - self.c_last_idr[ci]) for ci in ps]
         self._keep = keep
-        self.lb.end([ci for ci, _ in todo])
+        if not self.post_scenecut:
+            self.lb.end([ci for ci, _ in todo])
         self.last_bufs, self.last_ctx = rb, c
         self._coding = {cd.frame for cd in out}
-        if self.n_frames is not None and not self.flushing:
-            self._prep = self._prepare(fill)            # beside the sweep just launched
         return out
+
+    def _scenecut_hits(self):
+        """After sync(): the chains whose P picture of the last sweep the reference would give up (encoder.c:1603-1644)."""
+        if not self._post:
+            return []
+        L, d, lp = self.lib, self.ctx.dims, self.la_params
+        L.x264hip_scenecut_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        got, hits = {}, []
+        for pic_i, ci, frame, gop in self._post:
+            if pic_i not in got:
+                got[pic_i] = self.stats_dev[pic_i].get()
+            rec = np.ascontiguousarray(got[pic_i][ci])
+            if L.x264hip_scenecut_post(rec.ctypes.data_as(C.c_void_p), d.mb_w * d.mb_h, gop, lp.scenecut_threshold, lp.keyint_min, lp.keyint_max):
+                hits.append(ci)
+        self._post = []
+        return hits
+
+    def _give_up(self, ci):
+        """The attempt of chain ci is dropped: its reconstruction never joined the DPB, its payload is never read, its frame was never counted
+        (x264_reference_update and x264_encoder_frame_end are not reached for it); the chain's queue rearranges itself (x264hip_lookahead_scenecut)."""
+        self.crefs[ci], self.c_coded[ci] = self._undo[ci]
+        self.coded_now[ci] = None
+        self.lb.chains[ci].scenecut()
+        self.lb.pending[ci] = None
 
     def _entry(self, ci, fr, keep):
         """One chain's sweep for the frame its queue handed it: the x264hip_chain_sweep record (whatever it points at goes into `keep`), the
@@ -263,6 +316,8 @@ class StreamEncoder(ChainEncoder):
         cd = Coded()
         cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
         cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
+        cd.frame_num_reset = int(getattr(fr, "frame_num_reset", 0))
+        self._undo[ci] = (list(refs_all), self.c_coded[ci])
         self.coded_now[ci] = cd
         if stype != SLICE_B:                           # kept: filtered below, then this chain's newest reference
             self.crefs[ci] = ([(pic_i, poc, mine)] + refs_all)[:self.dpb]
@@ -290,26 +345,6 @@ class StreamEncoder(ChainEncoder):
         c = self.ctx
         for s in self.states:
             c.check(self.lib.x264hip_slice_sweep_status(c.h, C.byref(s.st)), "slice_sweep_status")
-        self.check_scenecut()
-
-    def check_scenecut(self):
-        """After sync(): x264_encoder_encode's look at the P frames of the last step (encoder.c:1603-1644).  Raises if the reference would now
-        code one of them again as I / IDR."""
-        if not self._post:
-            return
-        L, d, lp = self.lib, self.ctx.dims, self.la_params
-        L.x264hip_scenecut_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-        got = {}
-        for pic_i, ci, frame, gop in self._post:
-            if pic_i not in got:
-                got[pic_i] = self.stats_dev[pic_i].get()
-            rec = np.ascontiguousarray(got[pic_i][ci])
-            if L.x264hip_scenecut_post(rec.ctypes.data_as(C.c_void_p), d.mb_w * d.mb_h, gop, lp.scenecut_threshold, lp.keyint_min, lp.keyint_max):
-                st = rec.view(np.int64)[:2], rec.view(np.int32)[4:]
-                raise RuntimeError("chain %d, input frame %d: the reference's post-encode scene cut fires here (intra / inter cost %d / %d, analysed / I / P / skip "
-                                   "%s) and codes the picture again as I or IDR -- that re-encode is not built: run with pre_scenecut=1" %
-                                   (ci, frame, st[0][0], st[0][1], list(st[1])))
-        self._post = []
 
     def close(self):
         self.sync()

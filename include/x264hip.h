@@ -360,6 +360,9 @@ typedef struct x264hip_slice_b {
     int weightb;                         /* param.analyse.b_weighted_bipred */
     const int16_t *lowres_mv1;           /* fenc->lowres_mvs[1][fref1[0]->i_frame - fenc->i_frame - 1], as x264hip_slice_params.lowres_mv, or NULL */
     int direct_spatial;                  /* sh.b_direct_spatial_mv_pred; 0 = temporal (R/common/macroblock.c:155-224): needs rd.stale in every sweep of the chain */
+    int32_t *direct_score;               /* --direct auto (h->mb.b_direct_auto_write): device [batch][2].  The sweep then predicts BOTH direct modes in every
+                                          * macroblock and leaves h->stat.frame.i_direct_score[0 temporal, 1 spatial] here (R/encoder/analyse.c:2476-2496); the host
+                                          * keeps the running scores that pick direct_spatial of the next B frame (encoder.c:113-118,1777-1790).  NULL: off.  Needs rd.stale. */
 } x264hip_slice_b;
 
 /* h->nr_residual_sum / nr_count / nr_offset of every chain of the batch (R/common/common.h:308-310), device memory:
@@ -529,6 +532,14 @@ void x264hip_lookahead_end(x264hip_lookahead *la);
  * -- the same picture as I / IDR, or, with B pictures waiting before it, the last of them as the P.  Returns 1 (same picture), 2 (another), -1 (no P
  * picture in flight).  The rate control keeps what x264_ratecontrol_start did for the given-up attempt, as the reference's does. */
 int x264hip_lookahead_scenecut(x264hip_lookahead *la);
+/* Running x264hip_lookahead_end / _put / _get for the NEXT frame ahead of that verdict (beside the sweep whose P picture is being judged) is possible with
+ * a copy of the state taken before them: x264hip_lookahead_save (0, or -1 if more pictures are queued than the copy holds: do not run ahead then) into
+ * x264hip_lookahead_state_bytes() bytes, and, if the verdict is "give up", x264hip_lookahead_restore -- back to the frame in flight, the pictures that came
+ * in meanwhile queued again -- followed by x264hip_lookahead_scenecut.  Costs computed for the abandoned decisions are dropped with them (they would be
+ * computed again, with the same result, if asked for). */
+size_t x264hip_lookahead_state_bytes(void);
+int x264hip_lookahead_save(const x264hip_lookahead *la, void *buf);
+void x264hip_lookahead_restore(x264hip_lookahead *la, const void *buf);
 /* frames the caller may drop now: every input number < the returned one is neither queued, nor last_nonb, nor a reference */
 int x264hip_lookahead_oldest_live(const x264hip_lookahead *la);
 

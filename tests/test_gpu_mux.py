@@ -85,7 +85,8 @@ def med_stream(hip_lib, p, w, h, n, pre_scenecut=0):
                 enc.sync()
                 enc.status()
                 cd = coded[0]
-                out.append(m.frame(frame=cd.frame, ftype=cd.type, qp=cd.qp, payload=enc.payloads()[0], n_ref0=cd.n_ref0, n_ref1=cd.n_ref1, frame_num_reset=cd.frame_num_reset))
+                out.append(m.frame(frame=cd.frame, ftype=cd.type, qp=cd.qp, payload=enc.payloads()[0], n_ref0=cd.n_ref0, n_ref1=cd.n_ref1, frame_num_reset=cd.frame_num_reset,
+                                   direct_spatial=cd.direct_spatial))
                 order.append((cd.frame, cd.type, cd.qp))
     finally:
         enc.close()
@@ -103,3 +104,15 @@ def test_med_stream_md5(hip_lib, cfg):
     stream = b"".join(nals)
     assert len(nals) == n, order
     assert hashlib.md5(stream).hexdigest() == M.STREAM_MD5[cfg], "%d bytes, coded %s" % (len(stream), order)
+
+
+def test_c4_slow_stream_md5(hip_lib):
+    """BASELINE config 4's flag set as stated (SLOW: --ref 5 --b-adapt 2 --me umh --subme 8 --direct auto, the post-encode scene cut) on hd24:
+    the product's stream has the md5 of the reference command line's file.  --direct auto: every B macroblock predicts both direct modes, the
+    running skip scores pick each B frame's mode (temporal for the first, spatial later on this clip)."""
+    import mux_cases as M
+    p = mux.encoder_params(hip_lib, width=1920, height=1080, **M.SLOW)
+    nals, order = med_stream(hip_lib, p, 1920, 1080, 24)
+    stream = b"".join(nals)
+    assert len(nals) == 24, order
+    assert hashlib.md5(stream).hexdigest() == M.STREAM_MD5["C4_SLOW_hd24"], "%d bytes, coded %s" % (len(stream), order)

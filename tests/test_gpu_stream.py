@@ -38,6 +38,7 @@ def run_stream(hip_lib, cs, pipeline=False):
     enc = encoder_for(hip_lib, c0, len(cs), pipeline)
     got = [[] for _ in cs]
     run_stream.resets = [[] for _ in cs]               # per coded frame: the encoder says "scene-cut IDR: frame_num restarts" (Coded.frame_num_reset)
+    run_stream.direct_spatial = [[] for _ in cs]       # ... and the direct mode a B slice's header carries
 
     def fill(pic, f):
         for b, (y, u, v) in enumerate(clips):
@@ -57,6 +58,7 @@ def run_stream(hip_lib, cs, pipeline=False):
             for cd in coded:
                 got[cd.chain].append((cd.frame, cd.slice_type, cd.qp, pl[cd.chain]))
                 run_stream.resets[cd.chain].append(int(cd.frame_num_reset))
+                run_stream.direct_spatial[cd.chain].append(int(cd.direct_spatial))
     enc.close()
     return got
 
@@ -201,7 +203,9 @@ def test_stream_post_encode_scenecut_equals_reference(hip_lib, seed):
     if c["scenecut_threshold"] < 0:
         c["scenecut_threshold"] = 40
     cs = [dict(c), dict(c, t0=c["t0"] + 61, cut=max(c["cut"] - 2, 0))]
-    got = run_stream(hip_lib, cs)
+    # odd seeds: the encoder knows the clip's length and runs the next call's lookahead AHEAD of the verdicts, beside the sweep, with a copy of the judged
+    # chains' queues to come back to (x264hip_lookahead_save / _restore)
+    got = run_stream(hip_lib, cs, pipeline=bool(seed & 1))
     resets, gave_up = run_stream.resets, 0
     for i, ck in enumerate(cs):
         a = K.reference_records(ck)
@@ -218,3 +222,26 @@ def test_stream_post_encode_scenecut_equals_reference(hip_lib, seed):
             assert used == int(a["look_cost"][f][7]), "seed %d chain %d coded frame %d: frame_num %d, the reference %d" % (seed, i, f, used, int(a["look_cost"][f][7]))
     assert gave_up > 0, "seed %d: no attempt was given up -- the clip does not test the scene cut" % seed
 
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [3, 13, 21, 26, 35, 203])
+def test_stream_direct_auto_equals_reference(hip_lib, seed):
+    """--direct auto: every B macroblock predicts BOTH direct modes (the other one first, then the frame's; R/encoder/analyse.c:2476-2496) and credits each
+    with the skip it would give; the running scores pick every B frame's mode and decay as x264_encoder_frame_end lets them (encoder.c:113-118,
+    1777-1790).  Clips with B frames (fixed pattern and b-adapt 1 / 2), below and with the RD levels, two chains with different content: order, types,
+    QPs, payloads -- and the direct_spatial_mv_pred bit of every B slice header -- against the reference's encoder."""
+    base = K.config(seed)
+    c = dict(base, direct_pred=3, bframes=max(base["bframes"], 2), subme=[4, 6, 7, 5, 8, 7][seed % 6], n_refs=2, inter=0x113 if seed % 2 else 0x13, trellis=seed % 3 == 0)
+    cs = [dict(c), dict(c, t0=c["t0"] + 61, slow=1 + (c["slow"] % 3))]
+    got = run_stream(hip_lib, cs)
+    n_b, modes = 0, set()
+    for i, ck in enumerate(cs):
+        a = K.reference_records(ck)
+        check(got[i], a, ck, "seed %d chain %d" % (seed, i))
+        for f in range(ck["frames"]):
+            if int(a["frame_info"][f][0]) == rs.SLICE_B:
+                n_b += 1
+                modes.add(int(a["frame_info2"][f][3]))
+                assert run_stream.direct_spatial[i][f] == int(a["frame_info2"][f][3]), "seed %d chain %d coded frame %d: direct mode" % (seed, i, f)
+    assert n_b > 0

@@ -141,7 +141,7 @@ static int sweep_build(x264hip_frame_ctx *c, const x264hip_picture *fenc, const 
     const x264hip_slice_b *pb = is_b ? p->b : nullptr;
     if (is_b) {
         if (!pb || !pb->fref1 || !pb->l1_state || !p->rd) { set_error("slice_sweep: a B slice needs x264hip_slice_params.b (list 1) and .rd (the raster variant)"); return -1; }
-        if (!pb->direct_spatial && !p->rd->stale) { set_error("slice_sweep: temporal direct prediction needs x264hip_slice_rd.stale (in every sweep of the chain)"); return -1; }
+        if ((!pb->direct_spatial || pb->direct_score) && !p->rd->stale) { set_error("slice_sweep: temporal direct prediction needs x264hip_slice_rd.stale (in every sweep of the chain)"); return -1; }
         if (p->subme < 2 || p->subme > 8 || !p->rd->write || !p->cabac) { set_error("slice_sweep: B slices are built for subme 2..8 with the CABAC writer in the loop (subme 9 refines a B macroblock's vectors by RD: x264_me_refine_bidir_rd, not built)"); return -1; }
         if (p->noise_reduction || p->lossless) { set_error("slice_sweep: B slices with --nr / lossless are not built"); return -1; }
         if (!out->mv1 || !pb->l1_state->mb_type) { set_error("slice_sweep: mb_state without list-1 arrays"); return -1; }
@@ -266,10 +266,11 @@ static int sweep_build(x264hip_frame_ctx *c, const x264hip_picture *fenc, const 
         r.stale = prd->stale;
         if (is_b) {
             r.direct_temporal = !pb->direct_spatial;
+            r.direct_score = pb->direct_score;
             r.mv1 = out->mv1; r.ref1 = (signed char *)out->ref1; r.mvr1 = out->mvr1; r.mvd1 = out->mvd1; r.skipbp = out->skipbp;
             r.col_type = (const signed char *)pb->l1_state->mb_type; r.col_ref = (const signed char *)pb->l1_state->ref; r.col_mv = pb->l1_state->mv;
             // the extended B kernel (temporal direct prediction, the lookahead's candidates) only where it is needed: the plain one is 6-8 % faster
-            kind = r.direct_temporal || a.lowres0 || a.lowres1 ? SW_KIND_BT : SW_KIND_B;
+            kind = r.direct_temporal || r.direct_score || a.lowres0 || a.lowres1 ? SW_KIND_BT : SW_KIND_B;
         } else
             kind = mbrd >= 2 ? SW_KIND_RF : SW_KIND_RD;     // subme 8-9: the I / P kernel with the RD refinement (slice_refine.h)
     }

@@ -647,6 +647,58 @@ extern "C" int x264hip_lookahead_scenecut(x264hip_lookahead *la)
     return ret;
 }
 
+// A copy of everything x264hip_lookahead_end / _put / _get change, so that a caller may run them AHEAD of the post-encode scene cut's verdict (beside
+// the sweep whose P picture is being judged) and come back if the verdict is "give up": the queues (pointers into the ring), the frame in flight and
+// its lists, the rate control, and of every queued picture the fields a decision rewrites.  Costs that arrived meanwhile stay (they are facts).
+namespace {
+enum { SAVED_LF = 96 };
+struct Saved {
+    LF *next[MAX_LENGTH + 8], *current[MAX_LENGTH + 8], *reference[16 + 2];
+    LF *last_nonb, *fenc, *fref0[16 + 2], *fref1[16 + 2];
+    int n_ref0, n_ref1, i_input, i_last_idr, i_frame, slice_type, frame_num_reset;
+    bool started, setup;
+    RC rc;
+    int n_lf;
+    struct { LF *f; LF copy; } lf[SAVED_LF];             // every picture a queue, the DPB or the frame in flight names: whole records (types, costs, what is "searched")
+};
+}
+extern "C" size_t x264hip_lookahead_state_bytes(void) { return sizeof(Saved); }
+extern "C" int x264hip_lookahead_save(const x264hip_lookahead *la, void *buf)
+{
+    Saved *s = (Saved *)buf;
+    memcpy(s->next, la->next, sizeof(s->next)); memcpy(s->current, la->current, sizeof(s->current)); memcpy(s->reference, la->reference, sizeof(s->reference));
+    s->last_nonb = la->last_nonb; s->fenc = la->fenc; memcpy(s->fref0, la->fref0, sizeof(s->fref0)); memcpy(s->fref1, la->fref1, sizeof(s->fref1));
+    s->n_ref0 = la->n_ref0; s->n_ref1 = la->n_ref1; s->i_input = la->i_input; s->i_last_idr = la->i_last_idr; s->i_frame = la->i_frame;
+    s->slice_type = la->slice_type; s->frame_num_reset = la->frame_num_reset; s->started = la->started; s->setup = la->setup; s->rc = la->rc;
+    s->n_lf = 0;
+    bool full = false;
+    auto keep = [&](LF *f) {
+        if (!f) return;
+        for (int i = 0; i < s->n_lf; i++) if (s->lf[i].f == f) return;
+        if (s->n_lf >= SAVED_LF) { full = true; return; }
+        s->lf[s->n_lf].f = f; s->lf[s->n_lf].copy = *f; s->n_lf++;
+    };
+    for (int i = 0; la->next[i]; i++) keep(la->next[i]);
+    for (int i = 0; la->current[i]; i++) keep(la->current[i]);
+    for (int i = 0; la->reference[i]; i++) keep(la->reference[i]);
+    keep(la->fenc); keep(la->last_nonb);
+    return full ? -1 : 0;
+}
+// back to the saved state; pictures that came in since (x264hip_lookahead_put) are queued again as put left them, in input order
+extern "C" void x264hip_lookahead_restore(x264hip_lookahead *la, const void *buf)
+{
+    const Saved *s = (const Saved *)buf;
+    const int i_input_now = la->i_input;
+    memcpy(la->next, s->next, sizeof(s->next)); memcpy(la->current, s->current, sizeof(s->current)); memcpy(la->reference, s->reference, sizeof(s->reference));
+    la->last_nonb = s->last_nonb; la->fenc = s->fenc; memcpy(la->fref0, s->fref0, sizeof(s->fref0)); memcpy(la->fref1, s->fref1, sizeof(s->fref1));
+    la->n_ref0 = s->n_ref0; la->n_ref1 = s->n_ref1; la->i_last_idr = s->i_last_idr; la->i_frame = s->i_frame;
+    la->slice_type = s->slice_type; la->frame_num_reset = s->frame_num_reset; la->started = s->started; la->setup = s->setup; la->rc = s->rc;
+    for (int i = 0; i < s->n_lf; i++) *s->lf[i].f = s->lf[i].copy;
+    la->i_input = s->i_input;
+    for (int n = s->i_input; n < i_input_now; n++) x264hip_lookahead_put(la);
+    la->n_needs = 0; la->miss = false;
+}
+
 extern "C" int x264hip_lookahead_oldest_live(const x264hip_lookahead *la)
 {
     int m = la->i_input;

@@ -286,8 +286,14 @@
         if (bstep == BS_PRE) {
             cache_fenc_satd();
             type = T_B_SKIP;
-            bool temporal = false;
-            if constexpr (TD) temporal = rd.direct_temporal != 0;
+            bool frame_temporal = false, dauto = false;
+            if constexpr (TD) { frame_temporal = rd.direct_temporal != 0; dauto = rd.direct_score != nullptr; }
+            bool b_skip = false, prev_ok = false;
+            // --direct auto (h->mb.b_direct_auto_write, R/encoder/analyse.c:2476-2496): BOTH direct modes are predicted in every macroblock -- the other one
+            // first, then the frame's -- and each is credited with the skip it would give; the frame's stays in the caches and in fdec
+            for (int it = dauto ? 0 : 1; it < 2; it++) {
+            const bool temporal = it == 0 ? !frame_temporal : frame_temporal;
+            direct_ok = true;
             if (temporal) {
                 // ---- x264_mb_predict_mv_direct16x16, temporal (R/common/macroblock.c:155-224; direct_8x8_inference: the corner blocks) ----
                 const int type_col = UNI((rd.col_type + cb)[mb]);
@@ -338,17 +344,47 @@
             }
             }
             WAVE_SYNC();
-            if (direct_ok && lane < 16) {
+            // x264_mb_predict_mv_direct16x16's b_changed (R/common/macroblock.c:323-343): asked for the second prediction when the first was available
+            bool changed = true;
+            if (dauto && it == 1 && prev_ok && direct_ok) {
+                const int type_col = UNI((rd.col_type + cb)[mb]);
+                int diff = 0;
+                if (IS_INTRA_T(type_col) || type_col == T_P_SKIP) {
+                    if (lane == 0) diff = sb.dref[0][0] != sr.cref[12] || sb.dref[1][0] != sb.cref1[12] || sb.dmv[0][0][0] != sr.cmv[12][0] || sb.dmv[0][0][1] != sr.cmv[12][1] ||
+                                          sb.dmv[1][0][0] != sb.cmv1[12][0] || sb.dmv[1][0][1] != sb.cmv1[12][1];
+                } else {
+                    if (lane < 16) {
+                        const int k = 12 + (lane & 3) + 8 * (lane >> 2);
+                        diff = sb.dmv[0][lane][0] != sr.cmv[k][0] || sb.dmv[0][lane][1] != sr.cmv[k][1] || sb.dmv[1][lane][0] != sb.cmv1[k][0] || sb.dmv[1][lane][1] != sb.cmv1[k][1];
+                    }
+                    if (lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); diff |= sb.dref[0][lane] != sr.cref[k] || sb.dref[1][lane] != sb.cref1[k]; }
+                }
+                changed = __builtin_amdgcn_ballot_w64(diff != 0) != 0;
+                WAVE_SYNC();
+            }
+            if (direct_ok && changed && lane < 16) {
                 const int k = 12 + (lane & 3) + 8 * (lane >> 2);
                 sb.dmv[0][lane][0] = sr.cmv[k][0]; sb.dmv[0][lane][1] = sr.cmv[k][1]; sb.dmv[1][lane][0] = sb.cmv1[k][0]; sb.dmv[1][lane][1] = sb.cmv1[k][1];
             }
-            if (direct_ok && lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); sb.dref[0][lane] = sr.cref[k]; sb.dref[1][lane] = sb.cref1[k]; }
-            bool b_skip = false;
+            if (direct_ok && changed && lane < 4) { const int k = 12 + 2 * (lane & 1) + 16 * (lane >> 1); sb.dref[0][lane] = sr.cref[k]; sb.dref[1][lane] = sb.cref1[k]; }
+            if (dauto) {
+                if (direct_ok) {
+                    if (changed) {
+                        WAVE_SYNC();
+                        finals_from_cache();
+                        mc_b();
+                        b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;
+                    }
+                    if (temporal) dscore0 += b_skip; else dscore1 += b_skip;
+                } else
+                    b_skip = false;
+                prev_ok = direct_ok;
+            }
+            }                                       // (the two predictions of --direct auto)
             if (direct_ok) {
-                finals_from_cache();
-                mc_b();
+                if (!dauto) { finals_from_cache(); mc_b(); }
                 if (mbrd) { bskip_cost = ssd_mb(); b_skip = bskip_cost <= ((6 * Q.lambda2 + 128) >> 8); }      // "6 = minimum cavlc cost of a non-skipped MB"
-                else b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;   // x264_macroblock_probe_bskip
+                else if (!dauto) b_skip = sw_probe_pskip(s, refs, a, Q, 0, 0, mbx, mby, oy, oc, by_, bc_, lane, true) != 0;   // x264_macroblock_probe_bskip
             }
             if (b_skip) { skip_mc = 1; fin = true; }
             else {

@@ -165,6 +165,7 @@ struct SwRd {                       // kernel argument
     const signed char *col_type, *col_ref;
     const i16 *col_mv;
     int direct_temporal;            // !sh.b_direct_spatial_mv_pred
+    int *direct_score;              // --direct auto: [batch][2] h->stat.frame.i_direct_score ({temporal, spatial}); NULL: off
     i16 *stale;                     // [batch][8]: the cache entry of block 12 that survives macroblocks and frames (x264hip_slice_rd.stale)
 };
 // what a B slice adds to the wavefront's LDS: list 1 of the motion caches, the direct prediction, the analysis records
@@ -1394,6 +1395,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
     u8 *payload0 = nullptr;
     int last_qp = a.qp, last_dqp = 0, prev_coded = 0, intra_before = 0;      // h->mb.i_last_qp / i_last_dqp; the previous macroblock "has coefficients"
+    int dscore0 = 0, dscore1 = 0;                                           // h->stat.frame.i_direct_score[temporal / spatial] (--direct auto)
+    (void)dscore0; (void)dscore1;
     if constexpr (RD) {
         if (rd.write) {
             payload0 = rd.payload + (size_t)bz * rd.payload_cap + 64;
@@ -2702,6 +2705,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
   }   // rows
     if constexpr (RD) {     // x264_slice_write's end (R/encoder/encoder.c:1269-1273)
         if (rd.write && lane == 0) { cd_encode_flush(cab, rd.i_frame + bz * rd.i_frame_stride); rd.payload_len[bz] = (int)(cab.p - payload0); }
+        if constexpr (TD) if (rd.direct_score && lane == 0) { rd.direct_score[2 * bz] = dscore0; rd.direct_score[2 * bz + 1] = dscore1; }
         if constexpr (TD) {
             if (rd.stale && lane == 30) { i16 *sp = rd.stale + (size_t)bz * 8; for (int k = 0; k < 6; k++) sp[k] = sb.stale[k]; }
         } else if (!BS && rd.stale && is_p && lane == 0) {            // (an I slice never touches the motion cache)

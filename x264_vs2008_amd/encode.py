@@ -16,7 +16,7 @@ given at once are coded as chains of one batch.
 
 Readers: raw I420 (R/muxers.c:63-122: frame i at i * w * h * 3 / 2) and YUV4MPEG2 (:124-316: W, H, F from the stream header, C420* only, every
 FRAME header skipped to its newline).  Refused, never approximated: what the library refuses (x264hip_validate_parameters, the encoders' own
-checks) -- ABR / VBV / 2-pass, --direct auto / none, B frames or adaptive decisions with --no-cabac, interlaced, threads > 1, b-pyramid.
+checks) -- ABR / VBV / 2-pass, --direct none, B frames or adaptive decisions with --no-cabac, interlaced, threads > 1, b-pyramid.
 Scene cuts work as in the reference: by default after the fact (a P picture that should have been intra is coded again, encoder.c:1603-1699), with
 --pre-scenecut in the lookahead."""
 import argparse
@@ -264,7 +264,7 @@ def encode_streams(lib, p, sources, n_frames, sinks):
                 pays = enc.payloads()
                 for cd in out:
                     sinks[cd.chain].write(muxers[cd.chain].frame(frame=cd.frame, ftype=cd.type, qp=cd.qp, payload=pays[cd.chain], n_ref0=cd.n_ref0, n_ref1=cd.n_ref1,
-                                                                 direct_spatial=int(p.direct_mv_pred != 2), frame_num_reset=cd.frame_num_reset))
+                                                                 direct_spatial=cd.direct_spatial, frame_num_reset=cd.frame_num_reset))
                     coded += 1
     finally:
         enc.close()

@@ -62,6 +62,9 @@ def bind(lib):
     lib.x264hip_lookahead_set_cost.argtypes = [C.c_void_p] + [C.c_int] * 7
     lib.x264hip_lookahead_end.argtypes = [C.c_void_p]
     lib.x264hip_lookahead_scenecut.argtypes = [C.c_void_p]
+    lib.x264hip_lookahead_state_bytes.restype = C.c_size_t
+    lib.x264hip_lookahead_save.argtypes = [C.c_void_p, C.c_void_p]
+    lib.x264hip_lookahead_restore.argtypes = [C.c_void_p, C.c_void_p]
     lib.x264hip_lookahead_oldest_live.argtypes = [C.c_void_p]
     return lib
 
@@ -114,6 +117,15 @@ class Lookahead:
         if rc < 0:
             raise RuntimeError("x264hip_lookahead_scenecut: no P picture in flight")
         return rc
+
+    def save(self):
+        """A copy of the queue's state (x264hip_lookahead_save) to come back to with restore(), or None if it does not fit."""
+        if getattr(self, "_state", None) is None:
+            self._state = C.create_string_buffer(self.lib.x264hip_lookahead_state_bytes())
+        return self._state if self.lib.x264hip_lookahead_save(self.h, self._state) == 0 else None
+
+    def restore(self, state):
+        self.lib.x264hip_lookahead_restore(self.h, state)
 
     def oldest_live(self):
         return self.lib.x264hip_lookahead_oldest_live(self.h)

@@ -35,7 +35,7 @@ class MbState(C.Structure):
 class SliceB(C.Structure):
     """x264hip_slice_b: list 1 of a B slice and what direct prediction reads."""
     _fields_ = [("fref1", C.c_void_p), ("l1_state", C.c_void_p), ("ref1_poc", C.c_int), ("weightb", C.c_int), ("lowres_mv1", C.c_void_p),
-                ("direct_spatial", C.c_int)]
+                ("direct_spatial", C.c_int), ("direct_score", C.c_void_p)]
 
 
 class SliceRd(C.Structure):
@@ -200,10 +200,11 @@ class ChainEncoder:
         self._fenc = None              # the picture upload() fills: allocated on first use (a caller with its own source pictures never needs it)
         # B frames (disposable, one list-1 picture): encode_frame(src, stype, disp) in coding_order(); the DPB then holds
         # max(n_refs, 2) pictures (sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200)
-        if bframes and direct_pred not in (1, 2):
+        if bframes and direct_pred not in (1, 2) and not (direct_pred == 3 and getattr(self, "_direct_auto_ok", False)):
             # --direct auto picks a B frame's direct mode from running skip scores and evaluates BOTH modes in every macroblock (R/encoder/analyse.c:2476-2496,
             # encoder.c:113-118,1777-1790): pinned on the reference side (tests/test_cpu_mux.py, BASELINE config 4), not built in the kernel; --direct none neither
-            raise ValueError("direct_pred %d: spatial (1) and temporal (2) direct prediction are built; --direct auto / none are refused" % direct_pred)
+            raise ValueError("direct_pred %d: spatial (1) and temporal (2) direct prediction are built, --direct auto (3) in StreamEncoder (it needs the running "
+                             "skip scores of the stream's B frames); --direct none is refused" % direct_pred)
         self.bopt = dict(bframes=bframes, weightb=int(bool(weightb)), direct_spatial=int(direct_pred != 2))
         self.dpb = max(n_refs, 2 if bframes else 1)
         self.pool = [self.ctx.new_picture() for _ in range(self.dpb + 1)]

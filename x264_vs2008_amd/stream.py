@@ -32,7 +32,7 @@ class ChainSweep(C.Structure):
 
 class Coded:
     """What one chain coded in a step."""
-    __slots__ = ("chain", "frame", "type", "slice_type", "qp", "f_qpm", "poc", "n_ref0", "n_ref1", "i_satd", "frame_num_reset")
+    __slots__ = ("chain", "frame", "type", "slice_type", "qp", "f_qpm", "poc", "n_ref0", "n_ref1", "i_satd", "frame_num_reset", "direct_spatial")
 
     def __repr__(self):
         return "Coded(chain=%d frame=%d type=%d qp=%d poc=%d)" % (self.chain, self.frame, self.type, self.qp, self.poc)
@@ -45,6 +45,7 @@ class StreamEncoder(ChainEncoder):
         kw.setdefault("levels", False)
         if kw.get("lanes"):
             raise ValueError("StreamEncoder: the chains of a step already run side by side; lanes belong to the lock-step encoder")
+        self._direct_auto_ok = True                     # --direct auto: the running scores live here (c_dscore)
         super().__init__(lib, width, height, cqm, batch=batch, **kw)
         if not self.raster or not self.rd_opt["write"]:
             raise ValueError("StreamEncoder: the chain-table sweep is the raster variant with the entropy coder in the loop")
@@ -105,6 +106,13 @@ class StreamEncoder(ChainEncoder):
         self.flushing = False
         self.coded_now = [None] * B
         self.n_sweeps = 0
+        # --direct auto (h->mb.b_direct_auto_write): every B macroblock predicts both direct modes and credits each with the skip it would give
+        # (the sweep leaves the frame's two sums in dscore_dev); h->stat.i_direct_score, the running scores that pick the next B frame's mode
+        # (encoder.c:113-118) and decay as x264_encoder_frame_end lets them (:1777-1790), are kept per chain here
+        self.direct_auto = bool(self.bopt["bframes"] and kw.get("direct_pred", 1) == 3)
+        self.dscore_dev = DeviceArray(lib, (B, 2), np.int32) if self.direct_auto else None
+        self.c_dscore = [[0, 0] for _ in range(B)]
+        self._dscore_pending = []
         # Without --pre-scenecut the reference looks at every P frame AFTER coding it (x264_encoder_encode, encoder.c:1603-1699) and, if it finds a
         # scene cut, codes again: the picture as I / IDR, or the B picture before it as the P.  The decision is made from the sweep's own
         # statistics (x264hip_frame_stats + x264hip_scenecut_post), the queue surgery by the library (x264hip_lookahead_scenecut), the second
@@ -124,6 +132,11 @@ class StreamEncoder(ChainEncoder):
     def _prepare(self, fill):
         """The lookahead's part of one x264_encoder_encode call for every chain: a picture comes in (or the flush begins), the queues decide.
         Runs on the lookahead's stream; everything it launched has finished when it returns."""
+        self._put(fill)
+        return self._decide()
+
+    def _put(self, fill):
+        """The picture comes in (x264_encoder_encode up to the frame queue: copy, lowres planes, intra costs, adaptive quantisation)."""
         more = fill is not None and (self.n_frames is None or self.lb.fed < self.n_frames)
         if not more:
             self.flushing = True
@@ -132,6 +145,9 @@ class StreamEncoder(ChainEncoder):
             if self.look.frame_of_slot[self.look.slot(self.lb.fed)] in self._coding:
                 self.ctx.sync()
             self.lb.put(lambda pic, f: self._fill(fill, pic, f))
+
+    def _decide(self):
+        """The queues decide (x264_slicetype_decide, x264_rc_analyse_slice, x264_ratecontrol_start) with the cost kernel behind them."""
         frames = self.lb.get(self.flushing)
         self.src_ctx.sync()
         return frames
@@ -141,37 +157,61 @@ class StreamEncoder(ChainEncoder):
         Returns the list of Coded for the chains that coded a frame (empty while the B buffer fills; empty for good once flushed).
         With n_frames given to the constructor the next call's lookahead is prepared before this one returns (fill is then also asked
         for the following picture) and the flush starts by itself after n_frames pictures."""
+        # with n_frames known the next call's lookahead (picture in, costs, decisions) runs beside this call's sweep
         frames = self._prep if self._prep is not None else self._prepare(fill)
         self._prep = None
         self.coded_now = [None] * self.ctx.batch
-        pipelined = self.n_frames is not None and not self.post_scenecut
+        pipelined = self.n_frames is not None
         if not any(fr is not None for fr in frames):
             self._coding = set()
             if pipelined and not self.flushing:
                 self._prep = self._prepare(fill)
             return []
         out = self._sweep(frames)
-        if self.post_scenecut:
-            # x264_encoder_encode looks at the P picture it just coded (encoder.c:1603-1699) and, if an intra picture would have been as good, gives the
-            # attempt up and codes again -- the same picture as I / IDR or the B picture before it as the P -- inside the same call.  Here: wait for
-            # the sweep, ask (x264hip_frame_stats + x264hip_scenecut_post), and run the given-up chains again, until none is left.  Each round costs a whole
-            # frame time for a few chains: fine for a handful of streams, a reason to decide scene cuts in the lookahead (pre_scenecut = 1) for thousands.
-            done = [cd.chain for cd in out]
-            while True:
-                self.ctx.sync()
-                hits = self._scenecut_hits()
-                if not hits:
-                    break
-                for ci in hits:
-                    self._give_up(ci)
-                again = self.lb.get(self.flushing, only=hits)
-                self.src_ctx.sync()
-                redo = {cd.chain: cd for cd in self._sweep(again)}
-                out = [redo.get(cd.chain, cd) for cd in out]
-                self.n_given_up += len(hits)
-            self.lb.end(done)
+        if not self.post_scenecut:
+            if pipelined and not self.flushing:
+                self._prep = self._prepare(fill)        # beside the sweep just launched
+            return out
+        # x264_encoder_encode looks at the P picture it just coded (encoder.c:1603-1699) and, if an intra picture would have been as good, gives the
+        # attempt up and codes again -- the same picture as I / IDR or the B picture before it as the P -- inside the same call.  Here: wait for the
+        # sweep, ask (x264hip_frame_stats + x264hip_scenecut_post), and run the given-up chains again until none is left.  Each round costs a whole
+        # frame time for a few chains: fine for a handful of streams, a reason to decide scene cuts in the lookahead (pre_scenecut = 1) for thousands.
+        # The next call's lookahead does not wait for the verdicts: it runs ahead beside the sweep, on the assumption that nothing is given up,
+        # with a copy of the judged chains' queues to come back to (x264hip_lookahead_save / _restore).
+        done = [cd.chain for cd in out]
+        judged = sorted({ci for _, ci, _, _ in self._post})
+        saved = None
         if pipelined and not self.flushing:
-            self._prep = self._prepare(fill)            # beside the sweep just launched
+            saved = {ci: self.lb.chains[ci].save() for ci in judged}
+            if any(v is None for v in saved.values()):
+                saved = None
+        if saved is not None:
+            self.lb.end(done)
+            self._prep = self._prepare(fill)
+        redone = []
+        while True:
+            self.ctx.sync()
+            hits = self._scenecut_hits()
+            if not hits:
+                break
+            for ci in hits:
+                if saved is not None and ci not in redone:
+                    self.lb.chains[ci].restore(saved[ci])
+                self._give_up(ci)
+            redone += [ci for ci in hits if ci not in redone]
+            again = self.lb.get(self.flushing, only=hits)
+            self.src_ctx.sync()
+            redo = {cd.chain: cd for cd in self._sweep(again)}
+            out = [redo.get(cd.chain, cd) for cd in out]
+            self.n_given_up += len(hits)
+        if saved is None:
+            self.lb.end(done)
+        elif redone:                                    # their decisions for the next call were made on the wrong assumption: made again
+            self.lb.end(redone)
+            nxt = self.lb.get(self.flushing, only=redone)
+            self.src_ctx.sync()
+            for ci in redone:
+                self._prep[ci] = nxt[ci]
         return out
 
     def _sweep(self, frames):
@@ -179,6 +219,15 @@ class StreamEncoder(ChainEncoder):
         L, c, o, ro = self.lib, self.ctx, self.opt, self.rd_opt
         B = c.batch
         todo = [(ci, fr) for ci, fr in enumerate(frames) if fr is not None]
+        if self._dscore_pending:                        # the B frames of the last sweep: their skip sums join the running scores before the next mode is picked
+            c.sync()
+            fs, n_mb = self.dscore_dev.get(), c.dims.mb_w * c.dims.mb_h
+            for ci in self._dscore_pending:
+                sc = self.c_dscore[ci]
+                if sc[0] + sc[1] > n_mb:
+                    sc[0], sc[1] = sc[0] * 9 // 10, sc[1] * 9 // 10
+                sc[0] += int(fs[ci][0]); sc[1] += int(fs[ci][1])
+            self._dscore_pending = []
         keep = []                                       # everything the C call reads must outlive it
         entries = (ChainSweep * len(todo))()
         b = self.cqm.bufs
@@ -301,9 +350,14 @@ class StreamEncoder(ChainEncoder):
                      stale=rb["stale"].ptr, i_frame_stride=0)
         p.rd = C.addressof(rd)
         keep += [p, rd]
+        dsp = self.bopt["direct_spatial"]
         if stype == SLICE_B:
+            if self.direct_auto:                       # x264_slice_header_init, encoder.c:113-118
+                dsp = int(self.c_dscore[ci][1] > self.c_dscore[ci][0])
+                self._dscore_pending.append(ci)
             sb = SliceB(fref1=C.addressof(self.pool[refs1[0][0]]), l1_state=C.addressof(refs1[0][2]), ref1_poc=refs1[0][1],
-                        weightb=self.bopt["weightb"], direct_spatial=self.bopt["direct_spatial"], lowres_mv1=lw1)
+                        weightb=self.bopt["weightb"], direct_spatial=dsp, lowres_mv1=lw1,
+                        direct_score=self.dscore_dev.ptr if self.direct_auto else None)
             p.b = C.addressof(sb)
             keep.append(sb)
         for i, r in enumerate(refs):
@@ -317,6 +371,7 @@ class StreamEncoder(ChainEncoder):
         cd.chain, cd.frame, cd.type, cd.slice_type, cd.qp, cd.f_qpm, cd.poc = ci, fr.frame, fr.type, stype, qp, fr.f_qpm, poc
         cd.n_ref0, cd.n_ref1, cd.i_satd = len(refs), len(refs1), fr.i_satd
         cd.frame_num_reset = int(getattr(fr, "frame_num_reset", 0))
+        cd.direct_spatial = dsp
         self._undo[ci] = (list(refs_all), self.c_coded[ci])
         self.coded_now[ci] = cd
         if stype != SLICE_B:                           # kept: filtered below, then this chain's newest reference
@@ -354,7 +409,7 @@ class StreamEncoder(ChainEncoder):
         for pair in self.aq_slots or []:
             for a in pair:
                 a.free()
-        for a in [self.tab_dev] + self.elems_dev + (self.stats_dev or []):
+        for a in [self.tab_dev] + self.elems_dev + (self.stats_dev or []) + ([self.dscore_dev] if self.dscore_dev else []):
             a.free()
         if self.tab_host:
             self.lib.x264hip_host_free(C.c_void_p(self.tab_host))

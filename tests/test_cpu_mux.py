@@ -115,7 +115,7 @@ def test_med_stream_md5_around_the_reference_encoder(hip_lib_host, cfg):
 def test_c4_slow_stream_md5s_around_the_reference_encoder(hip_lib_host):
     """BASELINE config 4's flag set (SLOW: 5 references, b-adapt 2, UMH, subme 8, --direct auto) on hd24, with and without --pre-scenecut: the
     harness (with --direct auto's running scores, x264_encoder_frame_end's part of them restated in ref_slice.c) inside this library's headers
-    has the md5 of both files the reference command line wrote.  The PRODUCT refuses --direct auto: this pins the reference side
+    has the md5 of both files the reference command line wrote (the product's own: tests/test_gpu_mux.py::test_c4_slow_stream_md5): this pins the reference side
     and the B slice header's direct_spatial_mv_pred bit, which changes from frame to frame here."""
     lib = hip_lib_host
     p = mux.encoder_params(lib, width=1920, height=1080, pre_scenecut=1, **M.SLOW)

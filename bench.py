@@ -53,6 +53,7 @@ from x264_vs2008_amd import slice as sl  # noqa: E402
 from x264_vs2008_amd.frame import cqm_init  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DIRECT_NAMES = {0: "none", 1: "spatial", 2: "temporal", 3: "auto"}
 ME_NAMES = {0: "dia", 1: "hex", 2: "umh", 3: "esa"}
 CAPTURE = 1 << 20          # bytes of chain 0's payload copied out per step for the parity check
 
@@ -68,7 +69,7 @@ def rd_options(args):
     """What the raster-order variant adds (x264hip_slice_rd)."""
     o = dict(trellis=args.trellis, psy_rd=args.psy_rd, aq_mode=args.aq_mode, aq_strength=1.0)
     if args.bframes:
-        o.update(bframes=args.bframes, weightb=args.weightb, direct_pred=1)
+        o.update(bframes=args.bframes, weightb=args.weightb, direct_pred=getattr(args, "direct", 1))
     return o
 
 
@@ -397,10 +398,10 @@ def run_stream(args, hip, dist, json_fd, rank, world, B, g_first, g_step, cpu, r
         what = ("%dx%d streams (one per chain, segments of one synthetic clip) through x264_encoder_encode's path on the GPU: pictures synthesised on the device, "
                 "x264_frame_init_lowres + lookahead costs (x264_slicetype_frame_cost, one wavefront per task) feeding the library's x264_slicetype_decide / x264_ratecontrol_start "
                 "(host C), then the per-macroblock loop in raster order (one wavefront per chain: cache_load, x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, "
-                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct spatial --me %s "
+                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct %s --me %s "
                 "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d%s, chroma ME, fast "
                 "P-skip, dct-decimate, CABAC; payload bytes stay on the device (the host downloads them and writes the headers around them: x264_vs2008_amd/mux.py)"
-                % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
+                % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, DIRECT_NAMES[args.direct], ME_NAMES[args.me], args.subme, args.trellis, args.psy_rd, args.aq_mode,
                    args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, psc))
         # Default: BASELINE.md's MED as it stands -- no --pre-scenecut: x264_encoder_encode's look at every coded P frame (the post-encode scene cut) is
         # evaluated from the sweep's statistics every step; a hit would be coded again inside the step (StreamEncoder), and this clip has none.
@@ -546,11 +547,11 @@ def run_stream_async(args, hip, dist, json_fd, rank, world, B, g_first, g_step, 
         what = ("%dx%d streams (one per chain, segments of one synthetic clip) through x264_encoder_encode's path on the GPU: pictures synthesised on the device, "
                 "x264_frame_init_lowres + lookahead costs (x264_slicetype_frame_cost, one wavefront per task) feeding the library's x264_slicetype_decide / x264_ratecontrol_start "
                 "(host C), then the per-macroblock loop in raster order (one wavefront per chain: cache_load, x264_macroblock_analyse with RD mode decision, x264_macroblock_encode, "
-                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct spatial --me %s "
+                "x264_macroblock_write_cabac, cache_save), deblock, borders, half-pel planes; --crf %.1f --ref %d --bframes %d --b-adapt %d --weightb --direct %s --me %s "
                 "--subme %d --trellis %d --psy-rd %.1f --aq-mode %d --8x8dct %d --mixed-refs %d --partitions 0x%x/0x%x --keyint %d --scenecut %d --pre-scenecut, chroma ME, fast "
                 "P-skip, dct-decimate, CABAC; payload bytes stay on the device (slice / NAL headers and the download are the host's).  No global step: a host scheduler launches "
                 "every chain's next frame as soon as that chain's own kernel has finished; warm-up = %d frames of every chain, timed = the next %d frames of every chain, the "
-                "device drained before and after" % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, ME_NAMES[args.me], args.subme, args.trellis,
+                "device drained before and after" % (args.width, args.height, args.crf, args.refs, args.bframes, args.b_adapt, DIRECT_NAMES[args.direct], ME_NAMES[args.me], args.subme, args.trellis,
                                                       args.psy_rd, args.aq_mode, args.dct8, args.mixed_refs, args.inter, args.intra, args.keyint, args.scenecut, args.warmup, args.steps))
         # the flag set is BASELINE.md's MED with --pre-scenecut ON BOTH SIDES (GPU and the reference leg): the reference forces that flag itself with
         # --threads > 1, and BASELINE.md prescribes it for GOP-sharded runs; the scene cut that re-encodes a frame is the only thing it replaces
@@ -609,7 +610,8 @@ def main():
     ap.add_argument("--preset", default="hd", choices=["hd", "uhd", "slow", "cif"], help="cif: BASELINE config 0 (352x288, the UF flag set: --qp 26 --no-cabac --me dia --subme 0 --partitions none "
                     "--no-deblock --ref 1 --bframes 0, lock-step I / P chains in the wavefront variant, payload from the CAVLC writer, parity-checked); "
                     "hd: BASELINE config 1 (1920x1080, hex); uhd: config 2 (3840x2160, --me umh); slow: config 4's flag set on "
-                    "one GPU (1920x1080, --ref 5 --b-adapt 2 --me umh --subme 8, --direct spatial --pre-scenecut as BASELINE.md prescribes for sharded runs)")
+                    "one GPU as BASELINE.md states it (1920x1080, --ref 5 --b-adapt 2 --me umh --subme 8 --direct auto, the post-encode scene cut)")
+    ap.add_argument("--direct", type=int, default=1, help="param.analyse.i_direct_mv_pred: 1 spatial, 2 temporal, 3 auto (stream mode; --preset slow sets it)")
     ap.add_argument("--wavefront", type=int, default=0, help="1: round 1's configuration (wavefront schedule, subme 5, no RD / trellis / AQ / entropy coding)")
     ap.add_argument("--trellis", type=int, default=1)
     ap.add_argument("--bframes", type=int, default=-1, help="disposable B frames between anchors, fixed pattern (-1: 3 for the raster variant = the medium "
@@ -672,6 +674,7 @@ def main():
     wf = bool(args.wavefront)
     uhd, slow = args.preset == "uhd", args.preset == "slow"
     if slow:
+        args.direct = 3 if args.direct == 1 else args.direct       # SLOW as BASELINE.md states it: --direct auto (the running skip scores of every chain's B frames)
         args.refs = 5 if args.refs == 3 else args.refs
         args.b_adapt = 2 if args.b_adapt == 1 else args.b_adapt
         args.subme = args.subme or 8

@@ -37,15 +37,14 @@ def reference_uf(w, h, n):
 
 
 def reference_med(p, w, h, n, t0=0):
-    """The reference's whole encoder (oracle/ref_slice.c refslice_encode_stream) with the validated parameters p.  The harness only has the
-    pre-encode scene cut; BASELINE's MED runs have the post-encode one -- neither fires on these clips, so the frames are the same and only
-    the SEI text differs (it is written from p, which says scenecut=40 without "(pre)")."""
+    """The reference's whole encoder (oracle/ref_slice.c refslice_encode_stream) with the validated parameters p -- the post-encode scene cut
+    included (BASELINE's runs have it: no --pre-scenecut; it never fires on those clips)."""
     from oracle import refslice as rs
     y, u, v = rs.clip(w, h, n, t0)
     rp = rs.make_params(w, h, n, qp=p.qp_constant, me_method=p.me_method, me_range=p.me_range, subme=p.subpel_refine, n_refs=p.frame_reference, inter=p.inter,
                         intra=p.intra, transform8x8=p.transform_8x8, cabac=p.cabac, deblock=p.deblocking_filter, keyint=p.keyint_max, mixed_refs=p.mixed_references,
                         chroma_me=p.chroma_me, mv_range=p.mv_range)
-    e = rs.make_ext(bframes=p.bframe, b_adapt=p.bframe_adaptive, pre_scenecut=1, scenecut_threshold=p.scenecut_threshold, keyint_min=p.keyint_min, crf=p.rf_constant,
+    e = rs.make_ext(bframes=p.bframe, b_adapt=p.bframe_adaptive, pre_scenecut=p.pre_scenecut, scenecut_threshold=p.scenecut_threshold, keyint_min=p.keyint_min, crf=p.rf_constant,
                     bframe_bias=p.bframe_bias, weightb=p.weighted_bipred, aq_mode=p.aq_mode, aq_strength=p.aq_strength, trellis=p.trellis, psy_rd=p.psy_rd,
                     direct_pred=p.direct_mv_pred)
     return rs.run_reference_stream(rp, e, y, u, v)

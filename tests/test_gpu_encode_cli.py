@@ -54,6 +54,23 @@ def test_cli_two_inputs_side_by_side_equal_the_reference_encoder(hip_lib, tmp_pa
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+def test_cli_slow_flag_set_with_direct_auto(hip_lib, tmp_path):
+    """BASELINE's SLOW flag set through the command line on a small clip: b-adapt 2, UMH, subme 8, five references, --direct auto (the B slice
+    headers' direct_spatial_mv_pred bit follows the running scores), the post-encode scene cut -- the file equals the reference encoder's + headers."""
+    w, h, n = 176, 96, 16
+    src, out = str(tmp_path / "in.y4m"), str(tmp_path / "o.264")
+    write_clip(src, w, h, n, t0=17, y4m=True)
+    args = "--crf 23 --ref 5 --bframes 3 --b-adapt 2 --me umh --subme 8 --8x8dct --partitions p8x8,b8x8,i8x8,i4x4 --trellis 1 --weightb --mixed-refs --direct auto"
+    assert E.main(args.split() + ["-o", out, src]) == 0
+    o = E.build_parser().parse_args(args.split() + ["-o", "x", src])
+    p = mux.encoder_params(hip_lib, width=w, height=h, fps_num=25, fps_den=1, **E.param_fields(o))
+    a = M.reference_med(p, w, h, n, t0=17)
+    want = M.mux_reference_stream(hip_lib, p, a, n)
+    got = open(out, "rb").read()
+    assert got == want, "%d vs %d bytes" % (len(got), len(want))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
 def test_cli_constant_qp_cabac_without_a_frame_queue(hip_lib, tmp_path):
     """--qp N --scenecut -1 --bframes 0: nothing for x264_slicetype_decide to decide -- the lock-step encoder (raster variant, CABAC in the loop,
     an IDR every --keyint frames) against the reference's loop + this library's headers; trellis, deblock offsets and a second IDR included."""

@@ -12,16 +12,8 @@ hip = L.load()
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(first, first + count):
-    r = np.random.default_rng(77000 + seed)
-    c = T.random_config(seed)
-    c.update(pre_scenecut=int(r.random() < 0.4), scenecut_threshold=int(r.choice([40, 40, 60, -1])), direct_pred=int(r.choice([1, 2, 3, 3])),
-             bframes=int(r.choice([0, 1, 2, 3])), b_adapt=int(r.choice([0, 1, 2])), cut=int(r.choice([0, 4, 7])))
-    if c["bframes"] == 0:
-        c["b_adapt"] = 0
-    if c["subme"] == 8 and c["bframes"] and c["inter"] & 0x20:
-        c["inter"] &= ~0x20
-    cs = [dict(c), dict(c, t0=c["t0"] + 61, slow=1 + (c["slow"] % 3), cut=max(c["cut"] - 2, 0))]
-    pipe = bool(r.random() < 0.5)
+    cs, pipe = T.mixed_config(seed)
+    c = cs[0]
     what = "seed %d pipe %d %s" % (seed, pipe, {k: c[k] for k in ("w", "h", "frames", "subme", "n_refs", "bframes", "b_adapt", "crf", "trellis", "direct_pred", "aq", "inter", "pre_scenecut", "scenecut_threshold", "cut", "keyint")})
     try:
         got = T.run_stream(hip, cs, pipeline=pipe)

@@ -245,3 +245,33 @@ def test_stream_direct_auto_equals_reference(hip_lib, seed):
                 modes.add(int(a["frame_info2"][f][3]))
                 assert run_stream.direct_spatial[i][f] == int(a["frame_info2"][f][3]), "seed %d chain %d coded frame %d: direct mode" % (seed, i, f)
     assert n_b > 0
+
+
+def mixed_config(seed):
+    """Two chains of a seeded configuration over round 3's additions on top of random_config: --direct auto / temporal / spatial, the post- or pre-encode scene
+    cut (or none), B patterns fixed / b-adapt 1 / 2, clips with and without scene changes; and whether the encoder runs its lookahead ahead (pipeline)."""
+    r = np.random.default_rng(77000 + seed)
+    c = random_config(seed)
+    c.update(pre_scenecut=int(r.random() < 0.4), scenecut_threshold=int(r.choice([40, 40, 60, -1])), direct_pred=int(r.choice([1, 2, 3, 3])),
+             bframes=int(r.choice([0, 1, 2, 3])), b_adapt=int(r.choice([0, 1, 2])), cut=int(r.choice([0, 4, 7])))
+    if c["bframes"] == 0:
+        c["b_adapt"] = 0
+    if c["subme"] == 8 and c["bframes"] and c["inter"] & 0x20:
+        c["inter"] &= ~0x20
+    cs = [dict(c), dict(c, t0=c["t0"] + 61, slow=1 + (c["slow"] % 3), cut=max(c["cut"] - 2, 0))]
+    return cs, bool(r.random() < 0.5)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libx264ref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [67, 68, 69, 91, 93, 99, 122, 139, 160, 203, 227, 238])
+def test_stream_mixed_round3_options_equal_reference(hip_lib, seed):
+    """Seeds of scratch/fuzz_stream_new.py (760 configurations equal) that combine --direct auto with given-up P pictures, with and without the lookahead
+    running ahead of the verdicts: order, types, QPs, payloads and every B slice's direct mode against the reference's encoder."""
+    cs, pipe = mixed_config(seed)
+    got = run_stream(hip_lib, cs, pipeline=pipe)
+    for i, ck in enumerate(cs):
+        a = K.reference_records(ck)
+        check(got[i], a, ck, "seed %d chain %d" % (seed, i))
+        for f in range(ck["frames"]):
+            if int(a["frame_info"][f][0]) == rs.SLICE_B:
+                assert run_stream.direct_spatial[i][f] == int(a["frame_info2"][f][3]), "seed %d chain %d coded frame %d: direct mode" % (seed, i, f)

@@ -279,6 +279,8 @@ def main(argv=None):
     if any((s.w, s.h) != (w, h) for s in sources):
         raise SystemExit("encode: all inputs must have the same picture size")
     n = min(s.n for s in sources)
+    if any(s.n != n for s in sources):             # the chains of a batch take their pictures in lock step: every stream ends with the shortest input
+        print("encode: inputs of different lengths (%s frames): every stream is coded up to the shortest, %d frames" % (", ".join(str(s.n) for s in sources), n), file=sys.stderr)
     if o.frames > 0:
         n = min(n, o.frames)
     if n < 1:

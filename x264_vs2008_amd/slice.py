@@ -202,7 +202,7 @@ class ChainEncoder:
         # max(n_refs, 2) pictures (sps->vui.i_max_dec_frame_buffering, R/encoder/set.c:196-200)
         if bframes and direct_pred not in (1, 2) and not (direct_pred == 3 and getattr(self, "_direct_auto_ok", False)):
             # --direct auto picks a B frame's direct mode from running skip scores and evaluates BOTH modes in every macroblock (R/encoder/analyse.c:2476-2496,
-            # encoder.c:113-118,1777-1790): pinned on the reference side (tests/test_cpu_mux.py, BASELINE config 4), not built in the kernel; --direct none neither
+            # encoder.c:113-118,1777-1790): the running scores are the stream encoder's (stream.py: x264hip_slice_b.direct_score); --direct none is not built
             raise ValueError("direct_pred %d: spatial (1) and temporal (2) direct prediction are built, --direct auto (3) in StreamEncoder (it needs the running "
                              "skip scores of the stream's B frames); --direct none is refused" % direct_pred)
         self.bopt = dict(bframes=bframes, weightb=int(bool(weightb)), direct_spatial=int(direct_pred != 2))

@@ -116,8 +116,13 @@ CONFIGS = {
     "badapt2_crf_rd": dict(w=112, h=96, frames=13, bframes=2, b_adapt=2, crf=28.0, subme=7, me=2, weightb=0, aq=0, n_refs=3, mixed_refs=1, trellis=1, inter=0x13),
     "scenecut_cqp": dict(w=96, h=80, frames=12, bframes=0, b_adapt=0, crf=None, subme=6, me=1, weightb=0, aq=1, keyint=8, inter=0x13),
     "temporal_crf": dict(w=128, h=80, frames=12, bframes=1, b_adapt=1, crf=20.0, subme=4, me=0, weightb=1, aq=0, direct_pred=2),
+    # the reference's default scene cut (after the encode: given-up P pictures coded again, queues rearranged) and --direct auto: fixtures, so that
+    # both are held to the reference where oracle/_ref is not built too
+    "postsc_crf": dict(w=112, h=96, frames=13, bframes=2, b_adapt=1, crf=24.0, subme=5, me=1, weightb=1, aq=1, n_refs=2, inter=0x13, pre_scenecut=0),
+    "direct_auto_crf": dict(w=128, h=96, frames=13, bframes=3, b_adapt=1, crf=22.0, subme=6, me=1, weightb=1, aq=0, n_refs=2, inter=0x113, direct_pred=3),
 }
-SEEDS = {"badapt1_crf_aq": [0, 3, 9], "badapt2_crf_rd": [4, 7], "scenecut_cqp": [5, 11, 12], "temporal_crf": [1, 6]}
+SEEDS = {"badapt1_crf_aq": [0, 3, 9], "badapt2_crf_rd": [4, 7], "scenecut_cqp": [5, 11, 12], "temporal_crf": [1, 6], "postsc_crf": [4, 13, 20], "direct_auto_crf": [3, 21]}
+STEP_ONLY = {"postsc_crf", "direct_auto_crf"}          # (the step-less scheduler keeps neither the verdict loop nor the running scores)
 
 
 def chains(name, seeds):
@@ -139,9 +144,12 @@ def test_stream_equals_reference_fixture(hip_lib, name, pipeline):
     for i, c in enumerate(cs):
         a = {k: gold["c%d_%s" % (i, k)] for k in ("frame_info", "frame_info2", "payload", "payload_len")}
         check(got[i], a, c, "%s chain %d" % (name, i))
+        for f in range(c["frames"]):                     # a B slice header's direct_spatial_mv_pred (--direct auto: it follows the running scores)
+            if int(a["frame_info"][f][0]) == rs.SLICE_B:
+                assert run_stream.direct_spatial[i][f] == int(a["frame_info2"][f][3]), "%s chain %d coded frame %d: direct mode" % (name, i, f)
 
 
-@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("name", sorted(set(CONFIGS) - STEP_ONLY))
 def test_async_stream_equals_reference_fixture(hip_lib, name):
     """Chains stepping on their own (AsyncStreamEncoder): each chain's frames, in its coding order, are the lock-step encoder's and the reference's."""
     gold = np.load(os.path.join(ROOT, "tests", "golden", "stream_%s.npz" % name))

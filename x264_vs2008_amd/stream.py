@@ -477,6 +477,8 @@ class AsyncStreamEncoder(StreamEncoder):
         self.launch_sizes = []
         if self.post_scenecut:
             raise ValueError("AsyncStreamEncoder: the post-encode scene cut's check is made per step (StreamEncoder); run with pre_scenecut=1")
+        if self.direct_auto:
+            raise ValueError("AsyncStreamEncoder: --direct auto's running scores are kept per step (StreamEncoder)")
 
     def _bufs_of(self, ci):
         return self.rd_bufs_alt if self.c_coded[ci] & 1 else self.rd_bufs
